@@ -1,0 +1,62 @@
+"""Shared helpers for the test-suite: golden fixture loading and oracle construction."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, 'golden')
+
+ALL_CASES = ['c1_int', 'c2a_int', 'c2b_sep', 'c3_sep', 'c3_int', 'c5_sep', 'c5_int', 'misc_grid', 'misc_sep',
+             'misc_family_hermite_e', 'misc_family_hermite', 'misc_family_power_series',
+             'misc_family_chebyshev', 'misc_family_laguerre', 'misc_family_legendre']
+INTEGRATED = [c for c in ALL_CASES if c.endswith('_int') or c == 'misc_grid' or c.startswith('misc_family')]
+SEPARABLE = ['c2b_sep', 'c3_sep', 'c5_sep', 'misc_sep']
+
+
+def load_case(name):
+    npz = dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+    with open(os.path.join(GOLDEN, name + '.json')) as f:
+        desc = json.load(f)
+    return npz, desc
+
+
+def case_X(name, npz):
+    """Raw training samples of a fixture (regenerated from the seeded sampler when
+    they were too big to commit)."""
+    if 'X' in npz:
+        return npz['X']
+    from triangular_transport_toolbox_amd import specs
+    if name == 'c5_sep':
+        return specs.sample_mixture(int(npz['N']))
+    if name == 'ex01_order10':
+        return specs.sample_spiral(int(npz['N']), seed=0)
+    raise KeyError(name)
+
+
+def ctor_kwargs(desc):
+    kw = dict(desc['kwargs'])
+    kw['quadrature_input'] = dict(kw['quadrature_input'])
+    return kw
+
+
+def coeff_lists(npz, D, prefix=''):
+    return ([npz['%scoeffs_mon_%d' % (prefix, k)] for k in range(D)],
+            [npz['%scoeffs_nonmon_%d' % (prefix, k)] for k in range(D)])
+
+
+def make_oracle(name, npz=None, desc=None, X=None):
+    from oracle.ttm_oracle import OracleMap
+    if npz is None:
+        npz, desc = load_case(name)
+    if X is None:
+        X = case_X(name, npz)
+    om = OracleMap(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], **ctor_kwargs(desc))
+    if 'coeffs_mon_0' in npz:
+        om.coeffs_mon, om.coeffs_nonmon = coeff_lists(npz, om.D)
+    return om
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1.0))) if a.size else 0.0
