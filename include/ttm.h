@@ -1,0 +1,206 @@
+/*
+ * ttm.h - C ABI of the MI355X-native triangular-transport-map engine (libttm.so).
+ *
+ * The reference (MaxRamgraber/Triangular-Transport-Toolbox, transport_map.py,
+ * "TM" below) has no FFI / plugin boundary: its hot path is NumPy code behind
+ * the Python class `transport_map`.  This header is the boundary the build adds
+ * beneath that class.  Every entry point names the reference routine whose
+ * per-sample arithmetic it replaces (file:line into /root/reference).
+ * `triangular_transport_toolbox_amd/_capi.py` binds it with ctypes; the same
+ * stub is what a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; all array arguments are DEVICE pointers unless the
+ *    name starts with h_ (host); the caller owns every buffer (PyTorch-ROCm is
+ *    the allocator in the Python host, any hipMalloc'ed memory works);
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); no entry
+ *    point synchronises, allocates or frees: all are graph-capturable;
+ *  - every function returns 0 on success, a negative TTM_E_* code otherwise;
+ *    ttm_last_error_string() describes the last failure of the calling thread;
+ *    no exception crosses the boundary;
+ *  - sample matrices are column-major on the device ("SoA": column j of an
+ *    N-sample ensemble starts at X + j*ldx, ldx >= N), fp64 throughout;
+ *  - handles do not exist: a map is described by a `ttm_program` value (plain
+ *    struct of sizes, small host tables and device table pointers) compiled by
+ *    the host from the reference's `monotone` / `nonmonotone` lists.
+ */
+#ifndef TTM_H
+#define TTM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTM_VERSION 100
+
+/* error codes */
+#define TTM_OK            0
+#define TTM_E_ARG        -1   /* invalid argument (shape, range, null pointer) */
+#define TTM_E_HIP        -2   /* a HIP runtime call failed */
+#define TTM_E_LIMIT      -3   /* program does not fit the kernel's LDS budget */
+#define TTM_E_UNSUPPORTED -4
+
+/* factor kinds (term tables) */
+#define TTM_KIND_POLY 1      /* P_n(x), polynomial family of the program            (TM:1099-1144) */
+#define TTM_KIND_HF   2      /* a_n P_n(x) exp(-x^2/4), normalised Hermite function (TM:1102-1150) */
+#define TTM_KIND_LET  3      /* left edge term                                      (TM:917-937)   */
+#define TTM_KIND_RET  4      /* right edge term                                     (TM:943-963)   */
+#define TTM_KIND_RBF  5      /* radial basis function                               (TM:969-989)   */
+#define TTM_KIND_IRBF 6      /* integrated radial basis function                    (TM:995-1016)  */
+
+/* polynomial families (TM:274-304) */
+#define TTM_FAM_HERMITE_E 0
+#define TTM_FAM_POWER     1
+#define TTM_FAM_HERMITE   2
+#define TTM_FAM_CHEBYSHEV 3
+#define TTM_FAM_LAGUERRE  4
+#define TTM_FAM_LEGENDRE  5
+
+/* monotonicity (TM:260-263) */
+#define TTM_MONO_INTEGRATED 0
+#define TTM_MONO_SEPARABLE  1
+
+/* rectifiers (TM:4981-5018) */
+#define TTM_RECT_EXPONENTIAL 0
+#define TTM_RECT_SOFTPLUS    1
+#define TTM_RECT_SQUARED     2
+#define TTM_RECT_EXPNEG      3
+#define TTM_RECT_ELU         4
+
+/* int32 layout of one component block inside ttm_program.itab
+ * (block k spans itab[h_comp_off[k] .. h_comp_off[k+1]) ):
+ *   header  : TTM_HDR_LEN int32
+ *   terms   : 4 int32 each  {f0, nf, b, ci}        nonmonotone terms, then monotone terms
+ *   factors : 4 int32 each  {var, kind, order, p0}  factors on columns other than kc
+ *   bfuns   : 4 int32 each  {kind, order, p0, 0}    distinct functions of x_kc alone, ordered
+ *                                                   [HF by order][POLY by order][special terms]
+ * f0 indexes the component's factor list, b its bfun list (-1: term has no x_kc
+ * factor), ci the coefficient inside coeffs_nonmon[k] / coeffs_mon[k], p0 the
+ * component's slice of dpar (HF: a_n ; special term: centre, scale). */
+#define TTM_HDR_LEN      16
+#define TTM_HDR_KC        0   /* column of x_k in the sample matrix (k + skip_dimensions) */
+#define TTM_HDR_N_NM      1
+#define TTM_HDR_OFF_NM    2
+#define TTM_HDR_N_MON     3
+#define TTM_HDR_OFF_MON   4
+#define TTM_HDR_OFF_FAC   5
+#define TTM_HDR_NB        6
+#define TTM_HDR_OFF_B     7
+#define TTM_HDR_NB_HF     8
+#define TTM_HDR_NB_POLY   9
+#define TTM_HDR_NB_ST    10
+#define TTM_HDR_MAXP_HF  11
+#define TTM_HDR_MAXP_POLY 12
+#define TTM_HDR_FLAGS    13   /* bit0: every monotone term is a function of x_kc alone */
+#define TTM_HDR_N_DPAR   14   /* doubles of dpar owned by this component                      */
+#define TTM_HDR_LEN_BLK  15   /* int32 length of this component block (header included)      */
+
+typedef struct ttm_program {
+    /* device tables */
+    const int32_t* itab;        /* all component blocks, back to back              */
+    const double*  dpar;        /* HF constants and special-term (centre, scale)   */
+    const double*  quad_x;      /* Gauss-Legendre nodes   (TM:199-225), length Q   */
+    const double*  quad_w;      /* Gauss-Legendre weights,               length Q   */
+    /* host tables, length D+1 each (prefix offsets per component) */
+    const int32_t* h_comp_off;  /* into itab                                       */
+    const int32_t* h_dpar_off;  /* into dpar                                       */
+    const int32_t* h_coef_off;  /* into the coefficient vector [nonmon_k | mon_k]  */
+    const int32_t* h_nslots;    /* length D: nB+1, per-sample scratch words needed */
+    const int32_t* h_n_nm;      /* length D: number of nonmonotone terms           */
+    int32_t D;                  /* number of map components (len(monotone))        */
+    int32_t d_cols;             /* columns of the sample matrix (skip + D)         */
+    int32_t family;             /* TTM_FAM_*                                       */
+    int32_t monotonicity;       /* TTM_MONO_*                                      */
+    int32_t rectifier;          /* TTM_RECT_*                                      */
+    int32_t Q;                  /* quadrature order                                */
+    double  delta;              /* TM:34, added to the rectifier / to dS           */
+} ttm_program;
+
+const char* ttm_last_error_string(void);
+int  ttm_version(void);
+/* number of visible HIP devices; 0 with an error string when there is none */
+int  ttm_device_count(int* count);
+
+/* ---- K0/K1: layout change + (de)standardisation ----------------------------
+ * TM:750-787 standardize(); TM:2413-2417, 3701-3704, 3721-3724 inline affine maps.
+ * ttm_colstats: mean and ddof-0 standard deviation of every column of a
+ *   row-major N x d host-layout matrix resident on the device.
+ *   work: >= ttm_colstats_work_size(N, d) doubles.
+ * ttm_import:  Xsoa[j*ldx + n] = (Xrow[n*d + j] - mean[j]) / std[j]   (mean/std NULL: plain transpose)
+ * ttm_export:  Xrow[n*dout + j] = Xsoa[(j0+j)*ldx + n] * std[j0+j] + mean[j0+j]          */
+int64_t ttm_colstats_work_size(int64_t N, int32_t d);
+int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double* std,
+                 double* work, void* stream);
+int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, const double* std,
+               double* Xsoa, int64_t ldx, void* stream);
+int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t dout,
+               const double* mean, const double* std, double* Xrow, void* stream);
+
+/* ---- K2/K3: forward map ------------------------------------------------------
+ * TM:2391-2437 map(), TM:2439-2567 s(), TM:4238-4258 GaussQuadrature (fused),
+ * TM:4981-5018 rectifier.evaluate; log-determinant part of TM:2618-2641 / 2686-2709.
+ * Z[(k-k0)*ldz + n] = S_k(x_n) for k in [k0,k1).  Z may be NULL (derivative only).
+ * logdet (nullable, length N): sum_k log( (dS_k/dx_k) / sigma[k-k0] )  (sigma NULL: no division)
+ * sumsq  (nullable, length N): sum_k S_k(x_n)^2, the Mahalanobis part of TM:2681-2684.            */
+int ttm_forward(const ttm_program* p, const double* coef, const double* Xsoa, int64_t ldx, int64_t N,
+                int32_t k0, int32_t k1, double* Zsoa, int64_t ldz,
+                double* logdet, const double* sigma, double* sumsq, void* stream);
+
+/* ---- basis matrices (inspection / tests) -------------------------------------
+ * TM:1498-1575 fun_mon / fun_nonmon, TM:2047-2120 der_fun_mon for component k.
+ * which: 0 = Psi_nonmon, 1 = Psi_mon, 2 = dPsi_mon/dx_k.  out[i*ldo + n].                        */
+int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa, int64_t ldx,
+              int64_t N, double* out, int64_t ldo, void* stream);
+
+/* ---- K4: table ("alternate") inverse, separable maps ---------------------------
+ * TM:3987-4084 vectorized_root_search_alternate + the k-loop of TM:3639-3796.
+ * ttm_inverse_table_build: out[(k-k0)*T + i] = Psi_mon_k(0,..,pts[i],..,0) . c_mon_k   (TM:4047-4058)
+ * ttm_inverse_table: for k in [k0,k1) sequentially: offset = Psi_nonmon_k(x) . c_nonmon_k,
+ *   target = clip(-offset + Z_k, tmin_k, tmax_k) (if truncate), x_k = lerp on (tab_x, tab_y) with
+ *   scipy.interpolate.interp1d semantics (searchsorted-left, clip to [1,T-1], slope form).
+ *   tab_x/tab_y: (k1-k0) x T, tab_x non-decreasing (the host applies interp1d's stable sort).
+ *   Xsoa holds the conditioning columns on entry and receives column kc of every component.       */
+int ttm_inverse_table_build(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+                            const double* pts, int32_t T, double* out, void* stream);
+int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+                      const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
+                      const double* tab_x, const double* tab_y, int32_t T,
+                      const double* tmin, const double* tmax, int32_t truncate, void* stream);
+
+/* ---- K5: bisection inverse (both monotonicity modes) -----------------------------
+ * TM:3798-3985 vectorized_root_search_bisection, exact bracket / window-shift / midpoint
+ * sequence per sample (start_distance 2, threshold 1e-9, max_iterations 100).
+ * iters (int32, length k1-k0, zero-initialised by the caller): receives the maximum midpoint-
+ *   iteration count over the processed samples (atomic max).
+ * cap (nullable, int32, length k1-k0): when given, every sample stops after cap[k-k0] midpoint
+ *   iterations - used to replay global sample 0 under the reference's `np.sum(indices) > 0`
+ *   loop guard (TM:3952).                                                                          */
+int ttm_inverse_bisect(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
+                       int32_t* iters, const int32_t* cap, void* stream);
+
+/* ---- K6/K7: objective + gradient reductions for optimize() -------------------------
+ * integrated: TM:3300-3376 objective_function, TM:3435-3569 objective_function_jacobian
+ *   out[0] = sum_n ( S^2/2 - log(r(g)+delta) ), out[1..] = sum_n d/dc of the same, [nonmon | mon]
+ * separable : inner loop of TM:2978-3018 fun_mon_objective
+ *   out[0] = sum_n log dS_n, out[1+i] = sum_n dPsi_{n,i}/dS_n, dS = dPsi.c + delta*rowsum(dPsi)
+ * (regularisation, 1/N and the A-matrix terms are O(m) host arithmetic).
+ * coef_k: device vector [nonmon_k | mon_k] for this component (the trial point).
+ * work: >= ttm_reduce_work_size(nout) doubles.  out: device, nout doubles.                        */
+int64_t ttm_reduce_work_size(int32_t nout);
+int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* Xsoa,
+                  int64_t ldx, int64_t N, double* work, double* out, void* stream);
+
+/* ---- K8: Gram matrix of [Psi_nonmon | Psi_mon] -------------------------------------
+ * replaces the N x m passes of TM:2966-2975 (QR projection) and TM:3031-3050 (L2 normal
+ * equations): out[i*m + j] = sum_n Psi_{n,i} Psi_{n,j}, m = n_nonmon + n_mon (full symmetric).
+ * work: >= ttm_reduce_work_size(m*m) doubles.                                                      */
+int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N,
+             double* work, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTM_H */

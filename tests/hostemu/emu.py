@@ -1,0 +1,143 @@
+"""
+TEST INFRASTRUCTURE: a host test double of libttm.so.
+
+tests/hostemu/ttm_hostemu.cpp exports the C ABI of include/ttm.h with host
+pointers (the kernels' per-sample bodies compiled for the CPU).  `install()`
+injects it into the product's ctypes layer and points the `transport_map` class
+at torch CPU tensors, so the host logic can be tested without a GPU.  The
+product never does this by itself: without an injected double it loads
+libttm.so and requires a HIP device.
+"""
+import contextlib
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from triangular_transport_toolbox_amd import _capi, termtable
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'ttm_hostemu.cpp')
+LIB = os.path.join(HERE, 'libttm_hostemu.so')
+DEPS = [SRC, os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc', 'ttm_eval.h'),
+        os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
+
+_lib = None
+
+
+def build():
+    if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in DEPS):
+        return LIB
+    subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', LIB, SRC], check=True)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = ctypes.CDLL(build())
+        for name, (res, args) in _capi._SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+@contextlib.contextmanager
+def install():
+    """Route the transport_map class through the host test double."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    saved = (_capi._lib, transport_map._DEVICE)
+    _capi._lib = lib()
+    transport_map._DEVICE = 'cpu'
+    try:
+        yield
+    finally:
+        _capi._lib, transport_map._DEVICE = saved
+
+
+def ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class EmuMap:
+    """Low-level driver: host-pointer program + helpers taking standardised N x d samples."""
+
+    def __init__(self, cm, monotonicity, rectifier='exponential', delta=1e-8, quad_order=100):
+        self.cm = cm
+        self.itab = np.ascontiguousarray(cm.itab)
+        self.dpar = np.ascontiguousarray(cm.dpar)
+        self.qx, self.qw = termtable.gauss_legendre(quad_order)
+        self.qx, self.qw = np.ascontiguousarray(self.qx), np.ascontiguousarray(self.qw)
+        self.prog = _capi.make_program(cm, self.itab.ctypes.data, self.dpar.ctypes.data, self.qx.ctypes.data,
+                                       self.qw.ctypes.data, len(self.qx), monotonicity, rectifier, delta)
+        self.pp = ctypes.byref(self.prog)
+
+    def pack(self, coeffs_nonmon, coeffs_mon):
+        return np.ascontiguousarray(np.concatenate([np.concatenate((np.asarray(n, float), np.asarray(m, float)))
+                                                    for n, m in zip(coeffs_nonmon, coeffs_mon)]))
+
+    @staticmethod
+    def soa(X):
+        return np.ascontiguousarray(np.asarray(X, dtype=float).T)
+
+    def forward(self, coef, Xs, k0=0, k1=None, sigma=None):
+        k1 = self.cm.D if k1 is None else k1
+        X = self.soa(Xs)
+        N = X.shape[1]
+        Z = np.zeros((k1 - k0, N))
+        ld = np.zeros(N)
+        sg = None if sigma is None else np.ascontiguousarray(sigma, dtype=float)
+        lib().ttm_forward(self.pp, ptr(coef), ptr(X), N, N, k0, k1, ptr(Z), N, ptr(ld), ptr(sg), None, None)
+        return Z.T.copy(), ld
+
+    def basis(self, k, which, Xs):
+        X = self.soa(Xs)
+        N = X.shape[1]
+        m = int(self.cm.n_nm[k] if which == 0 else self.cm.n_mon[k])
+        out = np.zeros((max(m, 1), N))
+        lib().ttm_basis(self.pp, k, which, ptr(X), N, N, ptr(out), N, None)
+        return out[:m].T.copy()
+
+    def objective(self, k, coef_k, Xs, separable):
+        X = self.soa(Xs)
+        N = X.shape[1]
+        nacc = 1 + int(self.cm.n_mon[k]) + (0 if separable else int(self.cm.n_nm[k]))
+        out = np.zeros(nacc)
+        ck = np.ascontiguousarray(coef_k, dtype=float)
+        lib().ttm_objective(self.pp, k, ptr(ck), ptr(X), N, N, None, ptr(out), None)
+        return out
+
+    def gram(self, k, Xs):
+        X = self.soa(Xs)
+        N = X.shape[1]
+        m = int(self.cm.n_nm[k] + self.cm.n_mon[k])
+        out = np.zeros(m * m)
+        lib().ttm_gram(self.pp, k, ptr(X), N, N, None, ptr(out), None)
+        return out.reshape(m, m)
+
+    def table_build(self, coef, k, pts):
+        out = np.zeros(len(pts))
+        pts = np.ascontiguousarray(pts)
+        lib().ttm_inverse_table_build(self.pp, ptr(coef), k, k + 1, ptr(pts), len(pts), ptr(out), None)
+        return out
+
+    def inverse_table(self, coef, k0, k1, Z, Xinit, tab_x, tab_y, tmin, tmax, truncate=True):
+        X = self.soa(Xinit)
+        Zs = self.soa(Z)
+        N = X.shape[1]
+        tab_x, tab_y = np.ascontiguousarray(tab_x), np.ascontiguousarray(tab_y)
+        tmin, tmax = np.ascontiguousarray(tmin), np.ascontiguousarray(tmax)
+        lib().ttm_inverse_table(self.pp, ptr(coef), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(tab_x), ptr(tab_y),
+                                tab_x.shape[1], ptr(tmin), ptr(tmax), int(truncate), None)
+        return X.T.copy()
+
+    def inverse_bisect(self, coef, k0, k1, Z, Xinit, cap=None):
+        X = self.soa(Xinit)
+        Zs = self.soa(Z)
+        N = X.shape[1]
+        iters = np.zeros(k1 - k0, dtype=np.int32)
+        capa = None if cap is None else np.ascontiguousarray(cap, dtype=np.int32)
+        lib().ttm_inverse_bisect(self.pp, ptr(coef), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(iters), ptr(capa), None)
+        return X.T.copy(), iters

@@ -1,0 +1,196 @@
+"""
+CPU checks of the product's host logic and kernel bodies (no GPU):
+
+* the term-table compiler reproduces the reference's term ordering / constants
+  bit-exactly (descriptors parsed from the reference's generated functions);
+* the per-sample evaluator bodies of csrc/ttm_eval.h, compiled for the host by
+  tests/hostemu (test infrastructure, not a product path), agree with the
+  reference goldens and the oracle.
+"""
+import numpy as np
+import pytest
+
+from tests.hostemu.emu import EmuMap
+from tests.util import ALL_CASES, INTEGRATED, SEPARABLE, case_X, ctor_kwargs, load_case, make_oracle, relerr
+from triangular_transport_toolbox_amd import termtable
+
+ST_NAMES = {'let': 'LET', 'ret': 'RET', 'rbf': 'RBF', 'irbf': 'iRBF'}
+
+
+def build(name):
+    npz, desc = load_case(name)
+    om = make_oracle(name, npz, desc)
+    kw = ctor_kwargs(desc)
+    d_cols = om.X.shape[1]
+    cm = termtable.compile_map(desc['monotone'], desc['nonmonotone'], d_cols, kw['polynomial_type'], kw['monotonicity'])
+    special = termtable.count_special_terms(desc['monotone'], desc['nonmonotone'], d_cols - len(desc['monotone']))
+    special = termtable.place_special_terms(special, lambda var, q: np.quantile(om.X[:, var], q),
+                                            kw['ST_scale_factor'], kw['ST_scale_mode'])
+    cm.fill_special_terms(special)
+    em = EmuMap(cm, kw['monotonicity'], kw['rectifier_type'], kw['delta'], kw['quadrature_input']['order'])
+    return npz, desc, om, cm, em, special
+
+
+def canon_ref(terms):
+    """Reference descriptors -> the compiler's descriptor format."""
+    if terms is None:
+        return None
+    out = []
+    for t in terms:
+        d = []
+        for f in t:
+            if f[0] == 'const':
+                d.append(['const'])
+            elif f[0] == 'poly':
+                d.append(['poly', f[1], f[2], f[3]])
+            else:
+                kind = {'LET': 'let', 'RET': 'ret', 'RBF': 'rbf', 'iRBF': 'irbf'}[f[1]]
+                d.append(['st', kind, f[4], f[3], f[5]])
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize('name', ALL_CASES + ['entf', 'ex01_order10'])
+def test_term_order_and_constants_bit_exact(name):
+    npz, desc = load_case(name)
+    kw = ctor_kwargs(desc)
+    d_cols = desc['D'] + desc['skip_dimensions']
+    cm = termtable.compile_map(desc['monotone'], desc['nonmonotone'], d_cols, kw['polynomial_type'], kw['monotonicity'])
+    assert cm.descriptors_mon == [canon_ref(t) for t in desc['fun_mon']]
+    assert [d for d in cm.descriptors_nonmon] == [canon_ref(t) for t in desc['fun_nonmon']]
+    assert list(cm.n_mon) == desc['n_coeffs_mon'] and list(cm.n_nm) == desc['n_coeffs_nonmon']
+    # Hermite-function constants: bit-exact against the literals embedded in the reference's functions
+    fam, polyclass = termtable.FAMILIES[kw['polynomial_type'].lower()]
+    for pre in desc['precalc_mon'] + desc['precalc_nonmon']:
+        for key, (var, famname, coefs, hf) in pre.items():
+            if hf:
+                assert termtable.hf_constant(polyclass, len(coefs) - 1) == coefs[-1]
+    if 'lb' in desc:
+        for k in range(desc['D']):
+            lb = [-np.inf if v is None else v for v in desc['lb'][k]]
+            ub = [np.inf if v is None else v for v in desc['ub'][k]]
+            assert [b[0] for b in cm.bounds[k]] == lb and [b[1] for b in cm.bounds[k]] == ub
+
+
+def test_quadrature_and_hf_constants_bit_exact():
+    npz = dict(np.load('tests/golden/consts.npz'))
+    for q in (5, 15, 20, 25, 40, 100):
+        xis, Ws = termtable.gauss_legendre(q)
+        assert np.array_equal(xis, npz['xis%d' % q]) and np.array_equal(Ws, npz['Ws%d' % q])
+    for n, a in enumerate(npz['hf_consts'], start=1):
+        assert termtable.hf_constant(np.polynomial.hermite_e.HermiteE, n) == a
+    assert termtable.hf_constant(np.polynomial.hermite_e.HermiteE, 1) == 1.1658220173858227
+    assert termtable.hf_constant(np.polynomial.hermite_e.HermiteE, 10) == 0.0007446732427839159
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_special_term_placement(name):
+    npz, desc, om, cm, em, special = build(name)
+    for kc, d in desc['special_terms'].items():
+        for var, v in d.items():
+            if var == 'cross-terms':
+                for var2, v2 in v.items():
+                    got = special[int(kc)]['cross-terms'][int(var2)]
+                    assert list(got['centers']) == v2['centers'] and list(got['scales']) == v2['scales']
+            else:
+                got = special[int(kc)][int(var)]
+                assert list(got['centers']) == v['centers'] and list(got['scales']) == v['scales']
+    assert not np.any(np.isnan(cm.dpar))
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_basis_rows(name):
+    npz, desc, om, cm, em, _ = build(name)
+    Xs = om.X[:256]
+    for k in range(om.D):
+        assert relerr(em.basis(k, 1, Xs), npz['Psi_mon_%d' % k]) < 1e-13
+        if cm.n_nm[k]:
+            assert relerr(em.basis(k, 0, Xs), npz['Psi_nonmon_%d' % k]) < 1e-13
+        if 'dPsi_mon_%d' % k in npz:
+            assert relerr(em.basis(k, 2, Xs), npz['dPsi_mon_%d' % k]) < 1e-13
+
+
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_forward(name):
+    npz, desc, om, cm, em, _ = build(name)
+    n = npz['Z'].shape[0]
+    coef = em.pack(om.coeffs_nonmon, om.coeffs_mon)
+    Z, ld = em.forward(coef, om._standardized(case_X(name, npz)[:n]))
+    assert relerr(Z, npz['Z']) < 1e-12
+    if name in SEPARABLE:
+        # log-determinant against the oracle's derivative basis
+        Xs = om._standardized(case_X(name, npz)[:n])
+        ref = sum(np.log(np.dot(om.der_fun_mon(k, Xs), om.coeffs_mon[k])) for k in range(om.D))
+        assert relerr(ld, ref) < 1e-11
+
+
+@pytest.mark.parametrize('name', INTEGRATED)
+def test_objective_integrated(name):
+    npz, desc, om, cm, em, _ = build(name)
+    N = om.X.shape[0]
+    for k in range(om.D):
+        div = int(cm.n_nm[k])
+        for c, J, G in zip(npz['obj_c_%d' % k], npz['obj_J_%d' % k], npz['obj_G_%d' % k]):
+            out = em.objective(k, c, om.X, separable=False)
+            reg_J = om._reg(k, div, c[:div], c[div:], False)
+            reg_G = om._reg(k, div, c[:div], c[div:], True)
+            assert abs(out[0] / N + reg_J - J) <= 1e-10 * (1 + abs(J))        # north_star: KL objective 1e-10 rel
+            assert relerr(out[1:] / N + reg_G, G) < 1e-10
+
+
+@pytest.mark.parametrize('name', ['c2b_sep', 'c3_sep', 'c5_sep'])
+def test_objective_separable(name):
+    npz, desc, om, cm, em, _ = build(name)
+    N = om.X.shape[0]
+    for k in range(0, om.D, 7 if om.D > 8 else 1):
+        A = npz['sep_A_%d' % k]
+        b = om.delta * np.sum(A, axis=-1)
+        for c, J, G in zip(npz['sep_c_%d' % k], npz['sep_J_%d' % k], npz['sep_G_%d' % k]):
+            out = em.objective(k, np.concatenate((np.zeros(cm.n_nm[k]), c)), om.X, separable=True)
+            Jg = c @ A @ c / 2 - out[0] / N + c @ b
+            Gg = A @ c - out[1:] / N + b
+            assert abs(Jg - J) <= 1e-10 * (1 + abs(J))
+            assert relerr(Gg, G) < 1e-10
+
+
+@pytest.mark.parametrize('name', SEPARABLE)
+def test_inverse_table(name):
+    npz, desc, om, cm, em, _ = build(name)
+    coef = em.pack(om.coeffs_nonmon, om.coeffs_mon)
+    pts = np.linspace(-10, 10, 1001)
+    tabs = np.stack([em.table_build(coef, k, pts) for k in range(om.D)])
+    for k in range(om.D):
+        if 'table_out_%d' % k in npz:
+            assert relerr(tabs[k], npz['table_out_%d' % k]) < 1e-13
+    order = np.argsort(tabs, axis=1, kind='mergesort')
+    tab_x = np.take_along_axis(tabs, order, axis=1)
+    tab_y = pts[order]
+    Zin = npz['inv_Z']
+    Xinit = np.zeros((Zin.shape[0], om.X.shape[1]))
+    X = em.inverse_table(coef, 0, om.D, Zin, Xinit, tab_x, tab_y, tabs.min(axis=1), tabs.max(axis=1))
+    X = X * om.X_std + om.X_mean
+    assert relerr(X[:, om.skip_dimensions:], npz['inv_X_table']) < 1e-10
+
+
+@pytest.mark.parametrize('name', ['c1_int', 'c2a_int', 'c3_int', 'misc_grid', 'c2b_sep', 'c3_sep', 'misc_sep'])
+def test_inverse_bisect(name):
+    npz, desc, om, cm, em, _ = build(name)
+    coef = em.pack(om.coeffs_nonmon, om.coeffs_mon)
+    Zin = npz['inv_Z']
+    N = Zin.shape[0]
+    key = 'inv_X' if 'inv_X' in npz and name != 'misc_grid' else ('inv_X_nostar' if name == 'misc_grid' else 'inv_X_bisect')
+    # reference semantics: samples 1.. run to convergence, sample 0 stops with the others (TM:3952)
+    Xinit = np.zeros((N, om.X.shape[1]))
+    X, iters = em.inverse_bisect(coef, 0, om.D, Zin[1:], Xinit[1:])
+    X0, _ = em.inverse_bisect(coef, 0, om.D, Zin[:1], Xinit[:1], cap=iters)
+    X = np.vstack((X0, X)) * om.X_std + om.X_mean
+    ref = npz[key]
+    assert relerr(X[:, om.skip_dimensions:], ref) < 1e-6
+    # residual under the oracle's forward map
+    Zback = om.map(np.column_stack((np.zeros((N, om.skip_dimensions)) * om.X_std[:om.skip_dimensions]
+                                    + om.X_mean[:om.skip_dimensions], X[:, om.skip_dimensions:])))
+    assert np.max(np.abs(Zback[1:] - Zin[1:])) < 5e-9
+    if 'inv_X_n1' in npz or 'inv_X_bisect_n1' in npz:
+        Xn1, _ = em.inverse_bisect(coef, 0, om.D, Zin[:1], Xinit[:1], cap=np.zeros(om.D, dtype=np.int32))
+        Xn1 = Xn1 * om.X_std + om.X_mean
+        assert relerr(Xn1[:, om.skip_dimensions:], npz.get('inv_X_n1', npz.get('inv_X_bisect_n1'))) < 1e-12

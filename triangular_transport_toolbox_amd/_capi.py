@@ -1,0 +1,113 @@
+"""
+ctypes binding of the C ABI in include/ttm.h (libttm.so).
+
+This is the thin layer north_star asks for: Python host code -> C ABI -> HIP
+kernels.  Device memory is owned by the caller (PyTorch-ROCm tensors, passed
+as raw pointers); no torch type crosses the boundary.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+c_i32, c_i64, c_dbl, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+
+class ttm_program(ctypes.Structure):
+    """Mirror of `struct ttm_program` (include/ttm.h)."""
+    _fields_ = [('itab', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
+                ('h_comp_off', c_vp), ('h_dpar_off', c_vp), ('h_coef_off', c_vp), ('h_nslots', c_vp), ('h_n_nm', c_vp),
+                ('D', c_i32), ('d_cols', c_i32), ('family', c_i32), ('monotonicity', c_i32), ('rectifier', c_i32),
+                ('Q', c_i32), ('delta', c_dbl)]
+
+
+MONO = {'integrated rectifier': 0, 'separable monotonicity': 1}
+RECT = {'exponential': 0, 'softplus': 1, 'squared': 2, 'expneg': 3, 'explinearunit': 4}
+
+_SIGNATURES = {
+    'ttm_last_error_string': (ctypes.c_char_p, []),
+    'ttm_version': (ctypes.c_int, []),
+    'ttm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    'ttm_colstats_work_size': (c_i64, [c_i64, c_i32]),
+    'ttm_colstats': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_import': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    'ttm_export': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_forward': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64,
+                                   c_vp, c_vp, c_vp, c_vp]),
+    'ttm_basis': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'ttm_inverse_table_build': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    'ttm_inverse_table': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64,
+                                         c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_inverse_bisect': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64,
+                                          c_vp, c_vp, c_vp]),
+    'ttm_reduce_work_size': (c_i64, [c_i32]),
+    'ttm_objective': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+}
+
+EXPORTED_SYMBOLS = sorted(_SIGNATURES)
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def load():
+    """Load libttm.so (never builds, never falls back): raises if it is missing."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError('libttm.so is not built (%s); run `python -c "import __graft_entry__ as g; g.build()"` '
+                               'or `python -m triangular_transport_toolbox_amd.build`' % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class TTMError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise TTMError('libttm error %d: %s' % (rc, load().ttm_last_error_string().decode()))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    load().ttm_device_count(ctypes.byref(n))
+    return n.value
+
+
+def require_device():
+    """The product has no CPU path: fail loudly when no MI355X/HIP device is visible."""
+    lib = load()
+    n = ctypes.c_int(0)
+    rc = lib.ttm_device_count(ctypes.byref(n))
+    if rc != 0 or n.value < 1:
+        raise RuntimeError('triangular_transport_toolbox_amd needs a HIP device (MI355X); none is visible: '
+                           + lib.ttm_last_error_string().decode())
+    return n.value
+
+
+def make_program(cm, itab_ptr, dpar_ptr, qx_ptr, qw_ptr, Q, monotonicity, rectifier, delta):
+    """Fill a ttm_program from a CompiledMap and raw table pointers.  The
+    returned object keeps the host offset arrays alive."""
+    p = ttm_program()
+    p._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (cm.comp_off, cm.dpar_off, cm.coef_off, cm.nslots, cm.n_nm)]
+    p.itab, p.dpar, p.quad_x, p.quad_w = itab_ptr, dpar_ptr, qx_ptr, qw_ptr
+    (p.h_comp_off, p.h_dpar_off, p.h_coef_off, p.h_nslots, p.h_n_nm) = [a.ctypes.data for a in p._keep]
+    p.D, p.d_cols, p.family = int(cm.D), int(cm.d_cols), int(cm.family)
+    p.monotonicity = MONO[monotonicity.lower()]
+    p.rectifier = RECT[rectifier]
+    p.Q = int(Q)
+    p.delta = float(delta)
+    return p

@@ -1,0 +1,399 @@
+"""
+Term-table compiler: turns the reference's ``monotone`` / ``nonmonotone``
+specification lists into the flat int32 / fp64 tables the HIP kernels
+interpret (layout: include/ttm.h, "int32 layout of one component block").
+
+The reference generates NumPy source strings from these lists and ``exec``s
+them (transport_map.py:823-1261 ``write_basis_function``, 1263-1856
+``function_constructor_alternative``, 1860-2134 derivative constructor).  No
+code is generated here; the same *semantics* are encoded as data:
+
+* an entry ``[]`` is the constant 1 (TM:885-898);
+* an int list (optional ``'HF'``) is a product over its unique variables, in
+  ascending order, of the top-order polynomial of the counted order
+  (TM:1064, 1096-1160); with ``'HF'`` every factor is the normalised Hermite
+  function a_n P_n(x) exp(-x^2/4) with a_n from TM:1102-1109;
+* a string ``'LET j' | 'RET j' | 'RBF j' | 'iRBF j'`` is a special term whose
+  (centre, scale) index is the running count of special terms on variable j in
+  list order (TM:1337, 1417-1427; separate counter for the nonmonotone list
+  TM:1623, 1686-1694); monotone special terms on a variable other than the
+  component's own live under 'cross-terms' (TM:1407-1412);
+* a component whose monotone list has cross-term special terms gets all its
+  monotone special terms removed and appended as the full tensor grid, lowest
+  variable outermost (TM:1446-1483);
+* term order = coefficient order.
+
+Every monotone term is split into an "A" part (factors on columns other than
+the component's own column kc) and at most one "B" function of x_kc alone;
+distinct B functions are listed once per component so that the kernels can
+evaluate g(t) = sum_b w_b B_b(t) at many t (quadrature nodes, bisection
+trials, table points) from per-sample weights w_b.
+"""
+
+import itertools
+
+import numpy as np
+
+# constants mirrored from include/ttm.h
+KIND_POLY, KIND_HF, KIND_LET, KIND_RET, KIND_RBF, KIND_IRBF = 1, 2, 3, 4, 5, 6
+ST_KINDS = {'let': KIND_LET, 'ret': KIND_RET, 'rbf': KIND_RBF, 'irbf': KIND_IRBF}
+FAM_HERMITE_E, FAM_POWER, FAM_HERMITE, FAM_CHEBYSHEV, FAM_LAGUERRE, FAM_LEGENDRE = range(6)
+HDR_LEN = 16
+(HDR_KC, HDR_N_NM, HDR_OFF_NM, HDR_N_MON, HDR_OFF_MON, HDR_OFF_FAC, HDR_NB, HDR_OFF_B, HDR_NB_HF, HDR_NB_POLY,
+ HDR_NB_ST, HDR_MAXP_HF, HDR_MAXP_POLY, HDR_FLAGS, HDR_N_DPAR, HDR_LEN_BLK) = range(16)
+
+# polynomial_type -> (family id, numpy class, unified name)   (TM:274-304)
+_P = np.polynomial
+FAMILIES = {
+    'standard': (FAM_POWER, _P.polynomial.Polynomial),
+    'polynomial': (FAM_POWER, _P.polynomial.Polynomial),
+    'power series': (FAM_POWER, _P.polynomial.Polynomial),
+    'hermite': (FAM_HERMITE, _P.hermite.Hermite),
+    "phycisist's hermite": (FAM_HERMITE, _P.hermite.Hermite),
+    'phycisists hermite': (FAM_HERMITE, _P.hermite.Hermite),
+    'hermite_e': (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+    "probabilist's hermite": (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+    'probabilists hermite': (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+    'chebyshev': (FAM_CHEBYSHEV, _P.chebyshev.Chebyshev),
+    'laguerre': (FAM_LAGUERRE, _P.laguerre.Laguerre),
+    'legendre': (FAM_LEGENDRE, _P.legendre.Legendre),
+    'hermite function': (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+    'hermite_function': (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+    'hermite functions': (FAM_HERMITE_E, _P.hermite_e.HermiteE),
+}
+
+_HF_CACHE = {}
+
+
+def hf_constant(polyclass, n):
+    """a_n = 1 / max |P_n(x) exp(-x^2/4)| over linspace(-100, 100, 100001), the
+    same NumPy evaluation as TM:1102-1109 (hence bit-identical constants)."""
+    key = (polyclass.__name__, int(n))
+    if key not in _HF_CACHE:
+        hf_x = np.linspace(-100, 100, 100001)
+        hfeval = polyclass([0.] * int(n) + [1.])(hf_x) * np.exp(-hf_x ** 2 / 4)
+        _HF_CACHE[key] = float(1 / np.max(np.abs(hfeval)))
+    return _HF_CACHE[key]
+
+
+def gauss_legendre(order):
+    """Quadrature rule exactly as TM:199-225 (legroots + derivative formula)."""
+    coefs = [0] * int(order) + [1]
+    coefs_der = np.polynomial.legendre.legder(coefs)
+    LegendreDer = np.polynomial.legendre.Legendre(coefs_der)
+    xis = np.polynomial.legendre.legroots(coefs)
+    Ws = 2.0 / ((1.0 - xis ** 2) * (LegendreDer(xis) ** 2))
+    return xis, Ws
+
+
+def count_special_terms(monotone, nonmonotone, skip):
+    """TM:2136-2217: special-term counters per (component column, variable);
+    monotone special terms on other variables are counted under 'cross-terms'."""
+    special = {}
+    for k in range(len(monotone)):
+        kc = k + skip
+        st = special[kc] = {}
+        for entry in nonmonotone[k]:
+            if isinstance(entry, str):
+                index = int(entry.split(' ')[1])
+                st.setdefault(index, {'counter': 0, 'centers': np.asarray([]), 'scales': np.asarray([])})['counter'] += 1
+        for entry in monotone[k]:
+            if isinstance(entry, str):
+                index = int(entry.split(' ')[1])
+                tgt = st if index == kc else st.setdefault('cross-terms', {})
+                tgt.setdefault(index, {'counter': 0, 'centers': np.asarray([]), 'scales': np.asarray([])})['counter'] += 1
+    return special
+
+
+def place_special_terms(special, column_quantiles, scale_factor, scale_mode):
+    """TM:2219-2330.  ``column_quantiles(var, q_array)`` returns np.quantile of the
+    standardised training column ``var`` (method 'linear')."""
+    def place(dictionary):
+        for d in [key for key in dictionary if key != 'cross-terms']:
+            n = dictionary[d]['counter']
+            if n == 1:
+                dictionary[d]['centers'] = np.asarray([column_quantiles(d, np.asarray([0.5]))[0]])
+                dictionary[d]['scales'] = np.asarray([scale_factor / 2 if scale_mode == 'dynamic' else scale_factor])
+            elif n > 1:
+                q = np.arange(1, n + 1, 1) / (n + 1)
+                c = dictionary[d]['centers'] = np.array(column_quantiles(d, q), dtype=float)
+                scales = np.zeros(n)
+                if scale_mode == 'dynamic':
+                    for i in range(n):
+                        if i == 0:
+                            scales[i] = (c[1] - c[0]) * scale_factor
+                        elif i == n - 1:
+                            scales[i] = (c[i] - c[i - 1]) * scale_factor
+                        else:
+                            scales[i] = (c[i + 1] - c[i - 1]) / 2 * scale_factor
+                    dictionary[d]['scales'] = scales
+                else:
+                    dictionary[d]['scales'] = scales + scale_factor
+        return dictionary
+    for kc in special:
+        if 'cross-terms' in special[kc]:
+            special[kc]['cross-terms'] = place(special[kc]['cross-terms'])
+        special[kc] = place(special[kc])
+    return special
+
+
+def quantile_requests(special):
+    """All (variable, quantile) pairs place_special_terms will ask for."""
+    req = {}
+    for kc, d in special.items():
+        groups = [d] + ([d['cross-terms']] if 'cross-terms' in d else [])
+        for g in groups:
+            for var, v in g.items():
+                if var == 'cross-terms':
+                    continue
+                n = v['counter']
+                qs = [0.5] if n == 1 else list(np.arange(1, n + 1, 1) / (n + 1))
+                req.setdefault(var, set()).update(float(q) for q in qs)
+    return {var: sorted(q) for var, q in req.items()}
+
+
+class CompiledMap:
+    """Result of compile_map: flat tables + bookkeeping."""
+
+    def __init__(self):
+        self.itab = None
+        self.dpar = None
+        self.comp_off = None
+        self.dpar_off = None
+        self.coef_off = None
+        self.nslots = None
+        self.n_nm = None
+        self.n_mon = None
+        self.dpar_sources = []     # per dpar entry: ('hf', value) | ('st', kc, cross, var, index, which)
+        self.descriptors_mon = []  # canonical term descriptors (tests)
+        self.descriptors_nonmon = []
+        self.bounds = []           # L-BFGS-B bounds per component (TM:1891-1892, 1925-1929)
+        self.family = 0
+        self.D = 0
+        self.d_cols = 0
+
+    def fill_special_terms(self, special):
+        """Refresh the (centre, scale) constants after a new placement."""
+        for i, src in enumerate(self.dpar_sources):
+            if src[0] == 'st':
+                _, kc, cross, var, index, which = src
+                d = special[kc]['cross-terms'][var] if cross else special[kc][var]
+                self.dpar[i] = d['centers' if which == 0 else 'scales'][index]
+        return self.dpar
+
+
+def _parse_entry(entry, kc, which, counter, polynomial_type):
+    """One list entry -> list of factors.
+    factor = ('poly', var, order, hf) | ('st', kind, var, cross, index)."""
+    if isinstance(entry, str):
+        parts = entry.split(' ')
+        kind = parts[0].lower()
+        if kind not in ST_KINDS:
+            raise ValueError("Special term '" + str(parts[0]) + "' not understood. Currently, only LET, RET, iRBF, "
+                             "and RBF are implemented.")
+        var = int(parts[1])
+        cross = (which == 'mon') and (var != kc)
+        idx = counter.get(var, 0)
+        counter[var] = idx + 1
+        return [('st', kind, var, cross, idx)]
+    if len(entry) == 0:
+        return []
+    hf = any(e == 'HF' for e in entry)
+    if any(e == 'LIN' for e in entry):
+        raise NotImplementedError("the 'LIN' tail-linearisation modifier (TM:1513-1541) is not supported by the "
+                                  "MI355X engine yet")
+    ints = [e for e in entry if not isinstance(e, str)]
+    ui, ct = np.unique(ints, return_counts=True)
+    return [('poly', int(u), int(c), bool(hf)) for u, c in zip(ui, ct)]
+
+
+def _descriptor(term):
+    if len(term) == 0:
+        return [['const']]
+    out = []
+    for f in term:
+        if f[0] == 'poly':
+            out.append(['poly', f[1], f[2], f[3]])
+        else:
+            out.append(['st', f[1], f[2], f[3], f[4]])
+    return out
+
+
+def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function',
+                monotonicity='integrated rectifier'):
+    """Compile the specification lists into device tables (special-term
+    constants are filled in later by CompiledMap.fill_special_terms)."""
+    if polynomial_type.lower() not in FAMILIES:
+        raise Exception("Polynomial type not understood. The variable polynomial_type should be either 'power series', "
+                        "'hermite', 'hermite_e', 'chebyshev', 'laguerre', or 'legendre'.")
+    family, polyclass = FAMILIES[polynomial_type.lower()]
+    separable = monotonicity.lower() == 'separable monotonicity'
+    D = len(monotone)
+    skip = d_cols - D
+    if skip < 0:
+        raise ValueError('X has fewer columns than the map has components')
+    cm = CompiledMap()
+    cm.family, cm.D, cm.d_cols = family, D, d_cols
+    itab, dpar = [], []
+    comp_off, dpar_off, coef_off = [0], [0], [0]
+    nslots, n_nm_all, n_mon_all = [], [], []
+
+    for k in range(D):
+        kc = k + skip
+        # ---- parse --------------------------------------------------------
+        counter = {}
+        nm_terms = [_parse_entry(e, kc, 'nonmon', counter, polynomial_type) for e in nonmonotone[k]]
+        counter = {}
+        mon_terms, st_idx = [], []
+        for i, e in enumerate(monotone[k]):
+            t = _parse_entry(e, kc, 'mon', counter, polynomial_type)
+            mon_terms.append(t)
+            if isinstance(e, str):
+                st_idx.append(i)
+        has_cross = any(t[0][3] for t in (mon_terms[i] for i in st_idx))
+        if has_cross:
+            if separable:
+                raise NotImplementedError('monotone cross-term special terms are not supported with separable '
+                                          'monotonicity (their x_k-derivative is identically zero, TM:2000-2037)')
+            rbf = [mon_terms[i] for i in st_idx]
+            dims = sorted(set(t[0][2] for t in rbf))
+            by_dim = {d: [t for t in rbf if t[0][2] == d] for d in dims}
+            grid = list(by_dim[dims[0]])
+            for d in dims[1:]:
+                grid = [a + b for a, b in itertools.product(grid, by_dim[d])]
+            mon_terms = [t for i, t in enumerate(mon_terms) if i not in st_idx] + grid
+        # ---- validate -------------------------------------------------------
+        for t in nm_terms:
+            for f in t:
+                var = f[1] if f[0] == 'poly' else f[2]
+                if var < 0 or var >= kc:
+                    raise ValueError('nonmonotone term of component %d depends on column %d; only columns < %d are '
+                                     'allowed' % (k, var, kc))
+        for t in mon_terms:
+            for f in t:
+                var = f[1] if f[0] == 'poly' else f[2]
+                if var < 0 or var > kc:
+                    raise ValueError('monotone term of component %d depends on column %d > %d' % (k, var, kc))
+        if separable:
+            keys = set()
+            for t in mon_terms:
+                polys = [f for f in t if f[0] == 'poly']
+                if any(f[3] for f in polys) and len(t) > 1:
+                    raise NotImplementedError('Hermite-function cross terms in a separable monotone list: the '
+                                              'reference derivative is ill-defined (TM:1245 overwrites factors)')
+                for f in polys:
+                    if f[1] == kc:
+                        keys.add((f[2], f[3]))
+            if len(set(o for o, _ in keys)) != len(keys):
+                raise NotImplementedError('the same polynomial order appears with and without HF in a separable '
+                                          'monotone list (reference shares the derivative key, TM:1172/1201)')
+        # ---- constants ------------------------------------------------------
+        dp_local, dp_index = [], {}
+
+        def dp_hf(order):
+            key = ('hf', order)
+            if key not in dp_index:
+                dp_index[key] = len(dp_local)
+                dp_local.append(('hf', hf_constant(polyclass, order)))
+            return dp_index[key]
+
+        def dp_st(f):
+            key = ('st', f[3], f[2], f[4])
+            if key not in dp_index:
+                dp_index[key] = len(dp_local)
+                dp_local.append(('st', kc, f[3], f[2], f[4], 0))
+                dp_local.append(('st', kc, f[3], f[2], f[4], 1))
+            return dp_index[key]
+
+        def fac_record(f):
+            if f[0] == 'poly':
+                return [f[1], KIND_HF if f[3] else KIND_POLY, f[2], dp_hf(f[2]) if f[3] else 0]
+            return [f[2], ST_KINDS[f[1]], 0, dp_st(f)]
+
+        # ---- B functions (of x_kc alone) --------------------------------------
+        bkeys = []
+        for t in mon_terms:
+            for f in t:
+                var = f[1] if f[0] == 'poly' else f[2]
+                if var == kc:
+                    key = ('hf' if f[3] else 'poly', f[2]) if f[0] == 'poly' else ('st', f[1], f[4])
+                    if key not in bkeys:
+                        bkeys.append(key)
+        b_hf = sorted([b for b in bkeys if b[0] == 'hf'], key=lambda b: b[1])
+        b_poly = sorted([b for b in bkeys if b[0] == 'poly'], key=lambda b: b[1])
+        b_st = [b for b in bkeys if b[0] == 'st']
+        blist = b_hf + b_poly + b_st
+        bfuns = []
+        for b in blist:
+            if b[0] == 'hf':
+                bfuns.append([KIND_HF, b[1], dp_hf(b[1]), 0])
+            elif b[0] == 'poly':
+                bfuns.append([KIND_POLY, b[1], 0, 0])
+            else:
+                bfuns.append([ST_KINDS[b[1]], 0, dp_st(('st', b[1], kc, False, b[2])), 0])
+        # ---- term + factor records ------------------------------------------
+        facs, terms = [], []
+        for ci, t in enumerate(nm_terms):
+            f0 = len(facs)
+            facs.extend(fac_record(f) for f in t)
+            terms.append([f0, len(t), -1, ci])
+        all_trivial = True
+        for ci, t in enumerate(mon_terms):
+            f0 = len(facs)
+            b = -1
+            nf = 0
+            for f in t:
+                var = f[1] if f[0] == 'poly' else f[2]
+                if var == kc:
+                    key = ('hf' if f[3] else 'poly', f[2]) if f[0] == 'poly' else ('st', f[1], f[4])
+                    b = blist.index(key)
+                else:
+                    facs.append(fac_record(f))
+                    nf += 1
+            if nf:
+                all_trivial = False
+            terms.append([f0, nf, b, ci])
+        # ---- assemble the block ---------------------------------------------
+        hdr = [0] * HDR_LEN
+        off_nm = HDR_LEN
+        off_mon = off_nm + 4 * len(nm_terms)
+        off_fac = off_mon + 4 * len(mon_terms)
+        off_b = off_fac + 4 * len(facs)
+        blk_len = off_b + 4 * len(bfuns)
+        hdr[HDR_KC] = kc
+        hdr[HDR_N_NM], hdr[HDR_OFF_NM] = len(nm_terms), off_nm
+        hdr[HDR_N_MON], hdr[HDR_OFF_MON] = len(mon_terms), off_mon
+        hdr[HDR_OFF_FAC] = off_fac
+        hdr[HDR_NB], hdr[HDR_OFF_B] = len(bfuns), off_b
+        hdr[HDR_NB_HF], hdr[HDR_NB_POLY], hdr[HDR_NB_ST] = len(b_hf), len(b_poly), len(b_st)
+        hdr[HDR_MAXP_HF] = max([b[1] for b in b_hf], default=0)
+        hdr[HDR_MAXP_POLY] = max([b[1] for b in b_poly], default=0)
+        hdr[HDR_FLAGS] = 1 if all_trivial else 0
+        hdr[HDR_N_DPAR] = len(dp_local)
+        hdr[HDR_LEN_BLK] = blk_len
+        block = hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b]
+        assert len(block) == blk_len
+        itab.extend(block)
+        for src in dp_local:
+            cm.dpar_sources.append(src)
+            dpar.append(src[1] if src[0] == 'hf' else np.nan)
+        comp_off.append(len(itab))
+        dpar_off.append(len(dpar))
+        coef_off.append(coef_off[-1] + len(nm_terms) + len(mon_terms))
+        nslots.append(len(bfuns) + 1)
+        n_nm_all.append(len(nm_terms))
+        n_mon_all.append(len(mon_terms))
+        cm.descriptors_mon.append([_descriptor(t) for t in mon_terms])
+        cm.descriptors_nonmon.append([_descriptor(t) for t in nm_terms] if len(nm_terms) else None)
+        cm.bounds.append([[-np.inf, np.inf] if (not isinstance(e, str) and len(e) == 0) else [0., np.inf]
+                          for e in monotone[k]])
+
+    cm.itab = np.asarray(itab, dtype=np.int32)
+    cm.dpar = np.asarray(dpar if len(dpar) else [0.0], dtype=np.float64)
+    cm.comp_off = np.asarray(comp_off, dtype=np.int32)
+    cm.dpar_off = np.asarray(dpar_off, dtype=np.int32)
+    cm.coef_off = np.asarray(coef_off, dtype=np.int32)
+    cm.nslots = np.asarray(nslots, dtype=np.int32)
+    cm.n_nm = np.asarray(n_nm_all, dtype=np.int32)
+    cm.n_mon = np.asarray(n_mon_all, dtype=np.int32)
+    return cm

@@ -1,0 +1,682 @@
+"""
+MI355X-native drop-in for the reference class ``transport_map``
+(MaxRamgraber/Triangular-Transport-Toolbox, transport_map.py - "TM" below).
+
+Same constructor keywords, methods, attributes and error behaviour as the
+reference for the hot path (TM:12-39 ctor, TM:710 reset, TM:2391 map, TM:2439 s,
+TM:2569/2646 densities, TM:2714 optimize, TM:3300/3435 objective, TM:3639
+inverse_map).  The host code stays Python; every per-sample computation runs in
+the HIP kernels of libttm.so through the C ABI of include/ttm.h (ctypes,
+``_capi``).  PyTorch-ROCm is used for device memory, streams and (optionally)
+``torch.distributed`` only - no torch op touches sample data.
+
+There is no CPU path: constructing a map without a visible HIP device or
+without libttm.so raises.
+
+What is deliberately different from the reference:
+* no source generation / ``exec``: the specification lists are compiled into
+  term tables (``termtable.compile_map``);
+* ``workers`` is accepted and ignored (the process pool of TM:2789-2874 is
+  replaced by the GPU; components / samples shard over ranks instead);
+* ``adaptation`` (TM:373-656, 4575-4950) and the ``'LIN'`` modifier are outside
+  the hot path and raise NotImplementedError;
+* reference defects that are only reachable through invalid specifications are
+  rejected instead of replicated (see ``termtable.compile_map``).
+Reference quirks on valid inputs are reproduced: the
+sample-0 bisection guard, the un-standardised derivative in the densities, the
+missing 1/N of the L2-regularised separable objective, ``map(X)`` ignoring X
+when ``standardize_samples`` is False.
+"""
+
+import copy
+import ctypes
+
+import numpy as np
+
+from . import _capi, termtable
+
+__all__ = ['transport_map']
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class transport_map():
+
+    # the device the class allocates on; tests that inject the host test double
+    # of the C ABI (tests/hostemu) set this to 'cpu'
+    _DEVICE = 'cuda'
+
+    def __init__(self,
+                 X,
+                 monotone=None,
+                 nonmonotone=None,
+                 polynomial_type='hermite function',
+                 monotonicity='integrated rectifier',
+                 standardize_samples=True,
+                 standardization='standard',
+                 workers=1,
+                 ST_scale_factor=1.0,
+                 ST_scale_mode='dynamic',
+                 coeffs_init=0.,
+                 alternate_root_finding=True,
+                 root_search_truncation=True,
+                 verbose=True,
+                 linearization=None,
+                 linearization_specified_as_quantiles=True,
+                 linearization_increment=1E-6,
+                 regularization=None,
+                 regularization_lambda=0.1,
+                 quadrature_input={},
+                 rectifier_type='exponential',
+                 delta=1E-8,
+                 adaptation=False,
+                 adaptation_map_type="cross-terms",
+                 adaptation_max_order=10,
+                 adaptation_skip_dimensions=0,
+                 adaptation_max_iterations=25,
+                 shard_samples=False):
+
+        self._lib = _capi.load()
+        if self._DEVICE == 'cuda':
+            _capi.require_device()
+        torch = _torch()
+        self._dev = torch.device(self._DEVICE, torch.cuda.current_device()) if self._DEVICE == 'cuda' \
+            else torch.device(self._DEVICE)
+
+        if adaptation:
+            raise NotImplementedError('map adaptation (TM:373-656, 4575-4950) is outside the MI355X hot path')
+        if linearization is not None:
+            raise NotImplementedError("tail linearisation ('LIN', TM:1513-1541) is not supported yet")
+        if monotone is None or nonmonotone is None:
+            raise ValueError("'monotone' and 'nonmonotone' must be specified (map adaptation is not supported)")
+
+        self.monotone = copy.deepcopy(monotone)
+        self.nonmonotone = copy.deepcopy(nonmonotone)
+        self.workers = workers
+        self.rectifier_type = rectifier_type
+        self.delta = delta
+        if rectifier_type not in _capi.RECT:
+            raise ValueError("rectifier_type '" + str(rectifier_type) + "' not understood")
+
+        # quadrature rule, TM:196-225 (the user's dict is copied, not mutated)
+        self.quadrature_input = dict(quadrature_input)
+        if 'xis' not in self.quadrature_input and 'Ws' not in self.quadrature_input:
+            order = self.quadrature_input.get('order', 100)
+            xis, Ws = termtable.gauss_legendre(order)
+            self.quadrature_input['xis'] = copy.copy(xis)
+            self.quadrature_input['Ws'] = copy.copy(Ws)
+        if self.quadrature_input.get('adaptive', False):
+            raise NotImplementedError('adaptive quadrature (TM:4322-4353) is not supported')
+
+        self.ST_scale_factor = ST_scale_factor
+        self.ST_scale_mode = ST_scale_mode
+        if self.ST_scale_mode not in ['dynamic', 'static']:
+            raise ValueError("'ST_scale_mode' must be either 'dynamic' or 'static'.")
+        self.standardization = standardization
+        self.coeffs_init = coeffs_init
+        self.alternate_root_finding = alternate_root_finding
+        self.root_search_truncation = root_search_truncation
+        self.verbose = verbose
+        self.regularization = regularization
+        self.regularization_lambda = regularization_lambda
+        self.linearization = linearization
+        self.linearization_specified_as_quantiles = linearization_specified_as_quantiles
+        self.linearization_increment = linearization_increment
+        self.monotonicity = monotonicity
+        if self.monotonicity.lower() not in ['integrated rectifier', 'separable monotonicity']:
+            raise ValueError("'monotonicity' type " + str(self.monotonicity) + " not understood. " +
+                             "Must be either 'integrated rectifier' or 'separable monotonicity'.")
+        self.polynomial_type = polynomial_type
+        if polynomial_type.lower() not in termtable.FAMILIES:
+            raise Exception("Polynomial type not understood. The variable polynomial_type should be either "
+                            "'power series', 'hermite', 'hermite_e', 'chebyshev', 'laguerre', or 'legendre'.")
+        if polynomial_type.lower() in ('hermite function', 'hermite_function', 'hermite functions'):
+            self.polynomial_type = 'hermite function'
+        self.standardize_samples = standardize_samples
+        self.adaptation = adaptation
+        self.shard_samples = bool(shard_samples)
+
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise Exception('X should be a two-dimensional array of shape (N,D), N = number of samples, '
+                            'D = number of dimensions. Current shape of X is ' + str(X.shape))
+        self.D = len(monotone)
+        self.skip_dimensions = X.shape[-1] - self.D
+
+        # ---- compile the specification into term tables -----------------------
+        self._cm = termtable.compile_map(self.monotone, self.nonmonotone, X.shape[-1], self.polynomial_type,
+                                         self.monotonicity)
+        self.special_terms = termtable.count_special_terms(self.monotone, self.nonmonotone, self.skip_dimensions)
+        self.coeffs_mon = [np.ones(int(n)) * self.coeffs_init for n in self._cm.n_mon]
+        self.coeffs_nonmon = [np.ones(int(n)) * self.coeffs_init for n in self._cm.n_nm]
+        if self.monotonicity.lower() == 'separable monotonicity':
+            self.optimization_constraints_lb = [np.asarray([b[0] for b in bk]) for bk in self._cm.bounds]
+            self.optimization_constraints_ub = [np.asarray([b[1] for b in bk]) for bk in self._cm.bounds]
+
+        self._itab_d = self._to_dev(self._cm.itab, dtype=torch.int32)
+        self._dpar_d = self._to_dev(self._cm.dpar)
+        self._qx_d = self._to_dev(np.asarray(self.quadrature_input['xis'], dtype=float))
+        self._qw_d = self._to_dev(np.asarray(self.quadrature_input['Ws'], dtype=float))
+        self._prog = _capi.make_program(self._cm, self._itab_d.data_ptr(), self._dpar_d.data_ptr(),
+                                        self._qx_d.data_ptr(), self._qw_d.data_ptr(), self._qx_d.numel(),
+                                        self.monotonicity, self.rectifier_type, self.delta)
+        self._pp = ctypes.byref(self._prog)
+        self._work = None
+        self._obj_cache = None
+
+        # ---- samples: upload, standardise, place special terms -----------------
+        self._load_samples(X)
+
+    # ------------------------------------------------------------------------
+    # device plumbing
+    # ------------------------------------------------------------------------
+
+    def _to_dev(self, a, dtype=None):
+        torch = _torch()
+        a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
+        t = torch.from_numpy(a)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self._dev)
+
+    def _empty(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype or torch.float64, device=self._dev)
+
+    def _zeros(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.zeros(shape, dtype=dtype or torch.float64, device=self._dev)
+
+    def _stream(self):
+        if self._dev.type != 'cuda':
+            return None
+        return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _ptr(t, offset=0):
+        if t is None:
+            return None
+        return ctypes.c_void_p(t.data_ptr() + 8 * offset)
+
+    def _workspace(self, n):
+        if self._work is None or self._work.numel() < n:
+            self._work = self._empty(int(n))
+        return self._work
+
+    def _dist(self):
+        """torch.distributed handle when samples are sharded over ranks."""
+        if not self.shard_samples:
+            return None
+        import torch.distributed as dist
+        return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+    def _allreduce(self, t, op='sum'):
+        dist = self._dist()
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
+        return t
+
+    # ------------------------------------------------------------------------
+    # samples
+    # ------------------------------------------------------------------------
+
+    def _import(self, X, standardize):
+        """Row-major host array -> standardised column-major device matrix (d x N)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        N, d = X.shape
+        Xrow = self._to_dev(X)
+        Xs = self._empty(d, N)
+        mean = self._mean_d if standardize else None
+        sd = self._std_d if standardize else None
+        _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(Xs), N,
+                                         self._stream()))
+        return Xs
+
+    def _export(self, Xs, N, j0, dout, destandardize):
+        out = self._empty(N, dout)
+        mean = self._mean_d if destandardize else None
+        sd = self._std_d if destandardize else None
+        _capi.check(self._lib.ttm_export(self._ptr(Xs), Xs.shape[1], N, j0, dout, self._ptr(mean), self._ptr(sd),
+                                         self._ptr(out), self._stream()))
+        return out.cpu().numpy()
+
+    def _load_samples(self, X):
+        torch = _torch()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        N, d = X.shape
+        self._N = N
+        self._Nglobal = N
+        dist = self._dist()
+        if dist is not None:
+            n = torch.tensor([N], dtype=torch.int64, device=self._dev)
+            dist.all_reduce(n)
+            self._Nglobal = int(n.item())
+        self._X_host = None
+        if self.standardize_samples:
+            self.standardize(X)
+        self._Xs = self._import(X, self.standardize_samples)
+        self._obj_cache = None
+        self.determine_special_term_locations()
+
+    @property
+    def X(self):
+        """Standardised training samples (host copy, fetched on demand)."""
+        if self._X_host is None:
+            self._X_host = self._export(self._Xs, self._N, 0, self._Xs.shape[0], False)
+        return self._X_host
+
+    def standardize(self, X=None):
+        """TM:750-787.  'standard': mean / ddof-0 std per column (device reduction);
+        'quantiles': median / quantile spread."""
+        torch = _torch()
+        if X is None:
+            raise ValueError('standardize() needs the raw samples')
+        N, d = X.shape
+        if self.standardization.lower() == 'standard':
+            Xrow = self._to_dev(X)
+            mean, sd = self._empty(d), self._empty(d)
+            work = self._workspace(self._lib.ttm_colstats_work_size(N, d))
+            _capi.check(self._lib.ttm_colstats(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(work),
+                                               self._stream()))
+            dist = self._dist()
+            if dist is not None:
+                # combine per-rank moments: mean = sum n_r m_r / n, var = sum n_r (v_r + (m_r - mean)^2) / n
+                n_r = float(N)
+                s1 = self._allreduce(mean * n_r)
+                gmean = s1 / self._Nglobal
+                s2 = self._allreduce((sd * sd + (mean - gmean) ** 2) * n_r)
+                mean, sd = gmean, torch.sqrt(s2 / self._Nglobal)
+            self.X_mean = mean.cpu().numpy()
+            self.X_std = sd.cpu().numpy()
+        elif self.standardization.lower() in ('quantile', 'quantiles'):
+            if self._dist() is not None:
+                raise NotImplementedError('quantile standardisation with sharded samples')
+            self.X_mean = np.quantile(X, q=0.5, axis=0)
+            self.X_std = (np.quantile(X - self.X_mean, q=0.8413447460685429, axis=0) -
+                          np.quantile(X - self.X_mean, q=0.15865525393145707, axis=0)) / 2
+        else:
+            raise ValueError("'standardization' must be either 'standard' or 'quantiles'.")
+        self._mean_d = self._to_dev(self.X_mean)
+        self._std_d = self._to_dev(self.X_std)
+
+    def determine_special_term_locations(self, k=None):
+        """TM:2219-2389: centres = quantiles of the standardised training columns."""
+        req = termtable.quantile_requests(self.special_terms)
+        if len(req) == 0:
+            return
+        if self._dist() is not None:
+            raise NotImplementedError('special-term placement with sharded samples needs a distributed quantile')
+        cache = {}
+
+        def column_quantiles(var, q):
+            if var not in cache:
+                cache[var] = self._Xs[var].cpu().numpy()
+            return np.quantile(cache[var], q)
+        termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
+        self._cm.fill_special_terms(self.special_terms)
+        self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
+
+    def reset(self, X):
+        """TM:710-748: new samples, coefficients back to coeffs_init."""
+        X = np.asarray(X)
+        if len(X.shape) != 2:
+            raise Exception('X should be a two-dimensional array of shape (N,D), N = number of samples, D = number '
+                            'of dimensions. Current shape of X is ' + str(X.shape))
+        if X.shape[-1] != self._cm.d_cols:
+            raise Exception('X has ' + str(X.shape[-1]) + ' columns, the map was built for ' + str(self._cm.d_cols))
+        for k in range(self.D):
+            self.coeffs_mon[k] = np.asarray(self.coeffs_mon[k], dtype=float) * 0 + self.coeffs_init
+            self.coeffs_nonmon[k] = np.asarray(self.coeffs_nonmon[k], dtype=float) * 0 + self.coeffs_init
+        self._load_samples(X)
+
+    # ------------------------------------------------------------------------
+    # coefficients
+    # ------------------------------------------------------------------------
+
+    def _pack_coeffs(self, override_k=None, coeffs_nonmon=None, coeffs_mon=None):
+        parts = []
+        for k in range(self.D):
+            cn = self.coeffs_nonmon[k] if (k != override_k or coeffs_nonmon is None) else coeffs_nonmon
+            cm = self.coeffs_mon[k] if (k != override_k or coeffs_mon is None) else coeffs_mon
+            cn, cm = np.asarray(cn, dtype=float).ravel(), np.asarray(cm, dtype=float).ravel()
+            if len(cn) != self._cm.n_nm[k] or len(cm) != self._cm.n_mon[k]:
+                raise ValueError('component %d expects %d nonmonotone and %d monotone coefficients, got %d and %d'
+                                 % (k, self._cm.n_nm[k], self._cm.n_mon[k], len(cn), len(cm)))
+            parts += [cn, cm]
+        return self._to_dev(np.concatenate(parts))
+
+    # ------------------------------------------------------------------------
+    # forward map
+    # ------------------------------------------------------------------------
+
+    def _samples_for(self, X):
+        """TM:2410-2422: a user X is only used when standardize_samples is True."""
+        if X is not None and self.standardize_samples:
+            X = np.asarray(X)
+            if X.ndim != 2 or X.shape[1] != self._cm.d_cols:
+                raise ValueError('X must have shape (N, %d)' % self._cm.d_cols)
+            return self._import(X, True), X.shape[0]
+        return self._Xs, self._N
+
+    def map(self, X=None):
+        """TM:2391-2437: Z[:, k] = S_k(x) for all map components."""
+        Xs, N = self._samples_for(X)
+        coef = self._pack_coeffs()
+        Z = self._empty(self.D, N)
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+                                          self._ptr(Z), N, None, None, None, self._stream()))
+        return self._export(Z, N, 0, self.D, False)
+
+    def s(self, x, k, coeffs_nonmon=None, coeffs_mon=None):
+        """TM:2439-2567: k-th map component on already-standardised samples x
+        (None = the training samples)."""
+        if x is None:
+            Xs, N = self._Xs, self._N
+        else:
+            x = np.asarray(x)
+            Xs, N = self._import(x, False), x.shape[0]
+        coef = self._pack_coeffs(k, coeffs_nonmon, coeffs_mon)
+        Z = self._empty(1, N)
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, int(k), int(k) + 1,
+                                          self._ptr(Z), N, None, None, None, self._stream()))
+        return Z[0].cpu().numpy()
+
+    def basis(self, k, which, x=None):
+        """Basis matrices of component k on standardised samples (None = training):
+        which 'nonmon' | 'mon' | 'der_mon'  (the reference's fun_nonmon / fun_mon / der_fun_mon)."""
+        sel = {'nonmon': 0, 'mon': 1, 'der_mon': 2}[which]
+        if x is None:
+            Xs, N = self._Xs, self._N
+        else:
+            Xs, N = self._import(np.asarray(x), False), np.asarray(x).shape[0]
+        m = int(self._cm.n_nm[k] if sel == 0 else self._cm.n_mon[k])
+        if m == 0:
+            return None
+        out = self._empty(m, N)
+        _capi.check(self._lib.ttm_basis(self._pp, int(k), sel, self._ptr(Xs), Xs.shape[1], N, self._ptr(out), N,
+                                        self._stream()))
+        return self._export(out, N, 0, m, False)
+
+    # ------------------------------------------------------------------------
+    # densities (separable maps only, as the reference)
+    # ------------------------------------------------------------------------
+
+    def _log_determinant_raw(self, X_full, skip_in_std):
+        """sum_k log( dPsi_mon,k(x_raw) c_k / sigma ) with the derivative basis
+        evaluated on the UN-standardised samples (reference behaviour,
+        TM:2627 / TM:2695) and sigma = X_std[k (+ skip)] (TM:2638 vs TM:2706)."""
+        N = X_full.shape[0]
+        Xraw = self._import(X_full, False)
+        off = self.skip_dimensions if skip_in_std else 0
+        sigma = self._to_dev(np.asarray(self.X_std[off:off + self.D], dtype=float))
+        coef = self._pack_coeffs()
+        ld = self._empty(N)
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xraw), N, N, 0, self.D, None, N,
+                                          self._ptr(ld), self._ptr(sigma), None, self._stream()))
+        return ld
+
+    def evaluate_pullback_density(self, X, X_star=None):
+        """TM:2646-2712."""
+        assert self.monotonicity == "separable monotonicity", \
+            "evaluate_pushforward_density is currently only implemented for monotonicity = 'separable monotonicity'."
+        if X_star is not None:
+            X = np.column_stack((X_star, X))
+        X = np.asarray(X, dtype=float)
+        Xs, N = self._samples_for(X)
+        coef = self._pack_coeffs()
+        ss = self._empty(N)
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+                                          None, N, None, None, self._ptr(ss), self._stream()))
+        ld = self._log_determinant_raw(X, skip_in_std=False)
+        log_ref = -0.5 * (self.D * np.log(2 * np.pi) + ss.cpu().numpy())
+        return np.exp(log_ref + ld.cpu().numpy())
+
+    def evaluate_pushforward_density(self, Z, log_target_pdf, X_star=None):
+        """TM:2569-2644."""
+        assert self.monotonicity == "separable monotonicity", \
+            "evaluate_pushforward_density is currently only implemented for monotonicity = 'separable monotonicity'."
+        X = self.inverse_map(Z, X_star)
+        log_target_densities = log_target_pdf(X)
+        if X_star is not None:
+            X = np.column_stack((X_star, X))
+        ld = self._log_determinant_raw(np.asarray(X, dtype=float), skip_in_std=True)
+        return np.exp(log_target_densities - ld.cpu().numpy())
+
+    # ------------------------------------------------------------------------
+    # inverse map
+    # ------------------------------------------------------------------------
+
+    def inverse_map(self, Z, X_star=None):
+        """TM:3639-3796: sequential inversion of the components; the three
+        conditioning shapes of the reference."""
+        torch = _torch()
+        Z = np.array(Z, dtype=float, copy=True)
+        N = Z.shape[0]
+        d = self._cm.d_cols
+        skip = self.skip_dimensions
+        if X_star is None:
+            k0, E, Xstar_cols = 0, 0, None
+        else:
+            X_star = np.asarray(X_star, dtype=float)
+            if X_star.shape[-1] == skip:
+                k0, E, Xstar_cols = 0, skip, X_star
+            elif skip == 0:
+                E = X_star.shape[-1]
+                k0, Xstar_cols = E, X_star
+                if E + Z.shape[-1] != self.D:
+                    raise ValueError('X_star and Z must together have %d columns' % self.D)
+            else:
+                raise UnboundLocalError("local variable 'X' referenced before assignment")   # as the reference
+        k1 = self.D
+        ncomp = k1 - k0
+        if Z.shape[-1] < ncomp:
+            raise IndexError('Z has %d columns, %d are needed' % (Z.shape[-1], ncomp))
+        Xs = self._zeros(d, N)
+        if Xstar_cols is not None and E > 0:
+            cols = np.array(Xstar_cols, dtype=float, copy=True)
+            if self.standardize_samples:
+                cols -= self.X_mean[:E]
+                cols /= self.X_std[:E]
+            Xs[:E].copy_(torch.from_numpy(np.ascontiguousarray(cols.T)))
+        Zs = self._to_dev(np.ascontiguousarray(Z[:, :ncomp].T))
+        coef = self._pack_coeffs()
+        table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
+        if table:
+            self._inverse_table(coef, k0, k1, Zs, Xs, N)
+        else:
+            self._inverse_bisect(coef, k0, k1, Zs, Xs, N)
+        X = self._export(Xs, N, 0, d, self.standardize_samples)
+        return X[:, skip:]
+
+    def _inverse_table(self, coef, k0, k1, Zs, Xs, N, resolution=1001, start_distance=10):
+        """TM:3987-4084 for all components: tabulate on the device, apply
+        interp1d's stable sort on the (tiny) tables, look up on the device."""
+        ncomp = k1 - k0
+        pts = np.linspace(-start_distance, start_distance, resolution)
+        pts_d = self._to_dev(pts)
+        out_d = self._empty(ncomp, resolution)
+        _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), k0, k1, self._ptr(pts_d), resolution,
+                                                      self._ptr(out_d), self._stream()))
+        out = out_d.cpu().numpy()
+        order = np.argsort(out, axis=1, kind='mergesort')              # interp1d(assume_sorted=False)
+        if np.array_equal(order, np.broadcast_to(np.arange(resolution), order.shape)):
+            tab_x_d, tab_y = out_d, np.broadcast_to(pts, out.shape)
+        else:
+            tab_x_d = self._to_dev(np.take_along_axis(out, order, axis=1))
+            tab_y = pts[order]
+        tab_y_d = self._to_dev(np.ascontiguousarray(tab_y))
+        tmin_d = self._to_dev(np.min(out, axis=1))
+        tmax_d = self._to_dev(np.max(out, axis=1))
+        _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, N,
+                                                self._ptr(tab_x_d), self._ptr(tab_y_d), resolution, self._ptr(tmin_d),
+                                                self._ptr(tmax_d), 1 if self.root_search_truncation else 0,
+                                                self._stream()))
+
+    def _inverse_bisect(self, coef, k0, k1, Zs, Xs, N):
+        """TM:3798-3985.  Samples 1..N-1 run to convergence and record the largest
+        midpoint-iteration count per component; global sample 0 is then replayed
+        with that count as its cap, which is what the reference's
+        ``while np.sum(indices) > 0`` guard (TM:3952) does to it."""
+        torch = _torch()
+        ncomp = k1 - k0
+        iters = self._zeros(ncomp, dtype=torch.int32)
+        dist = self._dist()
+        owns_first = dist is None or dist.get_rank() == 0
+        first = 1 if owns_first else 0
+        if N - first > 0:
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs, first), N,
+                                                     self._ptr(Xs, first), N, N - first,
+                                                     ctypes.c_void_p(iters.data_ptr()), None, self._stream()))
+        self._allreduce(iters, op='max')
+        if owns_first:
+            dummy = self._zeros(ncomp, dtype=torch.int32)
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, 1,
+                                                     ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(iters.data_ptr()),
+                                                     self._stream()))
+        if self.verbose and int(iters.max().item()) >= 100:
+            print('WARNING: root search stopped at maximum iterations.')
+
+    # ------------------------------------------------------------------------
+    # objective functions
+    # ------------------------------------------------------------------------
+
+    def _device_sums(self, k, coef_k):
+        """One fused objective+gradient reduction over the (local) training samples."""
+        nout = 1 + int(self._cm.n_mon[k]) + (0 if self.monotonicity.lower() == 'separable monotonicity'
+                                              else int(self._cm.n_nm[k]))
+        work = self._workspace(self._lib.ttm_reduce_work_size(nout))
+        out = self._empty(nout)
+        ck = self._to_dev(np.asarray(coef_k, dtype=float))
+        _capi.check(self._lib.ttm_objective(self._pp, int(k), self._ptr(ck), self._ptr(self._Xs), self._Xs.shape[1],
+                                            self._N, self._ptr(work), self._ptr(out), self._stream()))
+        self._allreduce(out)
+        return out.cpu().numpy()
+
+    def _regularization_terms(self, k, div, cn, cm):
+        """TM:3382-3431 and TM:3575-3633."""
+        if self.regularization is None:
+            return 0.0, 0.0
+        if type(self.regularization) != str:
+            raise ValueError("The variable 'regularization' must be either None, 'l1', or 'l2'.")
+        r = self.regularization.lower()
+        if r not in ('l1', 'l2'):
+            raise ValueError("regularization_type must be either 'l1' or 'l2'.")
+        lam = self.regularization_lambda
+        if np.isscalar(lam):
+            ln, lm = lam, lam
+        elif type(lam) == list:
+            ln, lm = np.asarray(lam[k][:div]), np.asarray(lam[k][div:])
+        else:
+            raise ValueError("Data type of regularization_lambda not understood. Must be either scalar or list.")
+        if r == 'l1':
+            return (np.sum(lm * np.abs(cm)) + np.sum(ln * np.abs(cn)),
+                    np.concatenate((ln * np.sign(cn), lm * np.sign(cm))))
+        return (np.sum(lm * cm ** 2) + np.sum(ln * cn ** 2), np.concatenate((ln * 2 * cn, lm * 2 * cm)))
+
+    def _objective_and_gradient(self, coeffs, k, div):
+        if self.monotonicity.lower() != 'integrated rectifier':
+            raise Exception("objective_function is defined for monotonicity = 'integrated rectifier'; separable maps "
+                            "are optimised through the reduced objective of optimize()")
+        if coeffs is None:
+            coeffs = np.concatenate((self.coeffs_nonmon[k], self.coeffs_mon[k]))
+            div = len(self.coeffs_nonmon[k])
+        coeffs = np.asarray(coeffs, dtype=float)
+        key = (int(k), coeffs.tobytes())
+        if self._obj_cache is None or self._obj_cache[0] != key:
+            sums = self._device_sums(k, coeffs)
+            cn, cm = coeffs[:div], coeffs[div:]
+            rJ, rG = self._regularization_terms(k, div, cn, cm)
+            self._obj_cache = (key, sums[0] / self._Nglobal + rJ, sums[1:] / self._Nglobal + rG)
+        return self._obj_cache[1], self._obj_cache[2]
+
+    def objective_function(self, coeffs, k, div=0):
+        """TM:3300-3433."""
+        return self._objective_and_gradient(coeffs, k, div)[0]
+
+    def objective_function_jacobian(self, coeffs, k, div=0):
+        """TM:3435-3635."""
+        return np.array(self._objective_and_gradient(coeffs, k, div)[1], copy=True)
+
+    # ------------------------------------------------------------------------
+    # optimisation
+    # ------------------------------------------------------------------------
+
+    def _gram(self, k):
+        m = int(self._cm.n_nm[k] + self._cm.n_mon[k])
+        work = self._workspace(self._lib.ttm_reduce_work_size(m * m))
+        out = self._empty(m * m)
+        _capi.check(self._lib.ttm_gram(self._pp, int(k), self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
+                                       self._ptr(out), self._stream()))
+        self._allreduce(out)
+        return out.cpu().numpy().reshape(m, m)
+
+    def separable_setup(self, k):
+        """The reduced separable problem of TM:2959-3050 from the Gram matrix of
+        [Psi_nonmon | Psi_mon] (one device pass instead of QR / inv on N x m
+        matrices).  Returns (A, solve_nonmon) with solve_nonmon(c_mon) -> c_nonmon
+        (TM:3148-3169)."""
+        n_nm = int(self._cm.n_nm[k])
+        if n_nm == 0:
+            raise ValueError('separable monotonicity needs at least one nonmonotone term (TM:2966)')
+        G = self._gram(k)
+        Gnn, Gnm, Gmm = G[:n_nm, :n_nm], G[:n_nm, n_nm:], G[n_nm:, n_nm:]
+        N = self._Nglobal
+        if self.regularization is None:
+            sol = np.linalg.solve(Gnn, Gnm)
+            A = (Gmm - Gnm.T @ sol) / N
+            A = (A + A.T) / 2
+            return A, (lambda c: -(sol @ c))
+        if self.regularization.lower() == 'l2':
+            lam = self.regularization_lambda
+            Gm = np.linalg.solve(Gnn + lam * np.identity(n_nm), Gnm)
+            dd = Gmm - Gnm.T @ Gm - Gm.T @ Gnm + Gm.T @ Gnn @ Gm
+            A = dd / 2 + lam * (Gm.T @ Gm + np.identity(Gm.shape[-1]))      # no 1/N: as TM:3040-3050
+            A = (A + A.T) / 2
+            sol2 = np.linalg.solve(Gnn + 2 * lam * np.identity(n_nm), Gnm)
+            return A, (lambda c: -(sol2 @ c))
+        raise ValueError("separable monotonicity supports regularization None or 'l2' (TM:2959, 3021)")
+
+    def separable_objective(self, coeffs_mon, A, k):
+        """TM:2978-3018: (objective, gradient) of the reduced problem."""
+        c = np.asarray(coeffs_mon, dtype=float)
+        sums = self._device_sums(k, np.concatenate((np.zeros(int(self._cm.n_nm[k])), c)))
+        N = self._Nglobal
+        b = self.delta * np.sum(A, axis=-1)
+        Ax = A @ c
+        objective = c @ Ax / 2 - sums[0] / N + np.inner(c, b)
+        grad = Ax - sums[1:] / N + b
+        return objective, grad
+
+    def optimize(self, K=None):
+        """TM:2714-2901: per-component SciPy minimisation (BFGS / L-BFGS-B as
+        TM:3252-3257 / TM:3108-3114) driven by the device reductions."""
+        from scipy.optimize import minimize
+        if K is None:
+            K = np.arange(self.D)
+        for k in K:
+            k = int(k)
+            if self.monotonicity == "integrated rectifier":
+                div = len(self.coeffs_nonmon[k])
+                x0 = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float),
+                                     np.asarray(self.coeffs_mon[k], dtype=float)))
+                opt = minimize(method='BFGS', fun=self.objective_function, jac=self.objective_function_jacobian,
+                               x0=x0, args=(k, div))
+                self.coeffs_nonmon[k] = copy.deepcopy(opt.x[:div])
+                self.coeffs_mon[k] = copy.deepcopy(opt.x[div:])
+            elif self.monotonicity == "separable monotonicity":
+                A, solve_nonmon = self.separable_setup(k)
+                bounds = [[self.optimization_constraints_lb[k][i], self.optimization_constraints_ub[k][i]]
+                          for i in range(len(self.optimization_constraints_lb[k]))]
+                opt = minimize(fun=self.separable_objective, method='L-BFGS-B',
+                               x0=np.asarray(self.coeffs_mon[k], dtype=float), jac=True, bounds=bounds, args=(A, k))
+                self.coeffs_mon[k] = copy.deepcopy(opt.x)
+                self.coeffs_nonmon[k] = solve_nonmon(opt.x)
+            if self.verbose:
+                string = '\r' + 'Progress: |' + (k + 1) * '█' + (len(K) - k - 1) * ' ' + '|'
+                print(string, end='\r')
+        return
