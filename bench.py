@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""
+bench.py - headline benchmark of the MI355X transport-map engine.
+
+Metric (BASELINE.json): map-evals/s, forward + inverse, N samples x D components,
+with the ensemble resident in HBM (column-major, the engine's native layout).
+One "step" = one forward map of the whole ensemble followed by one inverse map
+of the result (table inverse for separable maps, reference bisection semantics
+for integrated-rectifier maps).  value = N * D * steps / time, summed over ranks
+(weak scaling: every rank owns its own N-sample ensemble; the path has no
+data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C5|C2a|C2b|C3]
+
+prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel
+(forward map: algorithmic bytes 8 N (d_used + D)) and a
+`cpu_baseline` object (the CPU oracle timed on a bounded sample, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (config, N, golden coefficient fixture, description)
+    'C5': ('C5', 1000000, 'c5_sep', 'd=40 banded separable map, order 3, N=1e6 (Gaussian-mixture target)'),
+    'C3': ('C3', 500000, 'c3_sep', 'd=4 dense separable map, order 4, N=5e5 (banana target)'),
+    'C2b': ('C2b', 1000000, 'c2b_sep', 'spiral d=2 separable map, order 5, N=1e6'),
+    'C2a': ('C2a', 1000000, 'c2a_int', 'spiral d=2 integrated-rectifier map, order 5, Q=25, N=1e6'),
+}
+
+
+def load_coeffs(fixture, D):
+    npz = np.load(os.path.join(ROOT, 'tests', 'golden', fixture + '.npz'))
+    return ([npz['coeffs_mon_%d' % k] for k in range(D)], [npz['coeffs_nonmon_%d' % k] for k in range(D)])
+
+
+def build_map(workload, rank, n_override=None):
+    from triangular_transport_toolbox_amd import specs
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    cfgname, N, fixture, _ = WORKLOADS[workload]
+    if n_override:
+        N = n_override
+    cfg = specs.config(cfgname)
+    seed = {'C5': 12345, 'C3': 0, 'C2b': 0, 'C2a': 0}[workload] + 1000 * rank
+    X = cfg['sampler'](N, seed=seed)
+    tm = transport_map(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], verbose=False, **cfg['kwargs'])
+    tm.coeffs_mon, tm.coeffs_nonmon = load_coeffs(fixture, tm.D)
+    return tm, X, cfg
+
+
+def d_used(tm):
+    """number of distinct sample columns the forward map reads"""
+    cols = set()
+    for k in range(tm.D):
+        cols.add(k + tm.skip_dimensions)
+        for entry in list(tm.monotone[k]) + list(tm.nonmonotone[k]):
+            if isinstance(entry, str):
+                cols.add(int(entry.split(' ')[1]))
+            else:
+                cols.update(int(e) for e in entry if not isinstance(e, str))
+    return len(cols)
+
+
+def cpu_baseline(workload, X, cfg, tm, n_cpu):
+    """The CPU oracle (NumPy restatement of the reference path) on the first n_cpu samples."""
+    from oracle.ttm_oracle import OracleMap      # timed baseline only
+    Xc = X[:n_cpu]
+    om = OracleMap(X=Xc, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], **cfg['kwargs'])
+    om.coeffs_mon = [np.array(c, copy=True) for c in tm.coeffs_mon]
+    om.coeffs_nonmon = [np.array(c, copy=True) for c in tm.coeffs_nonmon]
+    t0 = time.perf_counter()
+    Z = om.map(Xc)
+    t1 = time.perf_counter()
+    om.inverse_map(Z)
+    t2 = time.perf_counter()
+    return dict(value=n_cpu * om.D / (t2 - t0), unit='map-evals/s', cores=1, kind='port',
+                sample='oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), forward+inverse on the '
+                       'first %d samples of the same ensemble: forward %.2f s, inverse %.2f s' % (n_cpu, t1 - t0, t2 - t1),
+                host_cores_available=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='C5', choices=sorted(WORKLOADS))
+    ap.add_argument('--n', type=int, default=0, help='override the ensemble size (testing only)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-samples', type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    tm, X, cfg = build_map(args.workload, rank, args.n or None)
+    N, D, d = tm._N, tm.D, tm._cm.d_cols
+    separable = tm.monotonicity == 'separable monotonicity'
+    coef = tm._pack_coeffs()
+    Xs = tm._Xs
+    Z = tm._empty(D, N)
+    Xinv = tm._zeros(d, N)
+
+    def step():
+        tm.forward_device(Xs, N, coef=coef, Z=Z)
+        tm.inverse_device(Z, N, coef=coef, X=Xinv)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    # round trip sanity inside the bench: S^{-1}(S(x)) == x up to the inverse's own accuracy
+    err = float((Xinv - Xs).abs().max().item())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel timing of the dominant kernel (forward map) with HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_inv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for (a, b), (c, e) in zip(ev, ev_inv):
+        a.record()
+        tm.forward_device(Xs, N, coef=coef, Z=Z)
+        b.record()
+        c.record()
+        tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        e.record()
+    torch.cuda.synchronize()
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    inv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_inv]))
+    extra = {}
+    if separable:
+        ld = tm._empty(N)
+        ss = tm._empty(N)
+        sigma = tm._to_dev(np.asarray(tm.X_std[:D], dtype=float))
+        evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for a, b in evp:
+            a.record()
+            tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss)   # fused S, log det, |S|^2
+            b.record()
+        torch.cuda.synchronize()
+        extra['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+
+    if rank == 0:
+        du = d_used(tm)
+        fwd_bytes = 8.0 * N * (du + D)
+        inv_bytes = 8.0 * N * (2 * D)
+        achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get(args.workload, {}).get('k_forward_hbm_bytes_per_launch')
+        out = {
+            'metric': 'map-evals/sec (forward+inverse, N samples x D comps)',
+            'value': world * N * D * args.steps / elapsed,
+            'unit': 'map-evals/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': args.workload + ': ' + WORKLOADS[args.workload][3],
+                       'N_per_gpu': N, 'D': D, 'columns': d, 'inverse': 'table' if separable else 'bisection',
+                       'layout': 'column-major resident in HBM', 'coefficients': 'reference-optimised (tests/golden)'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'k_forward', 'algorithmic_bytes_per_launch': fwd_bytes, 'avg_launch_ms': fwd_ms},
+            'forward_ms': fwd_ms, 'inverse_ms': inv_ms,
+            'inverse_GBps_algorithmic': inv_bytes / (inv_ms * 1e-3) / 1e9,
+            'roundtrip_max_abs_err': err,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = args.cpu_samples or {'C5': 300000, 'C3': 500000, 'C2b': 500000, 'C2a': 5000}[args.workload]
+            out['cpu_baseline'] = cpu_baseline(args.workload, X, cfg, tm, min(n_cpu, N))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

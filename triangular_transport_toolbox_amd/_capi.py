@@ -64,6 +64,10 @@ def load():
         if not os.path.exists(path):
             raise RuntimeError('libttm.so is not built (%s); run `python -c "import __graft_entry__ as g; g.build()"` '
                                'or `python -m triangular_transport_toolbox_amd.build`' % path)
+        # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It has to be
+        # loaded first so that libttm.so binds to that one runtime: two runtimes in a process
+        # cannot share streams / allocations (and the second one finds no GPU).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

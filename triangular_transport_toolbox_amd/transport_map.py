@@ -372,6 +372,29 @@ class transport_map():
                                           self._ptr(Z), N, None, None, None, self._stream()))
         return self._export(Z, N, 0, self.D, False)
 
+    # device-resident entry points (column-major tensors in, column-major tensors out; no PCIe traffic)
+    def forward_device(self, Xs, N, coef=None, Z=None, logdet=None, sigma=None, sumsq=None):
+        """S(x) for a standardised column-major device matrix Xs (d x N) -> Z (D x N)."""
+        coef = self._pack_coeffs() if coef is None else coef
+        Z = self._empty(self.D, N) if Z is None else Z
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+                                          self._ptr(Z), Z.shape[1], self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq),
+                                          self._stream()))
+        return Z
+
+    def inverse_device(self, Zs, N, coef=None, X=None, table=None):
+        """S^{-1}(z) for a column-major device matrix Zs (D x N) -> standardised X (d x N);
+        conditioning columns (if any) must already be in X."""
+        coef = self._pack_coeffs() if coef is None else coef
+        X = self._zeros(self._cm.d_cols, N) if X is None else X
+        if table is None:
+            table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
+        if table:
+            self._inverse_table(coef, 0, self.D, Zs, X, N)
+        else:
+            self._inverse_bisect(coef, 0, self.D, Zs, X, N)
+        return X
+
     def s(self, x, k, coeffs_nonmon=None, coeffs_mon=None):
         """TM:2439-2567: k-th map component on already-standardised samples x
         (None = the training samples)."""
