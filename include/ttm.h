@@ -72,14 +72,28 @@ extern "C" {
 /* int32 layout of one component block inside ttm_program.itab
  * (block k spans itab[h_comp_off[k] .. h_comp_off[k+1]) ):
  *   header  : TTM_HDR_LEN int32
- *   terms   : 4 int32 each  {f0, nf, b, ci}        nonmonotone terms, then monotone terms
- *   factors : 4 int32 each  {var, kind, order, p0}  factors on columns other than kc
- *   bfuns   : 4 int32 each  {kind, order, p0, 0}    distinct functions of x_kc alone, ordered
- *                                                   [HF by order][POLY by order][special terms]
- * f0 indexes the component's factor list, b its bfun list (-1: term has no x_kc
- * factor), ci the coefficient inside coeffs_nonmon[k] / coeffs_mon[k], p0 the
- * component's slice of dpar (HF: a_n ; special term: centre, scale). */
-#define TTM_HDR_LEN      16
+ *   terms   : 4 int32 each  {f0, nf, b, ci}         nonmonotone terms, then monotone terms
+ *   factors : 4 int32 each  {var, kind, order, p0}   factors on columns other than kc
+ *   bfuns   : 4 int32 each  {kind, order, p0, 0}     distinct functions of x_kc alone, ordered
+ *                                                    [HF by order][POLY by order][special terms]
+ *   groups  : 4 int32 each  {var, P, off, has_hf}    univariate polynomial/HF nonmonotone terms,
+ *                                                    grouped per variable: folded[off .. off+P) are the
+ *                                                    summed coefficients of P_1..P_P, the next P those of
+ *                                                    a_n P_n exp(-x^2/4)
+ *   gen     : 1 int32 each                           indices of the nonmonotone terms NOT covered by
+ *                                                    groups / the constant (cross terms, special terms)
+ *   mnt     : 1 int32 each                           indices of monotone terms with factors on other columns
+ * and, in the separate table ttm_program.ftab (block k at ftab[h_ftab_off[k] ..), read once per launch:
+ *   fslots  : 2 int32 each  {src0, nsrc}             recipe of each folded coefficient
+ *   fsrc    : 2 int32 each  {ci, p0}                 coefficient index within [nonmon | mon] and an
+ *                                                    optional dpar multiplier (-1: none)
+ * f0 indexes the component's factor list, b its bfun list (-1: term has no x_kc factor), ci the
+ * coefficient inside coeffs_nonmon[k] / coeffs_mon[k], p0 the component's slice of dpar
+ * (HF: a_n ; special term: centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)).
+ * Folded coefficients (recomputed from the coefficient vector when a kernel stages the program):
+ *   [0] sum of constant nonmonotone coefficients | group arrays | wB[0..nB] = summed coefficients of the
+ *   monotone terms that are functions of x_kc alone, per B function (slot nB: terms without x_kc). */
+#define TTM_HDR_LEN      28
 #define TTM_HDR_KC        0   /* column of x_k in the sample matrix (k + skip_dimensions) */
 #define TTM_HDR_N_NM      1
 #define TTM_HDR_OFF_NM    2
@@ -96,10 +110,24 @@ extern "C" {
 #define TTM_HDR_FLAGS    13   /* bit0: every monotone term is a function of x_kc alone */
 #define TTM_HDR_N_DPAR   14   /* doubles of dpar owned by this component                      */
 #define TTM_HDR_LEN_BLK  15   /* int32 length of this component block (header included)      */
+#define TTM_HDR_N_GRP    16
+#define TTM_HDR_OFF_GRP  17
+#define TTM_HDR_N_GEN    18
+#define TTM_HDR_OFF_GEN  19
+#define TTM_HDR_N_MNT    20
+#define TTM_HDR_OFF_MNT  21
+#define TTM_HDR_N_FOLD   22   /* doubles of folded coefficients of this component             */
+#define TTM_HDR_OFF_FSLOT 23
+#define TTM_HDR_OFF_FSRC 24
+#define TTM_HDR_OFF_WB   25   /* offset of wB inside the folded array                          */
+#define TTM_HDR_RSV0     26
+#define TTM_HDR_RSV1     27
+#define TTM_ST_NPAR       5   /* dpar doubles per special term                                 */
 
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
+    const int32_t* ftab;        /* fold recipes of all components, back to back    */
     const double*  dpar;        /* HF constants and special-term (centre, scale)   */
     const double*  quad_x;      /* Gauss-Legendre nodes   (TM:199-225), length Q   */
     const double*  quad_w;      /* Gauss-Legendre weights,               length Q   */
@@ -107,8 +135,15 @@ typedef struct ttm_program {
     const int32_t* h_comp_off;  /* into itab                                       */
     const int32_t* h_dpar_off;  /* into dpar                                       */
     const int32_t* h_coef_off;  /* into the coefficient vector [nonmon_k | mon_k]  */
-    const int32_t* h_nslots;    /* length D: nB+1, per-sample scratch words needed */
+    const int32_t* h_nslots;    /* length D: per-sample scratch doubles the map kernels need
+                                   (nB+1 for components with monotone cross terms, else 0) */
     const int32_t* h_n_nm;      /* length D: number of nonmonotone terms           */
+    const int32_t* h_fold_off;  /* length D+1: prefix offsets of folded coefficients */
+    const int32_t* h_ftab_off;  /* length D+1: prefix offsets into ftab              */
+    const int32_t* h_nb1;       /* length D: nB+1 (distinct x_k functions + 1)      */
+    /* device copy of the five prefix tables, 5 x (D+1) int32:
+       [comp_off | dpar_off | coef_off | fold_off | ftab_off]                        */
+    const int32_t* d_offsets;
     int32_t D;                  /* number of map components (len(monotone))        */
     int32_t d_cols;             /* columns of the sample matrix (skip + D)         */
     int32_t family;             /* TTM_FAM_*                                       */
@@ -138,14 +173,23 @@ int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, con
 int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t dout,
                const double* mean, const double* std, double* Xrow, void* stream);
 
+/* ---- folded coefficients -------------------------------------------------------
+ * The map kernels evaluate the nonmonotone part per variable with summed ("folded") coefficients
+ * and the monotone part through per-function weights (layout: "Folded coefficients" above).
+ * ttm_fold computes them for all components from the coefficient vector
+ * coef = [nonmon_0 | mon_0 | nonmon_1 | ...]; fold has ttm_fold_size(p) doubles.  Call it whenever
+ * the coefficients change, before ttm_forward / ttm_inverse_*.                                    */
+int64_t ttm_fold_size(const ttm_program* p);
+int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream);
+
 /* ---- K2/K3: forward map ------------------------------------------------------
  * TM:2391-2437 map(), TM:2439-2567 s(), TM:4238-4258 GaussQuadrature (fused),
  * TM:4981-5018 rectifier.evaluate; log-determinant part of TM:2618-2641 / 2686-2709.
  * Z[(k-k0)*ldz + n] = S_k(x_n) for k in [k0,k1).  Z may be NULL (derivative only).
  * logdet (nullable, length N): sum_k log( (dS_k/dx_k) / sigma[k-k0] )  (sigma NULL: no division)
  * sumsq  (nullable, length N): sum_k S_k(x_n)^2, the Mahalanobis part of TM:2681-2684.            */
-int ttm_forward(const ttm_program* p, const double* coef, const double* Xsoa, int64_t ldx, int64_t N,
-                int32_t k0, int32_t k1, double* Zsoa, int64_t ldz,
+int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* Xsoa, int64_t ldx,
+                int64_t N, int32_t k0, int32_t k1, double* Zsoa, int64_t ldz,
                 double* logdet, const double* sigma, double* sumsq, void* stream);
 
 /* ---- basis matrices (inspection / tests) -------------------------------------
@@ -160,14 +204,24 @@ int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa
  * ttm_inverse_table: for k in [k0,k1) sequentially: offset = Psi_nonmon_k(x) . c_nonmon_k,
  *   target = clip(-offset + Z_k, tmin_k, tmax_k) (if truncate), x_k = lerp on (tab_x, tab_y) with
  *   scipy.interpolate.interp1d semantics (searchsorted-left, clip to [1,T-1], slope form).
- *   tab_x/tab_y: (k1-k0) x T, tab_x non-decreasing (the host applies interp1d's stable sort).
+ *   tab_x: (k1-k0) x T, non-decreasing (the host applies interp1d's stable sort); tab_y: the matching
+ *   abscissae, row k at tab_y + (k-k0)*ldy (ldy = 0: one shared row, e.g. the unpermuted linspace).
+ *   bkt (int32, (k1-k0) x (nb+1)): search accelerator, bkt[b] = searchsorted_left(tab_x, tmin + b (tmax-tmin)/nb);
+ *   the kernel bisects only inside the buckets around the target - same index as the full search.
  *   Xsoa holds the conditioning columns on entry and receives column kc of every component.       */
-int ttm_inverse_table_build(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+int ttm_inverse_table_build(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                             const double* pts, int32_t T, double* out, void* stream);
-int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+/* ttm_inverse_table_index: for ncomp tables (rows of tab_x, length T) compute on the device what the lookup
+ * needs: tmin/tmax (np.min / np.max of the row, TM:4075-4076), the bucket index bkt (ncomp x (nb+1)) and
+ * unsorted[i] = 1 when row i is not non-decreasing (then interp1d's stable sort must be applied first -
+ * the host does that rare case - and tmin/tmax/bkt of that row are not valid).                          */
+int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32_t nb, double* tmin, double* tmax,
+                            int32_t* bkt, int32_t* unsorted, void* stream);
+int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
-                      const double* tab_x, const double* tab_y, int32_t T,
-                      const double* tmin, const double* tmax, int32_t truncate, void* stream);
+                      const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,
+                      const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
+                      int32_t truncate, void* stream);
 
 /* ---- K5: bisection inverse (both monotonicity modes) -----------------------------
  * TM:3798-3985 vectorized_root_search_bisection, exact bracket / window-shift / midpoint
@@ -177,7 +231,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int3
  * cap (nullable, int32, length k1-k0): when given, every sample stops after cap[k-k0] midpoint
  *   iterations - used to replay global sample 0 under the reference's `np.sum(indices) > 0`
  *   loop guard (TM:3952).                                                                          */
-int ttm_inverse_bisect(const ttm_program* p, const double* coef, int32_t k0, int32_t k1,
+int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                        const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                        int32_t* iters, const int32_t* cap, void* stream);
 
@@ -187,7 +241,8 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, int32_t k0, int
  * separable : inner loop of TM:2978-3018 fun_mon_objective
  *   out[0] = sum_n log dS_n, out[1+i] = sum_n dPsi_{n,i}/dS_n, dS = dPsi.c + delta*rowsum(dPsi)
  * (regularisation, 1/N and the A-matrix terms are O(m) host arithmetic).
- * coef_k: device vector [nonmon_k | mon_k] for this component (the trial point).
+ * coef_k: device vector [nonmon_k | mon_k] for this component (the trial point); its folded
+ * coefficients are computed internally into `work`.
  * work: >= ttm_reduce_work_size(nout) doubles.  out: device, nout doubles.                        */
 int64_t ttm_reduce_work_size(int32_t nout);
 int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* Xsoa,

@@ -68,15 +68,20 @@ class EmuMap:
         self.cm = cm
         self.itab = np.ascontiguousarray(cm.itab)
         self.dpar = np.ascontiguousarray(cm.dpar)
+        self.ftab = np.ascontiguousarray(cm.ftab)
+        self.offsets = np.ascontiguousarray(cm.offsets)
         self.qx, self.qw = termtable.gauss_legendre(quad_order)
         self.qx, self.qw = np.ascontiguousarray(self.qx), np.ascontiguousarray(self.qw)
-        self.prog = _capi.make_program(cm, self.itab.ctypes.data, self.dpar.ctypes.data, self.qx.ctypes.data,
-                                       self.qw.ctypes.data, len(self.qx), monotonicity, rectifier, delta)
+        self.prog = _capi.make_program(cm, self.itab.ctypes.data, self.ftab.ctypes.data, self.dpar.ctypes.data, self.qx.ctypes.data,
+                                       self.qw.ctypes.data, self.offsets.ctypes.data, len(self.qx), monotonicity, rectifier, delta)
         self.pp = ctypes.byref(self.prog)
 
     def pack(self, coeffs_nonmon, coeffs_mon):
-        return np.ascontiguousarray(np.concatenate([np.concatenate((np.asarray(n, float), np.asarray(m, float)))
+        coef = np.ascontiguousarray(np.concatenate([np.concatenate((np.asarray(n, float), np.asarray(m, float)))
                                                     for n, m in zip(coeffs_nonmon, coeffs_mon)]))
+        self.fold = np.zeros(max(int(self.cm.fold_off[-1]), 1))
+        lib().ttm_fold(self.pp, ptr(coef), ptr(self.fold), None)
+        return coef
 
     @staticmethod
     def soa(X):
@@ -89,7 +94,7 @@ class EmuMap:
         Z = np.zeros((k1 - k0, N))
         ld = np.zeros(N)
         sg = None if sigma is None else np.ascontiguousarray(sigma, dtype=float)
-        lib().ttm_forward(self.pp, ptr(coef), ptr(X), N, N, k0, k1, ptr(Z), N, ptr(ld), ptr(sg), None, None)
+        lib().ttm_forward(self.pp, ptr(coef), ptr(self.fold), ptr(X), N, N, k0, k1, ptr(Z), N, ptr(ld), ptr(sg), None, None)
         return Z.T.copy(), ld
 
     def basis(self, k, which, Xs):
@@ -120,17 +125,21 @@ class EmuMap:
     def table_build(self, coef, k, pts):
         out = np.zeros(len(pts))
         pts = np.ascontiguousarray(pts)
-        lib().ttm_inverse_table_build(self.pp, ptr(coef), k, k + 1, ptr(pts), len(pts), ptr(out), None)
+        lib().ttm_inverse_table_build(self.pp, ptr(coef), ptr(self.fold), k, k + 1, ptr(pts), len(pts), ptr(out), None)
         return out
 
-    def inverse_table(self, coef, k0, k1, Z, Xinit, tab_x, tab_y, tmin, tmax, truncate=True):
+    def inverse_table(self, coef, k0, k1, Z, Xinit, tab_x, tab_y, tmin, tmax, truncate=True, nb=64):
         X = self.soa(Xinit)
         Zs = self.soa(Z)
         N = X.shape[1]
         tab_x, tab_y = np.ascontiguousarray(tab_x), np.ascontiguousarray(tab_y)
         tmin, tmax = np.ascontiguousarray(tmin), np.ascontiguousarray(tmax)
-        lib().ttm_inverse_table(self.pp, ptr(coef), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(tab_x), ptr(tab_y),
-                                tab_x.shape[1], ptr(tmin), ptr(tmax), int(truncate), None)
+        T = tab_x.shape[1]
+        edges = tmin[:, None] + np.arange(nb + 1)[None, :] * ((tmax - tmin) / nb)[:, None]
+        bkt = np.stack([np.searchsorted(tab_x[i], edges[i], side='left') for i in range(k1 - k0)]).astype(np.int32)
+        bkt[:, 0], bkt[:, -1] = 0, T
+        lib().ttm_inverse_table(self.pp, ptr(coef), ptr(self.fold), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(tab_x), ptr(tab_y),
+                                T, T, ptr(tmin), ptr(tmax), ptr(bkt), nb, int(truncate), None)
         return X.T.copy()
 
     def inverse_bisect(self, coef, k0, k1, Z, Xinit, cap=None):
@@ -139,5 +148,5 @@ class EmuMap:
         N = X.shape[1]
         iters = np.zeros(k1 - k0, dtype=np.int32)
         capa = None if cap is None else np.ascontiguousarray(cap, dtype=np.int32)
-        lib().ttm_inverse_bisect(self.pp, ptr(coef), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(iters), ptr(capa), None)
+        lib().ttm_inverse_bisect(self.pp, ptr(coef), ptr(self.fold), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(iters), ptr(capa), None)
         return X.T.copy(), iters

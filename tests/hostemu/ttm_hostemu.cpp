@@ -40,15 +40,31 @@ struct XFake {
     double operator()(int var) const { return var == kc ? t : 0.0; }
 };
 
+const double kErfTab[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
+
 Prog make_prog(const ttm_program* p) {
     Prog g;
-    g.qx = p->quad_x; g.qw = p->quad_w; g.Q = p->Q; g.family = p->family; g.mono = p->monotonicity;
+    g.qx = p->quad_x; g.qw = p->quad_w; g.erf_tab = kErfTab; g.Q = p->Q; g.family = p->family; g.mono = p->monotonicity;
     g.rect = p->rectifier; g.delta = p->delta;
     return g;
 }
 
-Comp comp_of(const ttm_program* p, int k, const double* coef_k) {
-    return make_comp(p->itab + p->h_comp_off[k], p->dpar + p->h_dpar_off[k], coef_k);
+// component view; fold_k = folded coefficients of this component (NULL: fold here from coef_k)
+struct HostComp {
+    std::vector<double> fold;
+    Comp c;
+};
+
+void comp_of(const ttm_program* p, int k, const double* coef_k, HostComp& h, const double* fold_k = nullptr) {
+    const int* cb = p->itab + p->h_comp_off[k];
+    const double* dp = p->dpar + p->h_dpar_off[k];
+    if (!fold_k) {
+        const int nf = cb[TTM_HDR_N_FOLD];
+        h.fold.assign(nf, 0.0);
+        if (coef_k) fold_coeffs(cb, p->ftab + p->h_ftab_off[k], dp, coef_k, h.fold.data(), 0, 1);
+        fold_k = h.fold.data();
+    }
+    h.c = make_comp(cb, dp, coef_k, fold_k);
 }
 
 }  // namespace
@@ -94,22 +110,34 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
     return 0;
 }
 
-int ttm_forward(const ttm_program* p, const double* coef, const double* X, int64_t ldx, int64_t N, int32_t k0, int32_t k1,
-                double* Z, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void*) {
+int64_t ttm_fold_size(const ttm_program* p) { return p->h_fold_off[p->D]; }
+
+int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
+    for (int k = 0; k < p->D; ++k)
+        fold_coeffs(p->itab + p->h_comp_off[k], p->ftab + p->h_ftab_off[k], p->dpar + p->h_dpar_off[k],
+                    coef + p->h_coef_off[k], fold + p->h_fold_off[k], 0, 1);
+    return 0;
+}
+
+int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
+                int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void*) {
     const Prog g = make_prog(p);
     std::vector<double> scr(4096);
+    std::vector<HostComp> hc(k1 - k0);
+    for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
     for (int64_t n = 0; n < N; ++n) {
-        XSoA x{X, ldx, n};
+        XSoA xa{X, ldx, n};
+        double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
         double ld = 0.0, ss = 0.0;
         for (int k = k0; k < k1; ++k) {
-            const Comp c = comp_of(p, k, coef + p->h_coef_off[k]);
+            const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
             double S, dS;
             if (logdet) {
-                sample_forward<true>(c, g, x, w, Z || sumsq, S, dS);
-                ld += log(sigma ? dS / sigma[k - k0] : dS);
+                sample_forward<-1, true>(c, g, x, w, Z || sumsq, S, dS);
+                ld += fast_log(sigma ? dS / sigma[k - k0] : dS);
             } else {
-                sample_forward<false>(c, g, x, w, true, S, dS);
+                sample_forward<-1, false>(c, g, x, w, true, S, dS);
             }
             if (Z) Z[(int64_t)(k - k0) * ldz + n] = S;
             ss = fma(S, S, ss);
@@ -120,9 +148,50 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* X, int64
     return 0;
 }
 
+// TEST ONLY: forward map evaluated with two samples per "thread" (VecD<2>), as the GPU kernel does
+struct VecSlots2 {
+    double* base;
+    VecD<2> get(int i) const { VecD<2> r; r.v[0] = base[2 * i]; r.v[1] = base[2 * i + 1]; return r; }
+    void set(int i, const VecD<2>& v) { base[2 * i] = v.v[0]; base[2 * i + 1] = v.v[1]; }
+};
+struct XSoA2 {
+    const double* X;
+    int64_t ld, n0, n1;
+    VecD<2> operator()(int var) const { VecD<2> r; r.v[0] = X[(int64_t)var * ld + n0]; r.v[1] = X[(int64_t)var * ld + n1]; return r; }
+};
+
+int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
+                     int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet) {
+    const Prog g = make_prog(p);
+    std::vector<double> scr(8192);
+    std::vector<HostComp> hc(k1 - k0);
+    for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
+    for (int64_t n = 0; n < N; n += 2) {
+        const int64_t n1 = n + 1 < N ? n + 1 : n;
+        XSoA2 xa{X, ldx, n, n1};
+        double cbuf[16];
+        VarCache<XSoA2, VecD<2>> x(xa, CacheStore<VecD<2>>{cbuf, 1});
+        VecD<2> ld(0.0);
+        for (int k = k0; k < k1; ++k) {
+            const Comp& c = hc[k - k0].c;
+            VecSlots2 w{scr.data()};
+            VecD<2> S, dS;
+            sample_forward<-1, true>(c, g, x, w, true, S, dS);
+            ld += fast_log(dS);
+            Z[(int64_t)(k - k0) * ldz + n] = S.v[0];
+            Z[(int64_t)(k - k0) * ldz + n1] = S.v[1];
+        }
+        logdet[n] = ld.v[0];
+        logdet[n1] = ld.v[1];
+    }
+    return 0;
+}
+
 int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* X, int64_t ldx, int64_t N, double* out, int64_t ldo, void*) {
     const Prog g = make_prog(p);
-    const Comp c = comp_of(p, k, nullptr);
+    HostComp h;
+    comp_of(p, k, nullptr, h);
+    const Comp& c = h.c;
     for (int64_t n = 0; n < N; ++n) {
         XSoA x{X, ldx, n};
         sample_basis(c, g, which, x, [&](int i, double v) { out[(int64_t)i * ldo + n] = v; });
@@ -135,14 +204,17 @@ int64_t ttm_reduce_work_size(int32_t nout) { return nout > 0 ? nout : 1; }
 int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* X, int64_t ldx, int64_t N, double*,
                   double* out, void*) {
     const Prog g = make_prog(p);
-    const Comp c = comp_of(p, k, coef_k);
+    HostComp h;
+    comp_of(p, k, coef_k, h);
+    const Comp& c = h.c;
     const int nb1 = c.nB + 1;
     std::vector<double> scr(3 * nb1 + 8);
     const int nacc = g.mono == TTM_MONO_SEPARABLE ? 1 + c.n_mon : 1 + c.n_nm + c.n_mon;
     for (int i = 0; i < nacc; ++i) out[i] = 0.0;
     VecAcc acc{out};
     for (int64_t n = 0; n < N; ++n) {
-        XSoA x{X, ldx, n};
+        XSoA xa{X, ldx, n};
+        double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
         VecSlots w{scr.data()}, Bv{scr.data() + nb1}, I{scr.data() + 2 * nb1};
         if (g.mono == TTM_MONO_SEPARABLE) sample_objective_sep(c, g, x, w, acc);
         else sample_objective_int(c, g, x, w, Bv, I, acc);
@@ -152,7 +224,9 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
 
 int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*) {
     const Prog g = make_prog(p);
-    const Comp c = comp_of(p, k, nullptr);
+    HostComp h;
+    comp_of(p, k, nullptr, h);
+    const Comp& c = h.c;
     const int m = c.n_nm + c.n_mon;
     std::vector<double> row(m);
     for (int i = 0; i < m * m; ++i) out[i] = 0.0;
@@ -166,35 +240,62 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int6
     return 0;
 }
 
-int ttm_inverse_table_build(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* pts, int32_t T,
-                            double* out, void*) {
+int ttm_inverse_table_build(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
+                            const double* pts, int32_t T, double* out, void*) {
     const Prog g = make_prog(p);
     for (int k = k0; k < k1; ++k) {
-        const Comp c = comp_of(p, k, coef + p->h_coef_off[k]);
+        HostComp h;
+        comp_of(p, k, coef + p->h_coef_off[k], h, fold + p->h_fold_off[k]);
+        const Comp& c = h.c;
         std::vector<double> scr(c.nB + 2);
         for (int i = 0; i < T; ++i) {
             XFake x{c.kc, pts[i]};
             VecSlots w{scr.data()};
-            mon_weights(c, g.family, x, w);
+            mon_weights<double>(c, g, x, w);
             double v, dv;
-            g_eval<false>(c, g.family, pts[i], w, v, dv);
+            g_eval<false>(c, g, pts[i], w, v, dv);
             out[(int64_t)(k - k0) * T + i] = v;
         }
     }
     return 0;
 }
 
-int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* Z, int64_t ldz, double* X,
-                      int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int32_t T, const double* tmin,
-                      const double* tmax, int32_t truncate, void*) {
+int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32_t nb, double* tmin, double* tmax,
+                            int32_t* bkt, int32_t* unsorted, void*) {
+    for (int c = 0; c < ncomp; ++c) {
+        const double* xs = tab_x + (int64_t)c * T;
+        int bad = 0;
+        for (int i = 1; i < T; ++i) bad |= !(xs[i - 1] <= xs[i]);
+        tmin[c] = xs[0]; tmax[c] = xs[T - 1]; unsorted[c] = bad;
+        const double step = (xs[T - 1] - xs[0]) / (double)nb;
+        for (int q = 0; q <= nb; ++q) {
+            int a = 0, b = T;
+            if (q == nb) a = T;
+            else if (q > 0) {
+                const double u = xs[0] + (double)q * step;
+                while (a < b) { const int mid = (a + b) >> 1; if (xs[mid] < u) a = mid + 1; else b = mid; }
+            }
+            bkt[(int64_t)c * (nb + 1) + q] = a;
+        }
+    }
+    return 0;
+}
+
+int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
+                      int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
+                      int32_t T, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb, int32_t truncate, void*) {
+    (void)bkt; (void)nb;   // the host double does the full search; the accelerated search must give the same index
     const Prog g = make_prog(p);
     for (int k = k0; k < k1; ++k) {
-        const Comp c = comp_of(p, k, coef + p->h_coef_off[k]);
+        HostComp h;
+        comp_of(p, k, coef + p->h_coef_off[k], h, fold + p->h_fold_off[k]);
+        const Comp& c = h.c;
         const double* xs = tab_x + (int64_t)(k - k0) * T;
-        const double* ys = tab_y + (int64_t)(k - k0) * T;
+        const double* ys = tab_y + (int64_t)(k - k0) * ldy;
         for (int64_t n = 0; n < N; ++n) {
-            XSoA x{X, ldx, n};
-            const double off = nonmon_sum(c, g.family, x);
+            XSoA xa{X, ldx, n};
+            double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
+            const double off = nonmon_sum<double>(c, g, x);
             double target = -off + Z[(int64_t)(k - k0) * ldz + n];
             if (truncate) {
                 if (target < tmin[k - k0]) target = tmin[k - k0];
@@ -206,19 +307,24 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int3
     return 0;
 }
 
-int ttm_inverse_bisect(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* Z, int64_t ldz, double* X,
-                       int64_t ldx, int64_t N, int32_t* iters, const int32_t* cap, void*) {
+int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
+                       int64_t ldz, double* X, int64_t ldx, int64_t N, int32_t* iters, const int32_t* cap, void*) {
     const Prog g = make_prog(p);
     std::vector<double> scr(4096);
+    std::vector<HostComp> hc(k1 - k0);
+    for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
     for (int64_t n = 0; n < N; ++n) {
-        XSoA x{X, ldx, n};
+        XSoA xa{X, ldx, n};
+        double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
         for (int k = k0; k < k1; ++k) {
-            const Comp c = comp_of(p, k, coef + p->h_coef_off[k]);
+            const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
-            const double off = nonmon_sum(c, g.family, x);
-            mon_weights(c, g.family, x, w);
+            const double off = nonmon_sum<double>(c, g, x);
+            mon_weights<double>(c, g, x, w);
             int it = 0;
-            X[(int64_t)c.kc * ldx + n] = sample_bisect(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, cap ? cap[k - k0] : -1, it);
+            const double r = sample_bisect<-1>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, cap ? cap[k - k0] : -1, it);
+            X[(int64_t)c.kc * ldx + n] = r;
+            x.put(c.kc, r);
             if (it > iters[k - k0]) iters[k - k0] = it;
         }
     }

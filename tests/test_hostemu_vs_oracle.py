@@ -194,3 +194,24 @@ def test_inverse_bisect(name):
         Xn1, _ = em.inverse_bisect(coef, 0, om.D, Zin[:1], Xinit[:1], cap=np.zeros(om.D, dtype=np.int32))
         Xn1 = Xn1 * om.X_std + om.X_mean
         assert relerr(Xn1[:, om.skip_dimensions:], npz.get('inv_X_n1', npz.get('inv_X_bisect_n1'))) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['c1_int', 'c3_sep', 'c5_sep', 'misc_grid', 'misc_sep'])
+def test_two_samples_per_thread_path_is_bitwise_equal(name):
+    """The VecD<2> instantiation of the evaluators (what the GPU forward kernel runs) gives the very same
+    bits as the one-sample path, for odd N too."""
+    import ctypes
+    from tests.hostemu import emu
+    npz, desc, om, cm, em, _ = build(name)
+    coef = em.pack(om.coeffs_nonmon, om.coeffs_mon)
+    Xs = om.X[:257]
+    Z1, ld1 = em.forward(coef, Xs)
+    X = em.soa(Xs)
+    N = X.shape[1]
+    Z2 = np.zeros((cm.D, N))
+    ld2 = np.zeros(N)
+    emu.lib().emu_forward_vec2(em.pp, emu.ptr(coef), emu.ptr(em.fold), emu.ptr(X), ctypes.c_int64(N), ctypes.c_int64(N), 0,
+                               cm.D, emu.ptr(Z2), ctypes.c_int64(N), emu.ptr(ld2))
+    assert np.array_equal(Z2.T, Z1)
+    ok = np.isfinite(ld1)
+    assert np.array_equal(ld2[ok], ld1[ok])

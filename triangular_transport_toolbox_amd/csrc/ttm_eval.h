@@ -12,6 +12,15 @@
 // the interpreter logic can be unit-tested without a GPU (tests/hostemu) - that
 // build is test infrastructure, never a fallback of the product.
 //
+// Evaluation strategy:
+//   nonmonotone part  = folded constant
+//                     + per variable: one polynomial recurrence with summed ("folded")
+//                       coefficients for the plain and the Hermite-function terms, one
+//                       exp(-x^2/4) per variable (cached across components in VarCache)
+//                     + generic products for cross terms / special terms
+//   monotone part     = g(t) = w_none + sum_b w_b B_b(t) over the distinct functions of x_k;
+//                       w_b = folded coefficients (+ per-sample products for cross terms)
+//
 // Reference formulas restated (TM = /root/reference/transport_map.py):
 //   factors / special terms  TM:905-1026, 1096-1150, 1166-1248
 //   s() and the quadrature    TM:2499-2558, 4238-4258
@@ -24,26 +33,24 @@
 #include <stdint.h>
 
 #include "../../include/ttm.h"
+#include "ttm_math.h"
 
-#if defined(__HIPCC__)
-#define TTM_HD __host__ __device__ __forceinline__
-#else
-#define TTM_HD inline
-#endif
-
+// Term tables, constants, coefficients and the quadrature rule are identical for every lane.  On the
+// GPU they are read through constant-address-space pointers: the compiler then emits scalar loads
+// (s_load_dword*) into SGPRs, the interpreter's control flow is scalar (s_cbranch) and uniform fp64
+// operands feed v_fma_f64 directly as SGPR pairs - no LDS traffic, no v_readfirstlane, no VGPRs.
 #if defined(__HIP_DEVICE_COMPILE__)
-// table entries are identical in every lane: move them to SGPRs so the
-// interpreter's control flow is scalar (s_cbranch) instead of exec-masked
-#define TTM_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#define TTM_C __attribute__((address_space(4)))
 #else
-#define TTM_UNI(x) (x)
+#define TTM_C
 #endif
+#define TTM_UNI(x) (x)
 
 namespace ttm {
 
-static constexpr double kSqrt2 = 1.4142135623730951;       // np.sqrt(2)
-static constexpr double kSqrt2OverPi = 0.7978845608028654;  // np.sqrt(2/np.pi)
-static constexpr double kSqrt2Pi = 2.5066282746310002;      // np.sqrt(2*np.pi)
+typedef const TTM_C int* cint_p;
+typedef const TTM_C double* cdbl_p;
+
 static constexpr double kLn2 = 0.6931471805599453;          // np.log(2)
 
 // ---------------------------------------------------------------------------
@@ -51,8 +58,9 @@ static constexpr double kLn2 = 0.6931471805599453;          // np.log(2)
 // ---------------------------------------------------------------------------
 
 struct Prog {            // what is common to all components
-    const double* qx;    // quadrature nodes / weights
-    const double* qw;
+    cdbl_p qx;           // quadrature nodes / weights
+    cdbl_p qw;
+    const double* erf_tab;   // per-lane gathers: staged in LDS on the GPU
     int Q;
     int family;
     int mono;
@@ -61,17 +69,21 @@ struct Prog {            // what is common to all components
 };
 
 struct Comp {            // one component block (pointers into staged tables)
-    const int* nm_terms;
-    const int* mon_terms;
-    const int* facs;
-    const int* bfuns;
-    const double* dpar;
-    const double* cnm;   // coefficients of the nonmonotone / monotone terms
-    const double* cmon;
-    int kc, n_nm, n_mon, nB, nB_hf, nB_poly, nB_st, maxP_hf, maxP_poly, flags;
+    cint_p nm_terms;
+    cint_p mon_terms;
+    cint_p facs;
+    cint_p bfuns;
+    cint_p grp;
+    cint_p gen;
+    cint_p mnt;
+    cdbl_p dpar;
+    cdbl_p cnm;          // coefficients of the nonmonotone / monotone terms
+    cdbl_p cmon;
+    cdbl_p fold;         // folded coefficients (see include/ttm.h)
+    int kc, n_nm, n_mon, nB, nB_hf, nB_poly, nB_st, maxP_hf, maxP_poly, flags, n_grp, n_gen, n_mnt, off_wb;
 };
 
-TTM_HD Comp make_comp(const int* cb, const double* dpar, const double* coef) {
+TTM_HD Comp make_comp(cint_p cb, cdbl_p dpar, cdbl_p coef, cdbl_p fold) {
     Comp c;
     c.kc = TTM_UNI(cb[TTM_HDR_KC]);
     c.n_nm = TTM_UNI(cb[TTM_HDR_N_NM]);
@@ -83,30 +95,60 @@ TTM_HD Comp make_comp(const int* cb, const double* dpar, const double* coef) {
     c.maxP_hf = TTM_UNI(cb[TTM_HDR_MAXP_HF]);
     c.maxP_poly = TTM_UNI(cb[TTM_HDR_MAXP_POLY]);
     c.flags = TTM_UNI(cb[TTM_HDR_FLAGS]);
+    c.n_grp = TTM_UNI(cb[TTM_HDR_N_GRP]);
+    c.n_gen = TTM_UNI(cb[TTM_HDR_N_GEN]);
+    c.n_mnt = TTM_UNI(cb[TTM_HDR_N_MNT]);
+    c.off_wb = TTM_UNI(cb[TTM_HDR_OFF_WB]);
     c.nm_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_NM]);
     c.mon_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_MON]);
     c.facs = cb + TTM_UNI(cb[TTM_HDR_OFF_FAC]);
     c.bfuns = cb + TTM_UNI(cb[TTM_HDR_OFF_B]);
+    c.grp = cb + TTM_UNI(cb[TTM_HDR_OFF_GRP]);
+    c.gen = cb + TTM_UNI(cb[TTM_HDR_OFF_GEN]);
+    c.mnt = cb + TTM_UNI(cb[TTM_HDR_OFF_MNT]);
     c.dpar = dpar;
     c.cnm = coef;
     c.cmon = coef + c.n_nm;
+    c.fold = fold;
     return c;
+}
+
+// folded coefficients of one component: slots [first, last) with the given stride
+// (one thread per slot on the GPU; each slot sums its sources in a fixed order);
+// cb = the component's itab block, fb = its ftab block
+TTM_HD void fold_coeffs(const int* cb, const int* fb, const double* dpar, const double* coef, double* fold, int first, int stride) {
+    // (plain pointers: the slot index differs per thread here)
+    const int n = cb[TTM_HDR_N_FOLD];
+    const int* slots = fb + cb[TTM_HDR_OFF_FSLOT];
+    const int* src = fb + cb[TTM_HDR_OFF_FSRC];
+    for (int s = first; s < n; s += stride) {
+        const int s0 = slots[2 * s], ns = slots[2 * s + 1];
+        double acc = 0.0;
+        for (int j = 0; j < ns; ++j) {
+            const int ci = src[2 * (s0 + j)], p0 = src[2 * (s0 + j) + 1];
+            acc += (p0 >= 0) ? coef[ci] * dpar[p0] : coef[ci];
+        }
+        fold[s] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------
 // polynomial families: three-term recurrences with derivative propagation
 //   P_{n+1} = (a x + b) P_n - c P_{n-1}
+// (R = double or VecD<N>: per-sample values; everything else is uniform)
 // ---------------------------------------------------------------------------
 
-TTM_HD void poly_first(int fam, double x, double& p, double& dp) {
+template <class R>
+TTM_HD void poly_first(int fam, const R& x, R& p, R& dp) {
     switch (fam) {
-        case TTM_FAM_HERMITE: p = 2.0 * x; dp = 2.0; break;
-        case TTM_FAM_LAGUERRE: p = 1.0 - x; dp = -1.0; break;
-        default: p = x; dp = 1.0; break;
+        case TTM_FAM_HERMITE: p = 2.0 * x; dp = R(2.0); break;
+        case TTM_FAM_LAGUERRE: p = 1.0 - x; dp = R(-1.0); break;
+        default: p = x; dp = R(1.0); break;
     }
 }
 
-TTM_HD void poly_next(int fam, int n, double x, double& pm, double& p, double& dpm, double& dp) {
+template <bool DER, class R>
+TTM_HD void poly_next(int fam, int n, const R& x, R& pm, R& p, R& dpm, R& dp) {
     double a, b, c;
     switch (fam) {
         case TTM_FAM_HERMITE_E: a = 1.0; b = 0.0; c = (double)n; break;
@@ -116,45 +158,52 @@ TTM_HD void poly_next(int fam, int n, double x, double& pm, double& p, double& d
         case TTM_FAM_LAGUERRE: { double r = 1.0 / (n + 1.0); a = -r; b = (2.0 * n + 1.0) * r; c = n * r; } break;
         default: /* LEGENDRE */ { double r = 1.0 / (n + 1.0); a = (2.0 * n + 1.0) * r; b = 0.0; c = n * r; } break;
     }
-    const double lin = fma(a, x, b);
-    const double pn = fma(lin, p, -c * pm);
-    const double dpn = fma(a, p, fma(lin, dp, -c * dpm));
-    pm = p; p = pn; dpm = dp; dp = dpn;
+    const R lin = vfma(a, x, b);
+    const R pn = vfma(lin, p, -c * pm);
+    if (DER) {
+        const R dpn = vfma(a, p, vfma(lin, dp, -c * dpm));
+        dpm = dp; dp = dpn;
+    }
+    pm = p; p = pn;
 }
 
-// P_order(x) and its derivative, order >= 1
-TTM_HD void poly_eval(int fam, int order, double x, double& P, double& dP) {
-    double pm = 1.0, dpm = 0.0, p, dp;
+// P_order(x), order >= 1
+template <class R>
+TTM_HD R poly_eval(int fam, int order, const R& x) {
+    R pm(1.0), dpm(0.0), p, dp;
     poly_first(fam, x, p, dp);
-    for (int n = 1; n < order; ++n) poly_next(fam, n, x, pm, p, dpm, dp);
-    P = p; dP = dp;
+    for (int n = 1; n < order; ++n) poly_next<false>(fam, n, x, pm, p, dpm, dp);
+    return p;
 }
 
 // ---------------------------------------------------------------------------
-// special terms (TM:917-1016), value and d/dx
+// special terms (TM:917-1016), value and d/dx.
+// par = {centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}
 // ---------------------------------------------------------------------------
 
-template <bool VAL, bool DER>
-TTM_HD void st_eval(int kind, double x, double mu, double sc, double& val, double& der) {
-    const double d = x - mu;
-    val = 0.0; der = 0.0;
+template <bool VAL, bool DER, class R>
+TTM_HD void st_eval(const Prog& p, int kind, const R& x, cdbl_p par, R& val, R& der) {
+    const R d = x - par[0];
+    const R t = d * par[2];
+    val = R(0.0); der = R(0.0);
+    R e, g;
     if (kind == TTM_KIND_LET || kind == TTM_KIND_RET) {
-        const double t = d / (kSqrt2 * sc);
-        const double e = erf(t);
-        const double sgn = (kind == TTM_KIND_LET) ? -1.0 : 1.0;
+        if (VAL) erf_gauss_tab<true>(p.erf_tab, t, e, g); else erf_gauss_tab<false>(p.erf_tab, t, e, g);
+        const R h = (kind == TTM_KIND_LET) ? vfma(e, -0.5, 0.5) : vfma(e, 0.5, 0.5);   // (1 -/+ erf)/2
         if (VAL) {
-            const double g = exp(-(t * t));
-            val = (d * (1.0 + sgn * e) + sgn * (sc * kSqrt2OverPi * g)) / 2.0;
+            const R gg = (0.5 * par[3]) * g;
+            val = (kind == TTM_KIND_LET) ? vfma(d, h, -gg) : vfma(d, h, gg);
         }
-        if (DER) der = (1.0 + sgn * e) / 2.0;
+        if (DER) der = h;
     } else if (kind == TTM_KIND_RBF) {
-        const double u = d / sc;
-        const double g = exp(-(u * u) / 2.0);
-        if (VAL) val = g / (sc * kSqrt2Pi);
-        if (DER) der = -d / (kSqrt2Pi * (sc * sc * sc)) * g;
+        erf_gauss_tab<true>(p.erf_tab, t, e, g);
+        const R gg = g * par[4];
+        if (VAL) val = gg;
+        if (DER) der = (-2.0 * par[2]) * t * gg;                                    // -(x-mu)/scale^2 * value
     } else {  // TTM_KIND_IRBF
-        if (VAL) val = (1.0 + erf(d / (kSqrt2 * sc))) / 2.0;
-        if (DER) der = 1.0 / (kSqrt2Pi * sc) * exp(-(d * d) / (2.0 * (sc * sc)));
+        if (DER) erf_gauss_tab<true>(p.erf_tab, t, e, g); else erf_gauss_tab<false>(p.erf_tab, t, e, g);
+        if (VAL) val = vfma(e, 0.5, 0.5);
+        if (DER) der = par[4] * g;
     }
 }
 
@@ -162,176 +211,275 @@ TTM_HD void st_eval(int kind, double x, double mu, double sc, double& val, doubl
 // rectifiers
 // ---------------------------------------------------------------------------
 
-TTM_HD double rect_eval(int mode, double g) {
+template <class R>
+TTM_HD R rect_eval(int mode, const R& g) {
     switch (mode) {
-        case TTM_RECT_EXPONENTIAL: return exp(g);
-        case TTM_RECT_SOFTPLUS: { const double ag = kLn2 * g; return log(1.0 + exp(-fabs(ag))) + (ag < 0.0 ? 0.0 : ag); }
+        case TTM_RECT_EXPONENTIAL: return fast_exp(g);
+        case TTM_RECT_SOFTPLUS: { const R ag = kLn2 * g; return fast_log(1.0 + fast_exp(-vabs(ag))) + vselect_lt0(ag, R(0.0), ag); }
         case TTM_RECT_SQUARED: return g * g;
-        case TTM_RECT_EXPNEG: return exp(-g);
-        default: return g < 0.0 ? exp(g) : g + 1.0;   // ELU, TM:5012-5016
+        case TTM_RECT_EXPNEG: return fast_exp(-g);
+        default: return vselect_lt0(g, fast_exp(g), g + 1.0);   // ELU, TM:5012-5016
     }
 }
 
 // r(g), the factor of evaluate_dfdc (TM:5112-5165) and log(r + delta) as logevaluate (TM:5167-5213)
-TTM_HD void rect_all(int mode, double delta, double g, double& r, double& dr, double& logr) {
+template <class R>
+TTM_HD void rect_all(int mode, double delta, const R& g, R& r, R& dr, R& logr) {
     switch (mode) {
         case TTM_RECT_EXPONENTIAL:
-            r = exp(g); dr = r; logr = (delta == 0.0) ? g : log(r + delta); break;
+            r = fast_exp(g); dr = r; logr = (delta == 0.0) ? g : fast_log(r + delta); break;
         case TTM_RECT_SOFTPLUS:
-            r = rect_eval(mode, g); dr = 1.0 / (1.0 + exp(-kLn2 * g)); logr = log(r + delta); break;
+            r = rect_eval(mode, g); dr = fast_rcp(1.0 + fast_exp(-kLn2 * g)); logr = fast_log(r + delta); break;
         case TTM_RECT_EXPNEG:
-            r = exp(-g); dr = -r; logr = -g; break;
+            r = fast_exp(-g); dr = -r; logr = -g; break;
         case TTM_RECT_SQUARED:
-            r = g * g; dr = NAN; logr = log(r); break;          // dfdc "not implemented" in the reference
+            r = g * g; dr = R(NAN); logr = fast_log(r); break;     // dfdc "not implemented" in the reference
         default:
-            r = rect_eval(mode, g); dr = NAN; logr = log(r); break;
+            r = rect_eval(mode, g); dr = R(NAN); logr = fast_log(r); break;
     }
 }
+
+// ---------------------------------------------------------------------------
+// per-sample cache of recently used columns: x_j and exp(-x_j^2/4).
+// Tags are uniform (SGPRs); banded maps reuse each column in 2-3 consecutive
+// components, the inverse kernels read back columns they have just written.
+// ---------------------------------------------------------------------------
+
+template <class R>
+struct CacheStore {          // 8 values per sample: x of four columns, then their exp(-x^2/4)
+    double* base;            // this thread's column
+    int stride;              // doubles between consecutive slots of one element
+    TTM_HD R get(int i) const {
+        R r;
+#pragma unroll
+        for (int e = 0; e < lanes_of<R>::value; ++e) set_elem(r, e, base[(i * lanes_of<R>::value + e) * stride]);
+        return r;
+    }
+    TTM_HD void set(int i, const R& v) const {
+#pragma unroll
+        for (int e = 0; e < lanes_of<R>::value; ++e) base[(i * lanes_of<R>::value + e) * stride] = elem(v, e);
+    }
+};
+
+template <class XA, class R>
+struct VarCache {
+    // four ways; tags / valid flags are uniform (SGPRs), the values live in a per-thread LDS column
+    // (keeping them in VGPRs costs a register shuffle at every uniform branch merge)
+    const XA& xa;
+    CacheStore<R> st;
+    int t0, t1, t2, t3;          // tags
+    int h0, h1, h2, h3;          // exp(-x^2/4) valid
+    int rr;
+    TTM_HD VarCache(const XA& x, const CacheStore<R>& store)
+        : xa(x), st(store), t0(-1), t1(-1), t2(-1), t3(-1), h0(0), h1(0), h2(0), h3(0), rr(0) {}
+    TTM_HD int find(int var) const { return t0 == var ? 0 : (t1 == var ? 1 : (t2 == var ? 2 : (t3 == var ? 3 : -1))); }
+    TTM_HD void set_h(int s, int v) { if (s == 0) h0 = v; else if (s == 1) h1 = v; else if (s == 2) h2 = v; else h3 = v; }
+    TTM_HD int get_h(int s) const { return s == 0 ? h0 : (s == 1 ? h1 : (s == 2 ? h2 : h3)); }
+    TTM_HD int put(int var, const R& x) {
+        int s = find(var);
+        if (s < 0) {
+            s = rr;
+            rr = (rr + 1) & 3;
+            if (s == 0) t0 = var; else if (s == 1) t1 = var; else if (s == 2) t2 = var; else t3 = var;
+        }
+        set_h(s, 0);
+        st.set(s, x);
+        return s;
+    }
+    TTM_HD R get(int var) {
+        const int s = find(var);
+        if (s >= 0) return st.get(s);
+        const R x = xa(var);
+        put(var, x);
+        return x;
+    }
+    // x and exp(-x^2/4)
+    TTM_HD void get_e(int var, R& x, R& e) {
+        int s = find(var);
+        if (s >= 0) {
+            x = st.get(s);
+        } else {
+            x = xa(var);
+            s = put(var, x);
+        }
+        if (get_h(s)) {
+            e = st.get(4 + s);
+        } else {
+            e = fast_exp(-0.25 * (x * x));
+            st.set(4 + s, e);
+            set_h(s, 1);
+        }
+    }
+    TTM_HD R operator()(int var) { return get(var); }
+};
 
 // ---------------------------------------------------------------------------
 // A-part of a term: product of its factors on columns other than kc
 // (all 'HF' factors of one term share a single exp(-sum x^2 / 4))
 // ---------------------------------------------------------------------------
 
-template <class XA>
-TTM_HD double eval_A(const int* term, const Comp& c, int fam, const XA& x) {
+template <class R, class XA>
+TTM_HD R eval_A(cint_p term, const Comp& c, const Prog& p, XA& x) {
     const int f0 = TTM_UNI(term[0]);
     const int nf = TTM_UNI(term[1]);
-    double prod = 1.0, ssq = 0.0;
+    R prod(1.0), ssq(0.0);
     bool hf = false;
     for (int f = 0; f < nf; ++f) {
-        const int* F = c.facs + 4 * (f0 + f);
+        cint_p F = c.facs + 4 * (f0 + f);
         const int var = TTM_UNI(F[0]);
         const int kind = TTM_UNI(F[1]);
         const int order = TTM_UNI(F[2]);
         const int p0 = TTM_UNI(F[3]);
-        const double xv = x(var);
+        const R xv = x(var);
         if (kind == TTM_KIND_POLY || kind == TTM_KIND_HF) {
-            double P, dP;
-            poly_eval(fam, order, xv, P, dP);
+            const R P = poly_eval(p.family, order, xv);
             if (kind == TTM_KIND_HF) {
-                prod *= c.dpar[p0] * P;
-                ssq = fma(xv, xv, ssq);
+                prod = prod * (c.dpar[p0] * P);
+                ssq = vfma(xv, xv, ssq);
                 hf = true;
             } else {
-                prod *= P;
+                prod = prod * P;
             }
         } else {
-            double v, dv;
-            st_eval<true, false>(kind, xv, c.dpar[p0], c.dpar[p0 + 1], v, dv);
-            prod *= v;
+            R v, dv;
+            st_eval<true, false>(p, kind, xv, c.dpar + p0, v, dv);
+            prod = prod * v;
         }
     }
-    if (hf) prod *= exp(-0.25 * ssq);
+    if (hf) prod = prod * fast_exp(-0.25 * ssq);
     return prod;
 }
 
-// sum_i c_i A_i over the nonmonotone terms
-template <class XA>
-TTM_HD double nonmon_sum(const Comp& c, int fam, const XA& x) {
-    double s = 0.0;
-    for (int i = 0; i < c.n_nm; ++i) {
-        const int* T = c.nm_terms + 4 * i;
-        s = fma(c.cnm[TTM_UNI(T[3])], eval_A(T, c, fam, x), s);
+// sum_i c_i Psi_nonmon,i : folded constant + per-variable recurrences + generic terms
+template <class R, class XA>
+TTM_HD R nonmon_sum(const Comp& c, const Prog& p, VarCache<XA, R>& x) {
+    R s(c.fold[0]);
+    for (int g = 0; g < c.n_grp; ++g) {
+        cint_p G = c.grp + 4 * g;
+        const int var = TTM_UNI(G[0]);
+        const int P = TTM_UNI(G[1]);
+        cdbl_p al = c.fold + TTM_UNI(G[2]);
+        cdbl_p be = al + P;
+        const int has_hf = TTM_UNI(G[3]);
+        R xv, e(0.0);
+        if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+        R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
+        poly_first(p.family, xv, pn, dp);
+        for (int n = 1; n <= P; ++n) {
+            accp = vfma(al[n - 1], pn, accp);
+            if (has_hf) acch = vfma(be[n - 1], pn, acch);
+            if (n < P) poly_next<false>(p.family, n, xv, pm, pn, dpm, dp);
+        }
+        s = s + accp;
+        if (has_hf) s = vfma(e, acch, s);
+    }
+    for (int i = 0; i < c.n_gen; ++i) {
+        cint_p T = c.nm_terms + 4 * TTM_UNI(c.gen[i]);
+        s = vfma(c.cnm[TTM_UNI(T[3])], eval_A<R>(T, c, p, x), s);
     }
     return s;
 }
 
-// w[b] = sum over monotone terms with x_k-function b of c_i A_i ; slot nB collects b == -1
-template <class XA, class Slots>
-TTM_HD void mon_weights(const Comp& c, int fam, const XA& x, Slots& w) {
-    for (int b = 0; b <= c.nB; ++b) w.set(b, 0.0);
-    for (int i = 0; i < c.n_mon; ++i) {
-        const int* T = c.mon_terms + 4 * i;
-        const int nf = TTM_UNI(T[1]);
+// weights of the B functions for this sample: folded part + cross-term products.
+// Only needed when the component has monotone cross terms (n_mnt > 0).
+template <class R, class XA, class Slots>
+TTM_HD void mon_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
+    cdbl_p wb = c.fold + c.off_wb;
+    for (int b = 0; b <= c.nB; ++b) w.set(b, R(wb[b]));
+    for (int j = 0; j < c.n_mnt; ++j) {
+        cint_p T = c.mon_terms + 4 * TTM_UNI(c.mnt[j]);
         int b = TTM_UNI(T[2]);
         if (b < 0) b = c.nB;
-        const double ci = c.cmon[TTM_UNI(T[3])];
-        const double a = (nf == 0) ? ci : ci * eval_A(T, c, fam, x);
-        w.set(b, w.get(b) + a);
+        w.set(b, vfma(c.cmon[TTM_UNI(T[3])], eval_A<R>(T, c, p, x), w.get(b)));
     }
 }
 
+struct UniformW {            // uniform weights straight from the folded array (SGPR operands)
+    cdbl_p wb;
+    TTM_HD double get(int i) const { return wb[i]; }
+};
+
 // visit every distinct x_k-univariate function: f(b, B_b(t), B_b'(t))
-template <bool DER, class F>
-TTM_HD void for_each_B(const Comp& c, int fam, double t, F&& f) {
+template <bool DER, class R, class F>
+TTM_HD void for_each_B(const Comp& c, const Prog& p, const R& t, F&& f) {
     int b = 0;
     if (c.nB_hf > 0) {
-        const double E = exp(-0.25 * (t * t));
-        double pm = 1.0, dpm = 0.0, p, dp;
-        poly_first(fam, t, p, dp);
+        const R E = fast_exp(-0.25 * (t * t));
+        R pm(1.0), dpm(0.0), pn, dp;
+        poly_first(p.family, t, pn, dp);
         for (int n = 1; n <= c.maxP_hf; ++n) {
-            const int* B = c.bfuns + 4 * b;
+            cint_p B = c.bfuns + 4 * b;
             if (TTM_UNI(B[1]) == n) {
                 const double a = c.dpar[TTM_UNI(B[2])];
                 // d/dt [a P e^{-t^2/4}] = -1/2 e^{-t^2/4} (t aP - 2 aP')   (TM:1245)
-                f(b, a * p * E, DER ? -0.5 * E * (t * (a * p) - 2.0 * (a * dp)) : 0.0);
+                f(b, a * pn * E, DER ? -0.5 * E * (t * (a * pn) - 2.0 * (a * dp)) : R(0.0));
                 ++b;
             }
-            if (n < c.maxP_hf) poly_next(fam, n, t, pm, p, dpm, dp);
+            if (n < c.maxP_hf) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
         }
     }
     if (c.nB_poly > 0) {
-        double pm = 1.0, dpm = 0.0, p, dp;
-        poly_first(fam, t, p, dp);
+        R pm(1.0), dpm(0.0), pn, dp;
+        poly_first(p.family, t, pn, dp);
         for (int n = 1; n <= c.maxP_poly; ++n) {
-            const int* B = c.bfuns + 4 * b;
+            cint_p B = c.bfuns + 4 * b;
             if (TTM_UNI(B[1]) == n) {
-                f(b, p, dp);
+                f(b, pn, dp);
                 ++b;
             }
-            if (n < c.maxP_poly) poly_next(fam, n, t, pm, p, dpm, dp);
+            if (n < c.maxP_poly) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
         }
     }
     for (int s = 0; s < c.nB_st; ++s, ++b) {
-        const int* B = c.bfuns + 4 * b;
-        const int p0 = TTM_UNI(B[2]);
-        double v, dv;
-        st_eval<true, DER>(TTM_UNI(B[0]), t, c.dpar[p0], c.dpar[p0 + 1], v, dv);
+        cint_p B = c.bfuns + 4 * b;
+        R v, dv;
+        st_eval<true, DER>(p, TTM_UNI(B[0]), t, c.dpar + TTM_UNI(B[2]), v, dv);
         f(b, v, dv);
     }
 }
 
 // g(t) = w[nB] + sum_b w[b] B_b(t)   (the argument of the rectifier, or the
 // monotone part itself for separable maps) and dg/dt
-template <bool DER, class Slots>
-TTM_HD void g_eval(const Comp& c, int fam, double t, const Slots& w, double& g, double& dg) {
-    double acc = w.get(c.nB), dacc = 0.0;
-    for_each_B<DER>(c, fam, t, [&](int b, double v, double dv) {
-        const double wb = w.get(b);
-        acc = fma(wb, v, acc);
-        if (DER) dacc = fma(wb, dv, dacc);
+template <bool DER, class R, class W>
+TTM_HD void g_eval(const Comp& c, const Prog& p, const R& t, const W& w, R& g, R& dg) {
+    R acc(w.get(c.nB)), dacc(0.0);
+    for_each_B<DER>(c, p, t, [&](int b, const R& v, const R& dv) {
+        const auto wb = w.get(b);
+        acc = vfma(wb, v, acc);
+        if (DER) dacc = vfma(wb, dv, dacc);
     });
     g = acc; dg = dacc;
 }
 
 // int_0^{xk} (r(g(t)) + delta) dt with the reference's node order and grouping (TM:4238-4258)
-template <class Slots>
-TTM_HD double integrate_rect(const Comp& c, const Prog& p, double xk, const Slots& w) {
-    const double half = xk * 0.5;
-    double res = 0.0;
+template <class R, class W>
+TTM_HD R integrate_rect(const Comp& c, const Prog& p, const R& xk, const W& w) {
+    const R half = xk * 0.5;
+    R res(0.0);
     for (int q = 0; q < p.Q; ++q) {
-        const double t = half * p.qx[q] + half;
-        double g, dg;
-        g_eval<false>(c, p.family, t, w, g, dg);
-        const double fr = rect_eval(p.rect, g) + p.delta;
-        const double term = half * (p.qw[q] * fr);
+        const R t = half * p.qx[q] + half;
+        R g, dg;
+        g_eval<false>(c, p, t, w, g, dg);
+        const R fr = rect_eval(p.rect, g) + p.delta;
+        const R term = half * (p.qw[q] * fr);
         res = (q == 0) ? term : res + term;
     }
     return res;
 }
 
 // monotone part of S_k at x_k = t given the sample's weights: value and dS/dx_k
-template <bool DER, class Slots>
-TTM_HD void mon_eval(const Comp& c, const Prog& p, double t, const Slots& w, double& m, double& dm) {
-    if (p.mono == TTM_MONO_SEPARABLE) {
-        g_eval<DER>(c, p.family, t, w, m, dm);
+// MONO >= 0 fixes the monotonicity mode at compile time (kernels), MONO < 0 reads it from the program
+template <int MONO, bool DER, class R, class W>
+TTM_HD void mon_eval(const Comp& c, const Prog& p, const R& t, const W& w, R& m, R& dm) {
+    const int mono = (MONO >= 0) ? MONO : p.mono;
+    if (mono == TTM_MONO_SEPARABLE) {
+        g_eval<DER>(c, p, t, w, m, dm);
     } else {
         m = integrate_rect(c, p, t, w);
-        dm = 0.0;
+        dm = R(0.0);
         if (DER) {
-            double g, dg;
-            g_eval<false>(c, p.family, t, w, g, dg);
+            R g, dg;
+            g_eval<false>(c, p, t, w, g, dg);
             dm = rect_eval(p.rect, g) + p.delta;
         }
     }
@@ -341,37 +489,43 @@ TTM_HD void mon_eval(const Comp& c, const Prog& p, double t, const Slots& w, dou
 // per-sample bodies
 // ---------------------------------------------------------------------------
 
-// S_k(x) and dS_k/dx_k.  scratch: nB+1 slots.
-template <bool DER, class XA, class Slots>
-TTM_HD void sample_forward(const Comp& c, const Prog& p, const XA& x, Slots& w, bool want_value, double& S, double& dS) {
-    mon_weights(c, p.family, x, w);
-    double m, dm;
-    mon_eval<DER>(c, p, x(c.kc), w, m, dm);
-    S = want_value ? nonmon_sum(c, p.family, x) + m : m;
+// S_k(x) and dS_k/dx_k.  scratch: nB+1 slots (touched only for components with monotone cross terms).
+template <int MONO, bool DER, class R, class XA, class Slots>
+TTM_HD void sample_forward(const Comp& c, const Prog& p, VarCache<XA, R>& x, Slots& w, bool want_value, R& S, R& dS) {
+    R m, dm;
+    const R xk = x.get(c.kc);
+    if (c.n_mnt == 0) {
+        const UniformW uw{c.fold + c.off_wb};
+        mon_eval<MONO, DER>(c, p, xk, uw, m, dm);
+    } else {
+        mon_weights<R>(c, p, x, w);
+        mon_eval<MONO, DER>(c, p, xk, w, m, dm);
+    }
+    S = want_value ? nonmon_sum<R>(c, p, x) + m : m;
     dS = dm;
 }
 
-// basis rows (inspection): which 0 Psi_nonmon, 1 Psi_mon, 2 dPsi_mon/dx_k ; out(i) = value
+// basis rows (inspection): which 0 Psi_nonmon, 1 Psi_mon, 2 dPsi_mon/dx_k ; out(i, value)
 template <class XA, class Out>
-TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, const XA& x, Out&& out) {
+TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, XA& x, Out&& out) {
     if (which == 0) {
         for (int i = 0; i < c.n_nm; ++i) {
-            const int* T = c.nm_terms + 4 * i;
-            out(TTM_UNI(T[3]), eval_A(T, c, p.family, x));
+            cint_p T = c.nm_terms + 4 * i;
+            out(TTM_UNI(T[3]), eval_A<double>(T, c, p, x));
         }
         return;
     }
     const double xk = x(c.kc);
     for (int i = 0; i < c.n_mon; ++i) {
-        const int* T = c.mon_terms + 4 * i;
+        cint_p T = c.mon_terms + 4 * i;
         const int bsel = TTM_UNI(T[2]);
         double v = 1.0, dv = 0.0;
         if (bsel >= 0) {
-            for_each_B<true>(c, p.family, xk, [&](int b, double bv, double bdv) {
+            for_each_B<true>(c, p, xk, [&](int b, double bv, double bdv) {
                 if (b == bsel) { v = bv; dv = bdv; }
             });
         }
-        const double a = eval_A(T, c, p.family, x);
+        const double a = eval_A<double>(T, c, p, x);
         out(TTM_UNI(T[3]), a * (which == 1 ? v : dv));
     }
 }
@@ -380,37 +534,31 @@ TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, const XA& x, O
 // (TM:3343-3376, 3475-3569).  acc layout: [0] J, [1..n_nm] d/dc_nonmon, then d/dc_mon.
 // scratch slots: w (nB+1) | Bv (nB+1) | I (nB+1)
 template <class XA, class Slots, class Acc>
-TTM_HD void sample_objective_int(const Comp& c, const Prog& p, const XA& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
-    mon_weights(c, p.family, x, w);
-    const double xk = x(c.kc);
+TTM_HD void sample_objective_int(const Comp& c, const Prog& p, VarCache<XA, double>& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
+    mon_weights<double>(c, p, x, w);
+    const double xk = x.get(c.kc);
     const double half = xk * 0.5;
     double mono = 0.0;
     for (int b = 0; b <= c.nB; ++b) I.set(b, 0.0);
     for (int q = 0; q < p.Q; ++q) {
         const double t = half * p.qx[q] + half;
         double g = w.get(c.nB);
-        for_each_B<false>(c, p.family, t, [&](int b, double v, double) {
+        for_each_B<false>(c, p, t, [&](int b, double v, double) {
             g = fma(w.get(b), v, g);
             Bv.set(b, v);
         });
         double r, dr, logr;
-        rect_all(p.rect, p.delta, g, r, dr, logr);
+        rect_all(p.rect, 0.0, g, r, dr, logr);          // logr unused here
         const double term = half * (p.qw[q] * (r + p.delta));
         mono = (q == 0) ? term : mono + term;
         const double cq = (half * p.qw[q]) * dr;       // lim_dif*0.5*W_q * r'(g_q)   (TM:4264-4278, 5127-5133)
         for (int b = 0; b < c.nB; ++b) I.set(b, fma(cq, Bv.get(b), I.get(b)));
         I.set(c.nB, I.get(c.nB) + cq);
     }
-    // nonmonotone part and its gradient
-    double off = 0.0;
-    for (int i = 0; i < c.n_nm; ++i) {
-        const int* T = c.nm_terms + 4 * i;
-        off = fma(c.cnm[TTM_UNI(T[3])], eval_A(T, c, p.family, x), off);
-    }
-    const double S = off + mono;
+    const double S = nonmon_sum<double>(c, p, x) + mono;
     // values at x_k for the log term
     double g = w.get(c.nB);
-    for_each_B<false>(c, p.family, xk, [&](int b, double v, double) {
+    for_each_B<false>(c, p, xk, [&](int b, double v, double) {
         g = fma(w.get(b), v, g);
         Bv.set(b, v);
     });
@@ -419,16 +567,16 @@ TTM_HD void sample_objective_int(const Comp& c, const Prog& p, const XA& x, Slot
     rect_all(p.rect, p.delta, g, r, dr, logr);
     acc.add(0, 0.5 * S * S - logr);
     for (int i = 0; i < c.n_nm; ++i) {
-        const int* T = c.nm_terms + 4 * i;
-        acc.add(1 + TTM_UNI(T[3]), S * eval_A(T, c, p.family, x));
+        cint_p T = c.nm_terms + 4 * i;
+        acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
     }
-    const double rinv = dr / (r + p.delta);
+    const double rinv = dr * fast_rcp(r + p.delta);
     for (int i = 0; i < c.n_mon; ++i) {
-        const int* T = c.mon_terms + 4 * i;
+        cint_p T = c.mon_terms + 4 * i;
         const int nf = TTM_UNI(T[1]);
         int b = TTM_UNI(T[2]);
         if (b < 0) b = c.nB;
-        const double a = (nf == 0) ? 1.0 : eval_A(T, c, p.family, x);
+        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
         acc.add(1 + c.n_nm + TTM_UNI(T[3]), a * (S * I.get(b) - rinv * Bv.get(b)));
     }
 }
@@ -437,30 +585,30 @@ TTM_HD void sample_objective_int(const Comp& c, const Prog& p, const XA& x, Slot
 // acc[0] += log dS, acc[1+i] += dPsi_i / dS with dS = dPsi.c + delta * rowsum(dPsi)
 // scratch: dB (nB+1)
 template <class XA, class Slots, class Acc>
-TTM_HD void sample_objective_sep(const Comp& c, const Prog& p, const XA& x, Slots& dB, Acc& acc) {
-    const double xk = x(c.kc);
-    for_each_B<true>(c, p.family, xk, [&](int b, double, double dv) { dB.set(b, dv); });
+TTM_HD void sample_objective_sep(const Comp& c, const Prog& p, VarCache<XA, double>& x, Slots& dB, Acc& acc) {
+    const double xk = x.get(c.kc);
+    for_each_B<true>(c, p, xk, [&](int b, double, double dv) { dB.set(b, dv); });
     dB.set(c.nB, 0.0);
     double dS = 0.0, rowsum = 0.0;
     for (int i = 0; i < c.n_mon; ++i) {
-        const int* T = c.mon_terms + 4 * i;
+        cint_p T = c.mon_terms + 4 * i;
         const int nf = TTM_UNI(T[1]);
         int b = TTM_UNI(T[2]);
         if (b < 0) b = c.nB;
-        const double a = (nf == 0) ? 1.0 : eval_A(T, c, p.family, x);
+        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
         const double d = a * dB.get(b);
         dS = fma(c.cmon[TTM_UNI(T[3])], d, dS);
         rowsum += d;
     }
     dS += rowsum * p.delta;
-    acc.add(0, log(dS));
-    const double inv = 1.0 / dS;
+    acc.add(0, fast_log(dS));
+    const double inv = fast_rcp(dS);
     for (int i = 0; i < c.n_mon; ++i) {
-        const int* T = c.mon_terms + 4 * i;
+        cint_p T = c.mon_terms + 4 * i;
         const int nf = TTM_UNI(T[1]);
         int b = TTM_UNI(T[2]);
         if (b < 0) b = c.nB;
-        const double a = (nf == 0) ? 1.0 : eval_A(T, c, p.family, x);
+        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
         acc.add(1 + TTM_UNI(T[3]), a * dB.get(b) * inv);
     }
 }
@@ -468,12 +616,12 @@ TTM_HD void sample_objective_sep(const Comp& c, const Prog& p, const XA& x, Slot
 // Bisection root search of one sample for one component (TM:3842-3976).
 // Returns the last trial point (what the reference leaves in X[:, kc]) and the
 // number of midpoint iterations it needed.  `cap` < 0: no cap.
-template <class Slots>
-TTM_HD double sample_bisect(const Comp& c, const Prog& p, double off, double zk, const Slots& w, int cap, int& iters) {
+template <int MONO, class W>
+TTM_HD double sample_bisect(const Comp& c, const Prog& p, double off, double zk, const W& w, int cap, int& iters) {
     double lo = -2.0, hi = 2.0, m, dm;
-    mon_eval<false>(c, p, lo, w, m, dm);
+    mon_eval<MONO, false>(c, p, lo, w, m, dm);
     double flo = (off + m) - zk;
-    mon_eval<false>(c, p, hi, w, m, dm);
+    mon_eval<MONO, false>(c, p, hi, w, m, dm);
     double fhi = (off + m) - zk;
     double last = hi;
     if (flo > fhi) { double t = flo; flo = fhi; fhi = t; t = lo; lo = hi; hi = t; }
@@ -485,13 +633,13 @@ TTM_HD double sample_bisect(const Comp& c, const Prog& p, double off, double zk,
             hi = lo; lo = lo - diff * 2.0;
             fhi = flo;
             last = lo;
-            mon_eval<false>(c, p, lo, w, m, dm);
+            mon_eval<MONO, false>(c, p, lo, w, m, dm);
             flo = (off + m) - zk;
         } else if (flo < 0.0) {
             lo = hi; hi = hi + diff * 2.0;
             flo = fhi;
             last = hi;
-            mon_eval<false>(c, p, hi, w, m, dm);
+            mon_eval<MONO, false>(c, p, hi, w, m, dm);
             fhi = (off + m) - zk;
         } else {
             break;
@@ -501,9 +649,9 @@ TTM_HD double sample_bisect(const Comp& c, const Prog& p, double off, double zk,
     const int maxit = (cap >= 0 && cap < 100) ? cap : 100;
     while (iters < maxit) {
         ++iters;
-        const double mid = (lo + hi) / 2.0;     // np.mean over two values
+        const double mid = (lo + hi) * 0.5;     // np.mean over two values
         last = mid;
-        mon_eval<false>(c, p, mid, w, m, dm);
+        mon_eval<MONO, false>(c, p, mid, w, m, dm);
         const double fm = (off + m) - zk;
         if (fm < 0.0) lo = mid;
         if (fm > 0.0) hi = mid;
@@ -514,7 +662,7 @@ TTM_HD double sample_bisect(const Comp& c, const Prog& p, double off, double zk,
 
 // interp1d lookup (TM:4062-4082): xs non-decreasing table of map outputs, ys the abscissae
 TTM_HD double table_lookup(const double* xs, const double* ys, int T, double target) {
-    // np.searchsorted(xs, target) (left): first i with xs[i] >= target; NaN sorts last
+    // np.searchsorted(xs, target) (left): first i with xs[i] >= target
     int lo = 0, hi = T;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
@@ -522,7 +670,7 @@ TTM_HD double table_lookup(const double* xs, const double* ys, int T, double tar
     }
     int i = lo < 1 ? 1 : (lo > T - 1 ? T - 1 : lo);
     const double x_lo = xs[i - 1], x_hi = xs[i], y_lo = ys[i - 1], y_hi = ys[i];
-    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);
     return slope * (target - x_lo) + y_lo;
 }
 

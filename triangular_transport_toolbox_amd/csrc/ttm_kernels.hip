@@ -2,13 +2,15 @@
 //
 // Geometry shared by all kernels: wave64, one thread = one sample, samples
 // column-major in HBM so that every column access of a wave is one contiguous
-// 512-byte transaction.  The term tables of the components a launch touches
-// (int32 records + fp64 constants + coefficients + quadrature rule) are staged
-// once per workgroup into LDS; per-sample scratch (the weights w_b of the
-// x_k-univariate functions, quadrature partials, gradient accumulators) lives
-// in per-thread LDS columns `slot*blockDim + tid` (conflict-free ds_read_b64 /
-// ds_write_b64).  Grids are persistent (<= 8 workgroups per CU, grid-stride over
-// sample tiles) so the staging cost is paid once per CU slot, not per tile.
+// 512-byte transaction.  Everything that is identical for all lanes - term
+// tables, fp64 constants, coefficients, folded coefficients, the quadrature
+// rule - is read through constant-address-space pointers, i.e. by scalar loads
+// into SGPRs (the scalar unit runs the table interpreter, the VALU only does
+// per-sample fp64 math).  LDS holds what lanes index individually: the erf
+// Taylor table (6.9 KB) and per-sample scratch in per-thread columns
+// `slot*blockDim + tid` (weights w_b of the x_k-univariate functions for
+// components with cross terms, quadrature partials, gradient accumulators),
+// plus the 1001-point inverse table of the table root search.
 // Reductions use a fixed tree (lane-strided partial sums -> wave shuffles ->
 // per-block partials -> finishing kernel) and are run-to-run deterministic.
 //
@@ -18,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ttm_eval.h"
@@ -48,21 +51,16 @@ static int check_launch(const char* what) {
 // device-side helpers
 // ---------------------------------------------------------------------------
 
-struct DevProg {             // by-value kernel argument
+struct DevProg {             // by-value kernel argument (all pointers are global memory)
     const int* itab;
+    const int* ftab;
     const double* dpar;
     const double* qx;
     const double* qw;
+    const int* off;          // 5 x (D+1): comp_off | dpar_off | coef_off | fold_off | ftab_off
+    int D;
     int Q, family, mono, rect;
     double delta;
-};
-
-struct Stage {               // what to copy into LDS for components [k0,k1)
-    int it0, nit;            // int32 range of itab
-    int dp0, ndp;            // double range of dpar
-    int ncf;                 // number of coefficients (pointer already offset)
-    int ncomp;
-    int nslots;              // per-thread scratch slots
 };
 
 struct LdsSlots {
@@ -70,6 +68,41 @@ struct LdsSlots {
     int stride;
     __device__ __forceinline__ double get(int i) const { return base[i * stride]; }
     __device__ __forceinline__ void set(int i, double v) { base[i * stride] = v; }
+};
+
+template <int NS> struct real_of { typedef VecD<NS> type; };
+template <> struct real_of<1> { typedef double type; };
+
+// per-thread scratch slots holding NS samples each
+template <class R>
+struct LdsSlotsN {
+    double* base;
+    int stride;
+    __device__ __forceinline__ R get(int i) const {
+        R r;
+#pragma unroll
+        for (int e = 0; e < lanes_of<R>::value; ++e) set_elem(r, e, base[(i * lanes_of<R>::value + e) * stride]);
+        return r;
+    }
+    __device__ __forceinline__ void set(int i, const R& v) {
+#pragma unroll
+        for (int e = 0; e < lanes_of<R>::value; ++e) base[(i * lanes_of<R>::value + e) * stride] = elem(v, e);
+    }
+};
+
+// NS samples of one thread: sample e is row n0 + e*step (rows beyond N are clamped to N-1 for loads)
+template <int NS>
+struct XSoAN {
+    typedef typename real_of<NS>::type R;
+    const double* X;
+    int64_t ld;
+    int64_t n[NS];
+    __device__ __forceinline__ R operator()(int var) const {
+        R r;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) set_elem(r, e, X[(int64_t)var * ld + n[e]]);
+        return r;
+    }
 };
 
 struct LdsAcc {
@@ -91,63 +124,62 @@ struct XFake {               // TM:4050-4051: zeros except column kc
     __device__ __forceinline__ double operator()(int var) const { return var == kc ? t : 0.0; }
 };
 
-struct Staged {
-    double* slots;           // nslots * blockDim
-    const double* dpar;
-    const double* coef;
-    const int* itab;
-    Prog prog;
-};
+__device__ const double g_erf_table[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
 
 extern __shared__ __align__(16) double g_smem[];
 
-// LDS image: [slots | dpar | coef | quad x | quad w | itab]
-__device__ __forceinline__ Staged stage_program(const DevProg& P, const Stage& st, const double* coef) {
-    const int tid = threadIdx.x, bd = blockDim.x;
-    double* slots = g_smem;
-    double* dpar = slots + (size_t)st.nslots * bd;
-    double* cf = dpar + st.ndp;
-    double* qx = cf + st.ncf;
-    double* qw = qx + P.Q;
-    int* it = reinterpret_cast<int*>(qw + P.Q);
-    for (int i = tid; i < st.ndp; i += bd) dpar[i] = P.dpar[st.dp0 + i];
-    for (int i = tid; i < st.ncf; i += bd) cf[i] = coef[i];
-    for (int i = tid; i < P.Q; i += bd) { qx[i] = P.qx[i]; qw[i] = P.qw[i]; }
-    for (int i = tid; i < st.nit; i += bd) it[i] = P.itab[st.it0 + i];
+#define TTM_CACHE_SLOTS 8     // per-thread column cache (VarCache): 4 x + 4 exp(-x^2/4)
+
+// LDS image: [erf table | column cache (8 x NS x blockDim) | per-thread slots ...]
+template <class R>
+__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots) {
+    double* et = g_smem;
+    for (int i = threadIdx.x; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
     __syncthreads();
-    Staged s;
-    s.slots = slots;
-    s.dpar = dpar;
-    s.coef = cf;
-    s.itab = it;
-    s.prog.qx = qx;
-    s.prog.qw = qw;
-    s.prog.Q = P.Q;
-    s.prog.family = P.family;
-    s.prog.mono = P.mono;
-    s.prog.rect = P.rect;
-    s.prog.delta = P.delta;
-    return s;
+    cache.base = et + TTM_ERF_TABLE_LEN + threadIdx.x;
+    cache.stride = blockDim.x;
+    slots = et + TTM_ERF_TABLE_LEN + (size_t)TTM_CACHE_SLOTS * lanes_of<R>::value * blockDim.x;
+    Prog g;
+    g.qx = (cdbl_p)P.qx;
+    g.qw = (cdbl_p)P.qw;
+    g.erf_tab = et;
+    g.Q = P.Q;
+    g.family = P.family;
+    g.mono = P.mono;
+    g.rect = P.rect;
+    g.delta = P.delta;
+    return g;
 }
 
-// walk the staged component blocks
-struct CompCursor {
-    const int* cb;
-    const double* dp;
-    const double* cf;
-    __device__ __forceinline__ Comp get() const { return make_comp(cb, dp, cf); }
-    __device__ __forceinline__ void next() {
-        const int n_nm = TTM_UNI(cb[TTM_HDR_N_NM]), n_mon = TTM_UNI(cb[TTM_HDR_N_MON]);
-        dp += TTM_UNI(cb[TTM_HDR_N_DPAR]);
-        cf += n_nm + n_mon;
-        cb += TTM_UNI(cb[TTM_HDR_LEN_BLK]);
-    }
-};
+// component k of the program; coefficient / folded arrays are given relative to component kbase
+__device__ __forceinline__ Comp comp_at(const DevProg& P, int k, int kbase, const double* coef, const double* fold) {
+    cint_p off = (cint_p)P.off;
+    const int D1 = P.D + 1;
+    cint_p cb = (cint_p)P.itab + off[k];
+    cdbl_p dp = (cdbl_p)P.dpar + off[D1 + k];
+    cdbl_p cf = coef ? (cdbl_p)coef + (off[2 * D1 + k] - off[2 * D1 + kbase]) : (cdbl_p)P.dpar;
+    cdbl_p fo = fold ? (cdbl_p)fold + (off[3 * D1 + k] - off[3 * D1 + kbase]) : (cdbl_p)P.dpar;
+    return make_comp(cb, dp, cf, fo);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// ---------------------------------------------------------------------------
+// folded coefficients: block k handles component kfirst + k, one thread per slot
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_fold(DevProg P, int kfirst, int kbase, const double* __restrict__ coef,
+                                             double* __restrict__ fold) {
+    const int k = kfirst + blockIdx.x;
+    const int D1 = P.D + 1;
+    const int* off = P.off;
+    fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k],
+                coef + (off[2 * D1 + k] - off[2 * D1 + kbase]), fold + (off[3 * D1 + k] - off[3 * D1 + kbase]),
+                threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -245,47 +277,79 @@ __global__ __launch_bounds__(64) void k_colfinish(const double* __restrict__ par
 }
 
 // ---------------------------------------------------------------------------
-// K2/K3: forward map (+ fused log-determinant)
+// K2/K3: forward map (+ fused log-determinant / squared norm)
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_forward(DevProg P, Stage st, const double* __restrict__ coef,
+template <int MONO, bool WANT_LD, int NS>
+__global__ __launch_bounds__(256) void k_forward(DevProg P, int k0, int k1, const double* __restrict__ coef,
+                                                 const double* __restrict__ fold,
                                                  const double* __restrict__ X, int64_t ldx, int64_t N,
                                                  double* __restrict__ Z, int64_t ldz,
                                                  double* __restrict__ logdet, const double* __restrict__ sigma,
-                                                 double* __restrict__ sumsq, int accumulate) {
-    const Staged s = stage_program(P, st, coef);
-    LdsSlots w{s.slots + threadIdx.x, (int)blockDim.x};
-    const bool want_ld = (logdet != nullptr);
+                                                 double* __restrict__ sumsq) {
+    typedef typename real_of<NS>::type R;
+    double* slots;
+    CacheStore<R> cst;
+    const Prog g = make_prog_lds(P, cst, slots);
+    const int bd = blockDim.x;
+    LdsSlotsN<R> w{slots + threadIdx.x, bd};
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        const XSoA x{X, ldx, n};
-        CompCursor cur{s.itab, s.dpar, s.coef};
-        double ld = 0.0, ss = 0.0;
-        for (int k = 0; k < st.ncomp; ++k, cur.next()) {
-            const Comp c = cur.get();
-            double S, dS;
-            if (want_ld) {
-                sample_forward<true>(c, s.prog, x, w, want_val, S, dS);
-                ld += log(sigma ? dS / sigma[k] : dS);
-            } else {
-                sample_forward<false>(c, s.prog, x, w, true, S, dS);
-            }
-            if (Z) Z[(int64_t)k * ldz + n] = S;
-            ss = fma(S, S, ss);
+    cint_p off = (cint_p)P.off;
+    cint_p itab = (cint_p)P.itab;
+    // a thread carries NS samples (rows tile + e*blockDim + tid) through one pass of the table interpreter
+    for (int64_t tile = (int64_t)blockIdx.x * NS * bd; tile < N; tile += (int64_t)gridDim.x * NS * bd) {
+        XSoAN<NS> xa;
+        xa.X = X; xa.ld = ldx;
+        bool act[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            const int64_t n = tile + (int64_t)e * bd + threadIdx.x;
+            act[e] = n < N;
+            xa.n[e] = act[e] ? n : N - 1;
         }
-        if (want_ld) logdet[n] = accumulate ? logdet[n] + ld : ld;
-        if (sumsq) sumsq[n] = accumulate ? sumsq[n] + ss : ss;
+        VarCache<XSoAN<NS>, R> x(xa, cst);
+        R ld(0.0), ss(0.0);
+        // the component's own column is fetched one component ahead, so its HBM latency overlaps
+        // the arithmetic of the current component
+        R xk_next = xa(itab[off[k0] + TTM_HDR_KC]);
+        for (int k = k0; k < k1; ++k) {
+            const Comp c = comp_at(P, k, 0, coef, fold);
+            x.put(c.kc, xk_next);
+            if (k + 1 < k1) xk_next = xa(itab[off[k + 1] + TTM_HDR_KC]);
+            R S, dS;
+            if (WANT_LD) {
+                sample_forward<MONO, true>(c, g, x, w, want_val, S, dS);
+                ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+            } else {
+                sample_forward<MONO, false>(c, g, x, w, true, S, dS);
+            }
+            if (Z) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    if (act[e]) Z[(int64_t)(k - k0) * ldz + xa.n[e]] = elem(S, e);
+            }
+            ss = vfma(S, S, ss);
+        }
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            if (act[e]) {
+                if (WANT_LD) logdet[xa.n[e]] = elem(ld, e);
+                if (sumsq) sumsq[xa.n[e]] = elem(ss, e);
+            }
+        }
     }
 }
 
 // basis matrices of one component
-__global__ __launch_bounds__(256) void k_basis(DevProg P, Stage st, int which, const double* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(256) void k_basis(DevProg P, int k, int which, const double* __restrict__ X, int64_t ldx,
                                                int64_t N, double* __restrict__ out, int64_t ldo) {
-    const Staged s = stage_program(P, st, nullptr);
+    double* slots;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, slots);
+    const Comp c = comp_at(P, k, 0, nullptr, nullptr);
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        const XSoA x{X, ldx, n};
-        const Comp c = make_comp(s.itab, s.dpar, s.coef);
-        sample_basis(c, s.prog, which, x, [&](int i, double v) { out[(int64_t)i * ldo + n] = v; });
+        XSoA x{X, ldx, n};
+        sample_basis(c, g, which, x, [&](int i, double v) { out[(int64_t)i * ldo + n] = v; });
     }
 }
 
@@ -293,54 +357,177 @@ __global__ __launch_bounds__(256) void k_basis(DevProg P, Stage st, int which, c
 // K4: table inverse
 // ---------------------------------------------------------------------------
 
-// blockIdx.y = component (relative to the staged range start), blockIdx.x over table points
-__global__ __launch_bounds__(256) void k_table_build(DevProg P, Stage st, const double* __restrict__ coef,
+// blockIdx.y = component k0 + y, blockIdx.x over table points
+__global__ __launch_bounds__(256) void k_table_build(DevProg P, int k0, const double* __restrict__ coef,
+                                                     const double* __restrict__ fold,
                                                      const double* __restrict__ pts, int T, double* __restrict__ out) {
-    const Staged s = stage_program(P, st, coef);
-    LdsSlots w{s.slots + threadIdx.x, (int)blockDim.x};
+    double* slots;
+    CacheStore<double> cst;
+    Prog g = make_prog_lds(P, cst, slots);
+    g.mono = TTM_MONO_SEPARABLE;
+    LdsSlots w{slots + threadIdx.x, (int)blockDim.x};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    CompCursor cur{s.itab, s.dpar, s.coef};
-    for (int k = 0; k < st.ncomp; ++k, cur.next()) {
-        const Comp c = cur.get();
-        if (i < T) {
-            const XFake x{c.kc, pts[i]};
-            mon_weights(c, s.prog.family, x, w);
-            double g, dg;
-            g_eval<false>(c, s.prog.family, pts[i], w, g, dg);
-            out[(int64_t)k * T + i] = g;
+    const int k = k0 + blockIdx.y;
+    const Comp c = comp_at(P, k, 0, coef, fold);
+    if (i < T) {
+        const double t = pts[i];
+        double v, dv;
+        if (c.n_mnt == 0) {
+            const UniformW uw{c.fold + c.off_wb};
+            g_eval<false>(c, g, t, uw, v, dv);
+        } else {
+            XFake x{c.kc, t};
+            mon_weights<double>(c, g, x, w);
+            g_eval<false>(c, g, t, w, v, dv);
         }
+        out[(int64_t)blockIdx.y * T + i] = v;
     }
 }
 
-// LDS image: [staged program ... | xs (T) | ys (T)] ; the table region starts at tab_off doubles
-__global__ __launch_bounds__(256) void k_inverse_table(DevProg P, Stage st, const double* __restrict__ coef,
+// tmin / tmax / sortedness / bucket index of one table per block (blockIdx.x = component)
+__global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ tab_x, int T, int nb,
+                                                     double* __restrict__ tmin, double* __restrict__ tmax,
+                                                     int* __restrict__ bkt, int* __restrict__ unsorted) {
+    __shared__ double xs[2048];
+    __shared__ int bad;
+    const double* row = tab_x + (int64_t)blockIdx.x * T;
+    if (threadIdx.x == 0) bad = 0;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = row[i];
+    __syncthreads();
+    int mybad = 0;
+    for (int i = threadIdx.x + 1; i < T; i += blockDim.x) mybad |= !(xs[i - 1] <= xs[i]);   // also flags NaN
+    if (mybad) atomicOr(&bad, 1);
+    __syncthreads();
+    const double lo = xs[0], hi = xs[T - 1];
+    if (threadIdx.x == 0) { tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad; }
+    const double step = (hi - lo) / (double)nb;
+    for (int q = threadIdx.x; q <= nb; q += blockDim.x) {
+        int a = 0, b = T;
+        if (q == nb) a = T;
+        else if (q > 0) {
+            const double u = lo + (double)q * step;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (xs[mid] < u) a = mid + 1; else b = mid;
+            }
+        }
+        bkt[(int64_t)blockIdx.x * (nb + 1) + q] = a;
+    }
+}
+
+// One sample per thread; per tile the thread walks the components in order, so its column cache
+// (VarCache) serves the just-solved x_j to the following components without touching HBM again.
+// The table of component k+1 and the sample's z_{k+1} are fetched (into registers) while component k
+// is being solved and written to the other LDS buffer afterwards: one barrier per component and no
+// exposed global-memory latency.
+// LDS image: [erf table | cache | ys (T) | xs A (T) | xs B (T) | bucket index A, B (nb+1 int32 each)]
+#define TTM_TAB_MAXPT 4       // table points per thread (T <= 4 * 256)
+#define TTM_TAB_MAXBK 4       // bucket entries per thread (nb + 1 <= 4 * 256)
+__global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1, const double* __restrict__ coef,
+                                                       const double* __restrict__ fold,
                                                        const double* __restrict__ Z, int64_t ldz,
                                                        double* X, int64_t ldx, int64_t N,
-                                                       const double* __restrict__ tab_x, const double* __restrict__ tab_y, int T,
+                                                       const double* __restrict__ tab_x, const double* __restrict__ tab_y,
+                                                       int64_t ldy, int T,
                                                        const double* __restrict__ tmin, const double* __restrict__ tmax,
-                                                       int truncate, int tab_off) {
-    const Staged s = stage_program(P, st, coef);
-    double* xs = g_smem + tab_off;
-    double* ys = xs + T;
-    CompCursor cur{s.itab, s.dpar, s.coef};
-    for (int k = 0; k < st.ncomp; ++k, cur.next()) {
+                                                       const int* __restrict__ bkt, int nb, int truncate) {
+    double* base;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, base);
+    const int bd = blockDim.x, tid = threadIdx.x;
+    const int nbk = nb + 1;
+    double* ysA = base;
+    double* xsA = ysA + T;
+    double* xsB = xsA + T;
+    int* bkA = reinterpret_cast<int*>(xsB + T);
+    int* bkB = bkA + nbk + (nbk & 1);
+    double* ysB = reinterpret_cast<double*>(bkB + nbk + (nbk & 1));   // only present when ldy != 0
+    for (int64_t tile = (int64_t)blockIdx.x * bd; tile < N; tile += (int64_t)gridDim.x * bd) {
+        const int64_t n = tile + tid;
+        const bool act = n < N;
+        const XSoA xa{X, ldx, act ? n : 0};
+        VarCache<XSoA, double> x(xa, cst);
+        // stage the first table
         __syncthreads();
-        for (int i = threadIdx.x; i < T; i += blockDim.x) {
-            xs[i] = tab_x[(int64_t)k * T + i];
-            ys[i] = tab_y[(int64_t)k * T + i];
+        for (int i = tid; i < T; i += bd) {
+            xsA[i] = tab_x[i];
+            ysA[i] = tab_y[i];
         }
+        for (int i = tid; i < nbk; i += bd) bkA[i] = bkt[i];
+        double z_next = act ? Z[n] : 0.0;
         __syncthreads();
-        const Comp c = cur.get();
-        const double lo = tmin[k], hi = tmax[k];
-        for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-            const XSoA x{X, ldx, n};
-            const double off = nonmon_sum(c, s.prog.family, x);
-            double target = -off + Z[(int64_t)k * ldz + n];
-            if (truncate) {                      // TM:4074-4076 (comparisons keep NaN untouched)
-                if (target < lo) target = lo;
-                if (target > hi) target = hi;
+        for (int k = k0; k < k1; ++k) {
+            const int par = (k - k0) & 1;
+            double* xs = par ? xsB : xsA;
+            double* ys = (ldy != 0 && par) ? ysB : ysA;
+            int* bk = par ? bkB : bkA;
+            // prefetch table k+1 and z_{k+1} into registers
+            const bool more = k + 1 < k1;
+            double px[TTM_TAB_MAXPT], py[TTM_TAB_MAXPT];
+            int pb[TTM_TAB_MAXBK];
+            const double zk = z_next;
+            if (more) {
+                const double* nx = tab_x + (int64_t)(k + 1 - k0) * T;
+                const double* ny = tab_y + (int64_t)(k + 1 - k0) * ldy;
+                const int* nbp = bkt + (int64_t)(k + 1 - k0) * nbk;
+#pragma unroll
+                for (int j = 0; j < TTM_TAB_MAXPT; ++j) {
+                    const int i = tid + j * bd;
+                    px[j] = i < T ? nx[i] : 0.0;
+                    py[j] = (ldy != 0 && i < T) ? ny[i] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < TTM_TAB_MAXBK; ++j) {
+                    const int i = tid + j * bd;
+                    pb[j] = i < nbk ? nbp[i] : 0;
+                }
+                if (act) z_next = Z[(int64_t)(k + 1 - k0) * ldz + n];
             }
-            X[(int64_t)c.kc * ldx + n] = table_lookup(xs, ys, T, target);
+            if (act) {
+                const Comp c = comp_at(P, k, 0, coef, fold);
+                const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
+                const double off = nonmon_sum<double>(c, g, x);
+                double target = -off + zk;
+                if (truncate) {                      // TM:4074-4076 (comparisons keep NaN untouched)
+                    if (target < lo) target = lo;
+                    if (target > hi) target = hi;
+                }
+                // np.searchsorted(xs, target) (left): bisect inside the buckets around the target only
+                int a = 0, b = T;
+                const double scale = (double)nb / (hi - lo);
+                if (scale > 0.0 && scale < 1.0e300) {
+                    int q = (int)((target - lo) * scale);
+                    q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
+                    a = bk[q > 0 ? q - 1 : 0];
+                    b = bk[q + 2 < nb ? q + 2 : nb];
+                }
+                while (a < b) {
+                    const int mid = (a + b) >> 1;
+                    if (xs[mid] < target) a = mid + 1; else b = mid;
+                }
+                const int i = a < 1 ? 1 : (a > T - 1 ? T - 1 : a);
+                const double x_lo = xs[i - 1], y_lo = ys[i - 1];
+                const double slope = fast_div(ys[i] - y_lo, xs[i] - x_lo);        // interp1d slope form (TM:4062-4065)
+                const double r = slope * (target - x_lo) + y_lo;
+                X[(int64_t)c.kc * ldx + n] = r;
+                x.put(c.kc, r);
+            }
+            if (more) {
+                double* xn = par ? xsA : xsB;
+                double* yn = par ? ysA : ysB;
+                int* bn = par ? bkA : bkB;
+#pragma unroll
+                for (int j = 0; j < TTM_TAB_MAXPT; ++j) {
+                    const int i = tid + j * bd;
+                    if (i < T) { xn[i] = px[j]; if (ldy != 0) yn[i] = py[j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < TTM_TAB_MAXBK; ++j) {
+                    const int i = tid + j * bd;
+                    if (i < nbk) bn[i] = pb[j];
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -349,30 +536,42 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, Stage st, cons
 // K5: bisection inverse
 // ---------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, Stage st, const double* __restrict__ coef,
+template <int MONO>
+__global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k1, const double* __restrict__ coef,
+                                                        const double* __restrict__ fold,
                                                         const double* __restrict__ Z, int64_t ldz,
                                                         double* X, int64_t ldx, int64_t N,
                                                         int* __restrict__ iters, const int* __restrict__ cap) {
-    const Staged s = stage_program(P, st, coef);
-    LdsSlots w{s.slots + threadIdx.x, (int)blockDim.x};
+    double* slots;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, slots);
+    LdsSlots w{slots + threadIdx.x, (int)blockDim.x};
     for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = n0 + threadIdx.x;
         const bool active = n < N;
-        const XSoA x{X, ldx, active ? n : 0};
-        CompCursor cur{s.itab, s.dpar, s.coef};
-        for (int k = 0; k < st.ncomp; ++k, cur.next()) {
-            const Comp c = cur.get();
+        const XSoA xa{X, ldx, active ? n : 0};
+        VarCache<XSoA, double> x(xa, cst);
+        for (int k = k0; k < k1; ++k) {
+            const Comp c = comp_at(P, k, 0, coef, fold);
             int it = 0;
             if (active) {
-                const double off = nonmon_sum(c, s.prog.family, x);
-                mon_weights(c, s.prog.family, x, w);
-                const double r = sample_bisect(c, s.prog, off, Z[(int64_t)k * ldz + n], w, cap ? cap[k] : -1, it);
+                const double off = nonmon_sum<double>(c, g, x);
+                const int capk = cap ? cap[k - k0] : -1;
+                double r;
+                if (c.n_mnt == 0) {
+                    const UniformW uw{c.fold + c.off_wb};
+                    r = sample_bisect<MONO>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], uw, capk, it);
+                } else {
+                    mon_weights<double>(c, g, x, w);
+                    r = sample_bisect<MONO>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, capk, it);
+                }
                 X[(int64_t)c.kc * ldx + n] = r;
+                x.put(c.kc, r);
             }
             // wave-level max, one atomic per wave
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) it = max(it, __shfl_down(it, off, 64));
-            if ((threadIdx.x & 63) == 0 && it > 0) atomicMax(&iters[k], it);
+            if ((threadIdx.x & 63) == 0 && it > 0) atomicMax(&iters[k - k0], it);
         }
     }
 }
@@ -383,25 +582,28 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, Stage st, con
 
 #define TTM_RED_BLOCKS 1024
 
-// LDS: [slots(nscr) | acc(nacc)] per thread columns, then the staged program
-__global__ __launch_bounds__(256) void k_objective(DevProg P, Stage st, const double* __restrict__ coef_k,
+// LDS: erf table | per-thread columns [scratch (nscr) | acc (nacc)]
+__global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const double* __restrict__ coef_k,
+                                                   const double* __restrict__ fold_k,
                                                    const double* __restrict__ X, int64_t ldx, int64_t N,
-                                                   int nacc, double* __restrict__ partial) {
-    const Staged s = stage_program(P, st, coef_k);
+                                                   int nscr, int nacc, double* __restrict__ partial) {
+    double* slots;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, slots);
     const int bd = blockDim.x, tid = threadIdx.x;
-    const Comp c = make_comp(s.itab, s.dpar, s.coef);
+    const Comp c = comp_at(P, k, k, coef_k, fold_k);
     const int nb1 = c.nB + 1;
-    const int nscr = st.nslots - nacc;
-    double* accbase = s.slots + (size_t)nscr * bd;
+    double* accbase = slots + (size_t)nscr * bd;
     for (int i = 0; i < nacc; ++i) accbase[i * bd + tid] = 0.0;
     LdsAcc acc{accbase + tid, bd};
-    LdsSlots w{s.slots + tid, bd};
-    LdsSlots Bv{s.slots + (size_t)nb1 * bd + tid, bd};
-    LdsSlots I{s.slots + (size_t)2 * nb1 * bd + tid, bd};
+    LdsSlots w{slots + tid, bd};
+    LdsSlots Bv{slots + (size_t)nb1 * bd + tid, bd};
+    LdsSlots I{slots + (size_t)2 * nb1 * bd + tid, bd};
     for (int64_t n = (int64_t)blockIdx.x * bd + tid; n < N; n += (int64_t)gridDim.x * bd) {
-        const XSoA x{X, ldx, n};
-        if (s.prog.mono == TTM_MONO_SEPARABLE) sample_objective_sep(c, s.prog, x, w, acc);
-        else sample_objective_int(c, s.prog, x, w, Bv, I, acc);
+        const XSoA xa{X, ldx, n};
+        VarCache<XSoA, double> x(xa, cst);
+        if (g.mono == TTM_MONO_SEPARABLE) sample_objective_sep(c, g, x, w, acc);
+        else sample_objective_int(c, g, x, w, Bv, I, acc);
     }
     __syncthreads();
     // block reduction: wave wv takes accumulators wv, wv+nw, ... ; lanes stride over threads
@@ -428,23 +630,24 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restric
 
 #define TTM_GRAM_MAXPAIR 8
 
-// LDS: [scratch (nB+1) | rows (m)] per-thread columns, then the staged program
-__global__ __launch_bounds__(256) void k_gram(DevProg P, Stage st, const double* __restrict__ X, int64_t ldx, int64_t N,
+// LDS: erf table | rows (m) per-thread columns
+__global__ __launch_bounds__(256) void k_gram(DevProg P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
                                               int m, double* __restrict__ partial) {
-    const Staged s = stage_program(P, st, nullptr);
+    double* rows;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, rows);
     const int bd = blockDim.x, tid = threadIdx.x;
-    const Comp c = make_comp(s.itab, s.dpar, s.coef);
-    double* rows = s.slots + (size_t)(c.nB + 1) * bd;
+    const Comp c = comp_at(P, k, 0, nullptr, nullptr);
     const int npair = m * m;
-    double g[TTM_GRAM_MAXPAIR];
+    double acc[TTM_GRAM_MAXPAIR];
 #pragma unroll
-    for (int q = 0; q < TTM_GRAM_MAXPAIR; ++q) g[q] = 0.0;
+    for (int q = 0; q < TTM_GRAM_MAXPAIR; ++q) acc[q] = 0.0;
     for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
         const int64_t n = n0 + tid;
         if (n < N) {
-            const XSoA x{X, ldx, n};
-            sample_basis(c, s.prog, 0, x, [&](int i, double v) { rows[i * bd + tid] = v; });
-            sample_basis(c, s.prog, 1, x, [&](int i, double v) { rows[(c.n_nm + i) * bd + tid] = v; });
+            XSoA x{X, ldx, n};
+            sample_basis(c, g, 0, x, [&](int i, double v) { rows[i * bd + tid] = v; });
+            sample_basis(c, g, 1, x, [&](int i, double v) { rows[(c.n_nm + i) * bd + tid] = v; });
         } else {
             for (int i = 0; i < m; ++i) rows[i * bd + tid] = 0.0;
         }
@@ -455,12 +658,12 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, Stage st, const double*
             if (pr < npair) {
                 const double* ri = rows + (pr / m) * bd;
                 const double* rj = rows + (pr % m) * bd;
-                double a = g[q];
+                double a = acc[q];
                 for (int t = 0; t < bd; ++t) {
                     const int tt = (t + tid) & (bd - 1);    // skewed start: conflict-free LDS columns
                     a = fma(ri[tt], rj[tt], a);
                 }
-                g[q] = a;
+                acc[q] = a;
             }
         }
         __syncthreads();
@@ -468,7 +671,7 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, Stage st, const double*
 #pragma unroll
     for (int q = 0; q < TTM_GRAM_MAXPAIR; ++q) {
         const int pr = tid + q * bd;
-        if (pr < npair) partial[(int64_t)blockIdx.x * npair + pr] = g[q];
+        if (pr < npair) partial[(int64_t)blockIdx.x * npair + pr] = acc[q];
     }
 }
 
@@ -476,10 +679,10 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, Stage st, const double*
 // host side: launch planning
 // ---------------------------------------------------------------------------
 
-static const int kLdsBudget = 64 * 1024;      // bytes per workgroup (2 workgroups/CU still fit in 160 KiB)
+static const int kLdsBudget = 64 * 1024;      // bytes per workgroup
 
-static int grid_for(int64_t N, int bd) {
-    int64_t tiles = (N + bd - 1) / bd;
+static int grid_for(int64_t N, int per_block) {
+    int64_t tiles = (N + per_block - 1) / per_block;
     const int64_t cap = 256 * 8;              // 256 CUs x up to 8 resident workgroups
     if (tiles > cap) tiles = cap;
     if (tiles < 1) tiles = 1;
@@ -488,13 +691,14 @@ static int grid_for(int64_t N, int bd) {
 
 static DevProg dev_prog(const ttm_program* p) {
     DevProg P;
-    P.itab = p->itab; P.dpar = p->dpar; P.qx = p->quad_x; P.qw = p->quad_w;
-    P.Q = p->Q; P.family = p->family; P.mono = p->monotonicity; P.rect = p->rectifier; P.delta = p->delta;
+    P.itab = p->itab; P.ftab = p->ftab; P.dpar = p->dpar; P.qx = p->quad_x; P.qw = p->quad_w; P.off = p->d_offsets;
+    P.D = p->D; P.Q = p->Q; P.family = p->family; P.mono = p->monotonicity; P.rect = p->rectifier; P.delta = p->delta;
     return P;
 }
 
 static int validate(const ttm_program* p, int k0, int k1) {
-    if (!p || !p->itab || !p->h_comp_off || !p->h_dpar_off || !p->h_coef_off || !p->h_nslots)
+    if (!p || !p->itab || !p->ftab || !p->dpar || !p->d_offsets || !p->h_comp_off || !p->h_dpar_off || !p->h_coef_off ||
+        !p->h_nslots || !p->h_n_nm || !p->h_fold_off || !p->h_ftab_off || !p->h_nb1)
         return set_err(TTM_E_ARG, "ttm_program has null tables%s");
     if (k0 < 0 || k1 > p->D || k0 >= k1) return set_err(TTM_E_ARG, "component range [%s%lld,%lld) invalid", "", k0, k1);
     if (p->Q < 0 || p->Q > 4096) return set_err(TTM_E_ARG, "quadrature order %s%lld out of range", "", p->Q);
@@ -503,51 +707,22 @@ static int validate(const ttm_program* p, int k0, int k1) {
     return TTM_OK;
 }
 
-// stage description + LDS bytes for components [ka,kb) with `extra_slots` per-thread slots on top of max(nB+1)
-static Stage make_stage(const ttm_program* p, int ka, int kb, int slots_mult, int extra_slots) {
-    Stage st;
-    st.it0 = p->h_comp_off[ka]; st.nit = p->h_comp_off[kb] - st.it0;
-    st.dp0 = p->h_dpar_off[ka]; st.ndp = p->h_dpar_off[kb] - st.dp0;
-    st.ncf = p->h_coef_off[kb] - p->h_coef_off[ka];
-    st.ncomp = kb - ka;
+// per-thread scratch slots the map kernels need for components [ka,kb)
+static int map_slots(const ttm_program* p, int ka, int kb) {
     int ns = 0;
     for (int k = ka; k < kb; ++k) ns = p->h_nslots[k] > ns ? p->h_nslots[k] : ns;
-    st.nslots = ns * slots_mult + extra_slots;
-    return st;
+    return ns;
 }
 
-static size_t lds_bytes(const ttm_program* p, const Stage& st, int bd, int extra_doubles) {
-    size_t dbl = (size_t)st.nslots * bd + st.ndp + st.ncf + 2 * (size_t)p->Q + extra_doubles;
-    return dbl * 8 + (size_t)st.nit * 4;
+static size_t lds_bytes(int nslots, int bd, int extra_doubles, int ns = 1) {
+    return ((size_t)TTM_ERF_TABLE_LEN + (size_t)(TTM_CACHE_SLOTS + nslots) * ns * bd + extra_doubles) * 8;
 }
 
-// pick the largest block size whose LDS image fits; 0 if none
-static int pick_block(const ttm_program* p, const Stage& st, int extra_doubles) {
+// largest block size whose LDS image fits; 0 if none
+static int pick_block(int nslots, int extra_doubles, int ns = 1) {
     for (int bd = 256; bd >= 64; bd >>= 1)
-        if (lds_bytes(p, st, bd, extra_doubles) <= (size_t)kLdsBudget) return bd;
+        if (lds_bytes(nslots, bd, extra_doubles, ns) <= (size_t)kLdsBudget) return bd;
     return 0;
-}
-
-// greedy split of [k0,k1) into chunks whose program fits the LDS budget at blockDim 256
-// (a single oversized component falls back to smaller blocks)
-template <class Fn>
-static int for_each_chunk(const ttm_program* p, int k0, int k1, int slots_mult, int extra_slots, int extra_doubles, Fn fn) {
-    int ka = k0;
-    while (ka < k1) {
-        int kb = ka + 1;
-        while (kb < k1) {
-            Stage st = make_stage(p, ka, kb + 1, slots_mult, extra_slots);
-            if (lds_bytes(p, st, 256, extra_doubles) > (size_t)kLdsBudget) break;
-            ++kb;
-        }
-        Stage st = make_stage(p, ka, kb, slots_mult, extra_slots);
-        int bd = pick_block(p, st, extra_doubles);
-        if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", ka);
-        int rc = fn(ka, kb, st, bd);
-        if (rc != TTM_OK) return rc;
-        ka = kb;
-    }
-    return TTM_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -604,19 +779,45 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
     return check_launch("k_export");
 }
 
-int ttm_forward(const ttm_program* p, const double* coef, const double* Xsoa, int64_t ldx, int64_t N, int32_t k0,
-                int32_t k1, double* Zsoa, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void* stream) {
+int64_t ttm_fold_size(const ttm_program* p) { return (p && p->h_fold_off) ? p->h_fold_off[p->D] : -1; }
+
+int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream) {
+    int rc = validate(p, 0, p ? p->D : 0);
+    if (rc) return rc;
+    if (!coef || !fold) return set_err(TTM_E_ARG, "ttm_fold: bad arguments%s");
+    hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
+    return check_launch("k_fold");
+}
+
+int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* Xsoa, int64_t ldx, int64_t N,
+                int32_t k0, int32_t k1, double* Zsoa, int64_t ldz, double* logdet, const double* sigma, double* sumsq,
+                void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
-    if (!coef || !Xsoa || N < 1 || ldx < N || (Zsoa && ldz < N) || (!Zsoa && !logdet && !sumsq))
+    if (!coef || !fold || !Xsoa || N < 1 || ldx < N || (Zsoa && ldz < N) || (!Zsoa && !logdet && !sumsq))
         return set_err(TTM_E_ARG, "ttm_forward: bad arguments%s");
-    const DevProg P = dev_prog(p);
-    return for_each_chunk(p, k0, k1, 1, 0, 0, [&](int ka, int kb, Stage st, int bd) {
-        hipLaunchKernelGGL(k_forward, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, P, st,
-                           coef + p->h_coef_off[ka], Xsoa, ldx, N, Zsoa ? Zsoa + (int64_t)(ka - k0) * ldz : nullptr, ldz,
-                           logdet, sigma ? sigma + (ka - k0) : nullptr, sumsq, ka > k0 ? 1 : 0);
-        return check_launch("k_forward");
-    });
+    const int nsl = map_slots(p, k0, k1);
+    // several samples per thread: the scalar (table-interpreter) work is paid once per NS*64 samples
+    int NS = N >= 4 * 256 * 256 ? 2 : 1;
+    if (const char* e = getenv("TTM_FORWARD_NS")) NS = atoi(e);           // tuning knob
+    if (NS != 1 && NS != 2 && NS != 4) NS = 1;
+    while (NS > 1 && !pick_block(nsl, 0, NS)) NS >>= 1;
+    const int bd = pick_block(nsl, 0, NS);
+    if (!bd) return set_err(TTM_E_LIMIT, "ttm_forward: %s%lld scratch slots per sample do not fit the LDS budget", "", nsl);
+    const bool sep = p->monotonicity == TTM_MONO_SEPARABLE;
+    typedef void (*kern_t)(DevProg, int, int, const double*, const double*, const double*, int64_t, int64_t, double*, int64_t,
+                           double*, const double*, double*);
+    kern_t kern;
+#define TTM_FWD_PICK(NSV)                                                                                              \
+    (sep ? (logdet ? k_forward<TTM_MONO_SEPARABLE, true, NSV> : k_forward<TTM_MONO_SEPARABLE, false, NSV>)              \
+         : (logdet ? k_forward<TTM_MONO_INTEGRATED, true, NSV> : k_forward<TTM_MONO_INTEGRATED, false, NSV>))
+    if (NS == 4) kern = TTM_FWD_PICK(4);
+    else if (NS == 2) kern = TTM_FWD_PICK(2);
+    else kern = TTM_FWD_PICK(1);
+#undef TTM_FWD_PICK
+    hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), lds_bytes(nsl, bd, 0, NS), (hipStream_t)stream, dev_prog(p),
+                       (int)k0, (int)k1, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);
+    return check_launch("k_forward");
 }
 
 int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa, int64_t ldx, int64_t N, double* out,
@@ -624,69 +825,68 @@ int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa
     int rc = validate(p, k, k + 1);
     if (rc) return rc;
     if (!Xsoa || !out || N < 1 || ldx < N || ldo < N || which < 0 || which > 2) return set_err(TTM_E_ARG, "ttm_basis: bad arguments%s");
-    Stage st = make_stage(p, k, k + 1, 1, 0);
-    st.ncf = 0;
-    int bd = pick_block(p, st, 0);
-    if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", k);
-    hipLaunchKernelGGL(k_basis, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, dev_prog(p), st,
+    hipLaunchKernelGGL(k_basis, dim3(grid_for(N, 256)), dim3(256), lds_bytes(0, 256, 0), (hipStream_t)stream, dev_prog(p), (int)k,
                        (int)which, Xsoa, ldx, N, out, ldo);
     return check_launch("k_basis");
 }
 
-int ttm_inverse_table_build(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* pts, int32_t T,
-                            double* out, void* stream) {
+int ttm_inverse_table_build(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
+                            const double* pts, int32_t T, double* out, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
-    if (!coef || !pts || !out || T < 2) return set_err(TTM_E_ARG, "ttm_inverse_table_build: bad arguments%s");
-    const DevProg P = dev_prog(p);
-    DevProg Psep = P;
-    Psep.mono = TTM_MONO_SEPARABLE;
-    return for_each_chunk(p, k0, k1, 1, 0, 0, [&](int ka, int kb, Stage st, int bd) {
-        hipLaunchKernelGGL(k_table_build, dim3((T + bd - 1) / bd), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, Psep, st,
-                           coef + p->h_coef_off[ka], pts, (int)T, out + (int64_t)(ka - k0) * T);
-        return check_launch("k_table_build");
-    });
+    if (!coef || !fold || !pts || !out || T < 2) return set_err(TTM_E_ARG, "ttm_inverse_table_build: bad arguments%s");
+    const int ns = map_slots(p, k0, k1);
+    const int bd = pick_block(ns, 0);
+    if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_table_build: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    hipLaunchKernelGGL(k_table_build, dim3((T + bd - 1) / bd, k1 - k0), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream,
+                       dev_prog(p), (int)k0, coef, fold, pts, (int)T, out);
+    return check_launch("k_table_build");
 }
 
-int ttm_inverse_table(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* Zsoa, int64_t ldz,
-                      double* Xsoa, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int32_t T,
-                      const double* tmin, const double* tmax, int32_t truncate, void* stream) {
+int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32_t nb, double* tmin, double* tmax,
+                            int32_t* bkt, int32_t* unsorted, void* stream) {
+    if (!tab_x || !tmin || !tmax || !bkt || !unsorted || ncomp < 1 || T < 2 || T > 2048 || nb < 1 || nb > 4096)
+        return set_err(TTM_E_ARG, "ttm_inverse_table_index: bad arguments%s");
+    hipLaunchKernelGGL(k_table_index, dim3(ncomp), dim3(256), 0, (hipStream_t)stream, tab_x, (int)T, (int)nb, tmin, tmax, bkt,
+                       unsorted);
+    return check_launch("k_table_index");
+}
+
+int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,
+                      int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
+                      int32_t T, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb, int32_t truncate,
+                      void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
-    if (!coef || !Zsoa || !Xsoa || !tab_x || !tab_y || !tmin || !tmax || N < 1 || ldx < N || ldz < N || T < 2 || T > 2048)
+    if (!coef || !fold || !Zsoa || !Xsoa || !tab_x || !tab_y || !tmin || !tmax || !bkt || N < 1 || ldx < N || ldz < N || T < 2 ||
+        T > TTM_TAB_MAXPT * 256 || nb < 1 || nb + 1 > TTM_TAB_MAXBK * 256 || (ldy != 0 && ldy < T))
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
-    const DevProg P = dev_prog(p);
-    return for_each_chunk(p, k0, k1, 0, 0, 2 * T, [&](int ka, int kb, Stage st, int bd) {
-        const size_t bytes = lds_bytes(p, st, bd, 2 * T);
-        const int tab_off = st.nslots * bd + st.ndp + st.ncf + 2 * p->Q;
-        // the int table follows the doubles; place xs/ys after it, 8-byte aligned
-        const int tab_off_d = tab_off + (st.nit + 1) / 2;
-        const size_t total = (size_t)(tab_off_d + 2 * T) * 8;
-        (void)bytes;
-        hipLaunchKernelGGL(k_inverse_table, dim3(grid_for(N, bd)), dim3(bd), total, (hipStream_t)stream, P, st,
-                           coef + p->h_coef_off[ka], Zsoa + (int64_t)(ka - k0) * ldz, ldz, Xsoa, ldx, N,
-                           tab_x + (int64_t)(ka - k0) * T, tab_y + (int64_t)(ka - k0) * T, (int)T, tmin + (ka - k0), tmax + (ka - k0),
-                           (int)truncate, tab_off_d);
-        return check_launch("k_inverse_table");
-    });
+    const int bd = 256;
+    const int extra = (ldy != 0 ? 4 : 3) * T + (nb + 2);
+    hipLaunchKernelGGL(k_inverse_table, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(0, bd, extra), (hipStream_t)stream, dev_prog(p),
+                       (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, tmin, tmax, bkt, (int)nb,
+                       (int)truncate);
+    return check_launch("k_inverse_table");
 }
 
-int ttm_inverse_bisect(const ttm_program* p, const double* coef, int32_t k0, int32_t k1, const double* Zsoa, int64_t ldz,
-                       double* Xsoa, int64_t ldx, int64_t N, int32_t* iters, const int32_t* cap, void* stream) {
+int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,
+                       int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, int32_t* iters, const int32_t* cap, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
-    if (!coef || !Zsoa || !Xsoa || !iters || N < 1 || ldx < N || ldz < N) return set_err(TTM_E_ARG, "ttm_inverse_bisect: bad arguments%s");
-    const DevProg P = dev_prog(p);
-    return for_each_chunk(p, k0, k1, 1, 0, 0, [&](int ka, int kb, Stage st, int bd) {
-        hipLaunchKernelGGL(k_inverse_bisect, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, P, st,
-                           coef + p->h_coef_off[ka], Zsoa + (int64_t)(ka - k0) * ldz, ldz, Xsoa, ldx, N, iters + (ka - k0),
-                           cap ? cap + (ka - k0) : nullptr);
-        return check_launch("k_inverse_bisect");
-    });
+    if (!coef || !fold || !Zsoa || !Xsoa || !iters || N < 1 || ldx < N || ldz < N) return set_err(TTM_E_ARG, "ttm_inverse_bisect: bad arguments%s");
+    const int ns = map_slots(p, k0, k1);
+    const int bd = pick_block(ns, 0);
+    if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_bisect: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE> : k_inverse_bisect<TTM_MONO_INTEGRATED>;
+    hipLaunchKernelGGL(kern, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1,
+                       coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, cap);
+    return check_launch("k_inverse_bisect");
 }
 
-int64_t ttm_reduce_work_size(int32_t nout) { return (int64_t)TTM_RED_BLOCKS * (nout > 0 ? nout : 1); }
+// workspace: [folded coefficients of the component (<= 4096) | per-block partials]
+#define TTM_OBJ_FOLD_MAX 4096
+int64_t ttm_reduce_work_size(int32_t nout) { return (int64_t)TTM_OBJ_FOLD_MAX + (int64_t)TTM_RED_BLOCKS * (nout > 0 ? nout : 1); }
 
 int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* Xsoa, int64_t ldx, int64_t N,
                   double* work, double* out, void* stream) {
@@ -700,14 +900,20 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     const int n_nm = p->h_n_nm[k];
     const int n_mon = p->h_coef_off[k + 1] - p->h_coef_off[k] - n_nm;
     const int nacc = sep ? 1 + n_mon : 1 + n_nm + n_mon;
-    Stage st = make_stage(p, k, k + 1, sep ? 1 : 3, nacc);
-    const int bd = pick_block(p, st, 0);
+    const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
+    const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
+    if (nfold > TTM_OBJ_FOLD_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
+    const int bd = pick_block(nscr + nacc, 0);
     if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", k);
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
-    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, dev_prog(p), st, coef_k,
-                       Xsoa, ldx, N, nacc, work);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)work, nb, nacc, out);
+    const DevProg P = dev_prog(p);
+    double* fold_k = work;
+    double* partial = work + TTM_OBJ_FOLD_MAX;
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, (int)k, coef_k, fold_k);
+    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k, coef_k,
+                       (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
     return check_launch("k_objective");
 }
 
@@ -717,15 +923,14 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     if (rc) return rc;
     if (!Xsoa || !work || !out || N < 1 || ldx < N) return set_err(TTM_E_ARG, "ttm_gram: bad arguments%s");
     const int m = p->h_coef_off[k + 1] - p->h_coef_off[k];
-    Stage st = make_stage(p, k, k + 1, 1, m);
-    st.ncf = 0;
-    int bd = pick_block(p, st, 0);
-    while (bd && m * m > TTM_GRAM_MAXPAIR * bd) bd = 0;
+    int bd = pick_block(m, 0);
+    if (bd && m * m > TTM_GRAM_MAXPAIR * bd) bd = 0;
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_gram: %s%lld basis functions exceed the kernel limits", "", m);
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
-    hipLaunchKernelGGL(k_gram, dim3(nb), dim3(bd), lds_bytes(p, st, bd, 0), (hipStream_t)stream, dev_prog(p), st, Xsoa, ldx, N, m, work);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)work, nb, m * m, out);
+    double* partial = work + TTM_OBJ_FOLD_MAX;
+    hipLaunchKernelGGL(k_gram, dim3(nb), dim3(bd), lds_bytes(m, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
     return check_launch("k_gram");
 }
 

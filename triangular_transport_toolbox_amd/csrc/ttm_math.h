@@ -1,0 +1,162 @@
+// ttm_math.h - fp64 elementary functions tuned for the transport-map kernels.
+//
+// CDNA4 has no fp64 transcendental unit: exp/erf/log are FMA chains, and the ROCm
+// device-library versions cost 62 (exp), 343 (erf) and 118 (log) instructions on
+// gfx950 with two divergent paths inside erf.  The map kernels are bound by
+// exactly these (profiles/r01_v1_*), so they get branch-free replacements:
+//   fast_exp : Cody-Waite reduction + degree-13 Taylor/Horner, ~22 instructions, <= 1 ulp
+//   erf_tab  : piecewise degree-9 Taylor table (96 intervals on [0,6), 7.7 KB, staged in
+//              LDS), 9 FMA + 10 LDS reads, max abs error 2.3e-16; the same coefficients give
+//              exp(-t^2) as the polynomial's derivative (9 more FMA, no exp call)
+//   fast_log : fdlibm-style log with a Newton reciprocal, ~35 instructions, <= 2 ulp
+//   fast_div : v_rcp_f64 + 2 Newton steps + residual correction (not IEEE-exact, <= 1 ulp)
+// Accuracy is tested against NumPy/SciPy in tests/test_math.py (host build of the same code).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "ttm_erf_table.h"
+#include "ttm_vec.h"
+
+namespace ttm {
+
+TTM_HD double fast_rcp(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / b;
+#endif
+}
+
+TTM_HD double fast_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = fast_rcp(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);     // one residual correction
+#else
+    return a / b;
+#endif
+}
+
+// Taylor coefficients 1/13! .. 1/2!, kept in constant memory: read by scalar loads into SGPRs and
+// fed to v_fma_f64 as scalar operands (hoisting them into VGPRs costs 24 registers and a v_mov per step)
+#if defined(__HIPCC__)
+__device__ double g_exp_coef[12] = {   // (not const: keeps the compiler from folding the loads into literals)
+#else
+static const double g_exp_coef[12] = {
+#endif
+    1.6059043836821613e-10, 2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07,
+    2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889,
+    0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
+
+TTM_HD double fast_exp(double y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __attribute__((address_space(4))) double* kc = (const __attribute__((address_space(4))) double*)g_exp_coef;
+#else
+    const double* kc = g_exp_coef;
+#endif
+    const double yc = fmin(fmax(y, -800.0), 800.0);
+    const double k = rint(yc * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, yc);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = kc[0];
+#pragma unroll
+    for (int j = 1; j < 12; ++j) p = fma(p, r, kc[j]);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double res = ldexp(p, (int)k);
+    return (y != y) ? y : res;
+}
+
+// erf(t) and exp(-t^2) from the staged Taylor table (TTM_ERF_TABLE_LEN doubles, [coefficient][interval]).
+// The Gaussian is the derivative of the same local polynomial (erf' = 2/sqrt(pi) exp(-t^2)): no exp call.
+// abs errors: erf 2.3e-16, exp(-t^2) 9e-16 (relative 2.5e-12 up to |t| < 4); |t| >= 6 returns erf = +-1 and
+// exp(-t^2) = 2.3e-16.
+template <bool GAUSS>
+TTM_HD void erf_gauss_tab(const double* tab, double t, double& erfv, double& gauss) {
+    const double a = fmin(fabs(t), 5.9999999);
+    const int i = (int)(a * 16.0);
+    const double d = fma(-((double)i + 0.5), 0.0625, a);
+    const double* c = tab + i;
+    double p = c[9 * TTM_ERF_NINT], dp = 0.0;
+#pragma unroll
+    for (int j = 8; j >= 0; --j) {
+        if (GAUSS) dp = fma(dp, d, p);
+        p = fma(p, d, c[j * TTM_ERF_NINT]);
+    }
+    const double res = copysign(p, t);
+    erfv = (t != t) ? t : res;
+    gauss = GAUSS ? ((t != t) ? t : 0.88622692545275801365 * dp) : 0.0;      // sqrt(pi)/2
+}
+
+TTM_HD double erf_tab(const double* tab, double t) {
+    double e, g;
+    erf_gauss_tab<false>(tab, t, e, g);
+    return e;
+}
+
+TTM_HD double fast_log(double x) {
+    int e;
+    double m = frexp(x, &e);                          // [0.5, 1)
+    const bool small = m < 0.70710678118654752440;
+    m = small ? m * 2.0 : m;
+    e = small ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    // fdlibm e_log.c polynomial (Lg1..Lg7), |error| < 2^-58.45
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double res = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    if (!(x > 1.0e-300) || !(x < 1.0e300)) res = log(x);   // rare: 0, negative, NaN, inf, denormal range
+    return res;
+}
+
+// ---- N samples per thread: the scalar routines applied per element (independent chains, the
+// scheduler interleaves them) ---------------------------------------------------------------------
+template <int N> TTM_HD VecD<N> fast_rcp(const VecD<N>& b) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = fast_rcp(b.v[i]);
+    return r;
+}
+template <int N> TTM_HD VecD<N> fast_div(const VecD<N>& a, const VecD<N>& b) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = fast_div(a.v[i], b.v[i]);
+    return r;
+}
+template <int N> TTM_HD VecD<N> fast_div(const VecD<N>& a, double b) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = fast_div(a.v[i], b);
+    return r;
+}
+template <int N> TTM_HD VecD<N> fast_exp(const VecD<N>& y) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = fast_exp(y.v[i]);
+    return r;
+}
+template <int N> TTM_HD VecD<N> fast_log(const VecD<N>& x) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = fast_log(x.v[i]);
+    return r;
+}
+template <bool GAUSS, int N>
+TTM_HD void erf_gauss_tab(const double* tab, const VecD<N>& t, VecD<N>& erfv, VecD<N>& gauss) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) erf_gauss_tab<GAUSS>(tab, t.v[i], erfv.v[i], gauss.v[i]);
+}
+
+}  // namespace ttm

@@ -38,9 +38,11 @@ import numpy as np
 KIND_POLY, KIND_HF, KIND_LET, KIND_RET, KIND_RBF, KIND_IRBF = 1, 2, 3, 4, 5, 6
 ST_KINDS = {'let': KIND_LET, 'ret': KIND_RET, 'rbf': KIND_RBF, 'irbf': KIND_IRBF}
 FAM_HERMITE_E, FAM_POWER, FAM_HERMITE, FAM_CHEBYSHEV, FAM_LAGUERRE, FAM_LEGENDRE = range(6)
-HDR_LEN = 16
+HDR_LEN = 28
 (HDR_KC, HDR_N_NM, HDR_OFF_NM, HDR_N_MON, HDR_OFF_MON, HDR_OFF_FAC, HDR_NB, HDR_OFF_B, HDR_NB_HF, HDR_NB_POLY,
- HDR_NB_ST, HDR_MAXP_HF, HDR_MAXP_POLY, HDR_FLAGS, HDR_N_DPAR, HDR_LEN_BLK) = range(16)
+ HDR_NB_ST, HDR_MAXP_HF, HDR_MAXP_POLY, HDR_FLAGS, HDR_N_DPAR, HDR_LEN_BLK, HDR_N_GRP, HDR_OFF_GRP, HDR_N_GEN,
+ HDR_OFF_GEN, HDR_N_MNT, HDR_OFF_MNT, HDR_N_FOLD, HDR_OFF_FSLOT, HDR_OFF_FSRC, HDR_OFF_WB, HDR_RSV0, HDR_RSV1) = range(28)
+ST_NPAR = 5   # centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)
 
 # polynomial_type -> (family id, numpy class, unified name)   (TM:274-304)
 _P = np.polynomial
@@ -162,6 +164,10 @@ class CompiledMap:
         self.dpar_off = None
         self.coef_off = None
         self.nslots = None
+        self.nb1 = None
+        self.fold_off = None
+        self.ftab = None
+        self.ftab_off = None
         self.n_nm = None
         self.n_mon = None
         self.dpar_sources = []     # per dpar entry: ('hf', value) | ('st', kc, cross, var, index, which)
@@ -173,12 +179,15 @@ class CompiledMap:
         self.d_cols = 0
 
     def fill_special_terms(self, special):
-        """Refresh the (centre, scale) constants after a new placement."""
+        """Refresh the special-term constants after a new placement: per special
+        term {centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}."""
         for i, src in enumerate(self.dpar_sources):
             if src[0] == 'st':
                 _, kc, cross, var, index, which = src
                 d = special[kc]['cross-terms'][var] if cross else special[kc][var]
-                self.dpar[i] = d['centers' if which == 0 else 'scales'][index]
+                mu, sc = float(d['centers'][index]), float(d['scales'][index])
+                self.dpar[i] = (mu, sc, 1.0 / (np.sqrt(2) * sc), sc * np.sqrt(2 / np.pi),
+                                1.0 / (np.sqrt(2 * np.pi) * sc))[which]
         return self.dpar
 
 
@@ -235,8 +244,9 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm = CompiledMap()
     cm.family, cm.D, cm.d_cols = family, D, d_cols
     itab, dpar = [], []
-    comp_off, dpar_off, coef_off = [0], [0], [0]
-    nslots, n_nm_all, n_mon_all = [], [], []
+    comp_off, dpar_off, coef_off, fold_off, ftab_off = [0], [0], [0], [0], [0]
+    ftab = []
+    nslots, nb1, n_nm_all, n_mon_all = [], [], [], []
 
     for k in range(D):
         kc = k + skip
@@ -301,8 +311,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
             key = ('st', f[3], f[2], f[4])
             if key not in dp_index:
                 dp_index[key] = len(dp_local)
-                dp_local.append(('st', kc, f[3], f[2], f[4], 0))
-                dp_local.append(('st', kc, f[3], f[2], f[4], 1))
+                for which in range(ST_NPAR):
+                    dp_local.append(('st', kc, f[3], f[2], f[4], which))
             return dp_index[key]
 
         def fac_record(f):
@@ -353,13 +363,55 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
             if nf:
                 all_trivial = False
             terms.append([f0, nf, b, ci])
+        # ---- folded coefficients: constant, per-variable groups, B weights ---------
+        # fold slot list: each slot = list of (coefficient index within [nonmon | mon], dpar multiplier or -1)
+        fold_slots = [[]]                                   # slot 0: constant nonmonotone terms
+        groups, gen_idx = [], []
+        by_var = {}
+        for ci, t in enumerate(nm_terms):
+            if len(t) == 0:
+                fold_slots[0].append((ci, -1))
+            elif len(t) == 1 and t[0][0] == 'poly':
+                by_var.setdefault(t[0][1], []).append((ci, t[0]))
+            else:
+                gen_idx.append(ci)
+        for var in sorted(by_var):
+            P = max(f[2] for _, f in by_var[var])
+            has_hf = any(f[3] for _, f in by_var[var])
+            off = len(fold_slots)
+            fold_slots.extend([] for _ in range(2 * P))
+            for ci, f in by_var[var]:
+                if f[3]:
+                    fold_slots[off + P + f[2] - 1].append((ci, dp_hf(f[2])))
+                else:
+                    fold_slots[off + f[2] - 1].append((ci, -1))
+            groups.append([var, P, off, 1 if has_hf else 0])
+        off_wb = len(fold_slots)
+        fold_slots.extend([] for _ in range(len(bfuns) + 1))
+        mnt_idx = []
+        for ci, tr in enumerate(terms[len(nm_terms):]):
+            if tr[1] == 0:
+                fold_slots[off_wb + (tr[2] if tr[2] >= 0 else len(bfuns))].append((len(nm_terms) + ci, -1))
+            else:
+                mnt_idx.append(ci)
+        fslots, fsrc = [], []
+        for sl in fold_slots:
+            fslots.append([len(fsrc), len(sl)])
+            fsrc.extend([list(e) for e in sl])
         # ---- assemble the block ---------------------------------------------
         hdr = [0] * HDR_LEN
         off_nm = HDR_LEN
         off_mon = off_nm + 4 * len(nm_terms)
         off_fac = off_mon + 4 * len(mon_terms)
         off_b = off_fac + 4 * len(facs)
-        blk_len = off_b + 4 * len(bfuns)
+        off_grp = off_b + 4 * len(bfuns)
+        off_gen = off_grp + 4 * len(groups)
+        off_mnt = off_gen + len(gen_idx)
+        blk_len = off_mnt + len(mnt_idx)
+        off_fslot = 0                                       # fold recipes live in a separate table (ftab):
+        off_fsrc = 2 * len(fslots)                          # they are read once at staging, not kept in LDS
+        pad = (-blk_len) % 4                               # keep every block 16-byte aligned
+        blk_len += pad
         hdr[HDR_KC] = kc
         hdr[HDR_N_NM], hdr[HDR_OFF_NM] = len(nm_terms), off_nm
         hdr[HDR_N_MON], hdr[HDR_OFF_MON] = len(mon_terms), off_mon
@@ -371,8 +423,17 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         hdr[HDR_FLAGS] = 1 if all_trivial else 0
         hdr[HDR_N_DPAR] = len(dp_local)
         hdr[HDR_LEN_BLK] = blk_len
-        block = hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b]
+        hdr[HDR_N_GRP], hdr[HDR_OFF_GRP] = len(groups), off_grp
+        hdr[HDR_N_GEN], hdr[HDR_OFF_GEN] = len(gen_idx), off_gen
+        hdr[HDR_N_MNT], hdr[HDR_OFF_MNT] = len(mnt_idx), off_mnt
+        hdr[HDR_N_FOLD], hdr[HDR_OFF_FSLOT], hdr[HDR_OFF_FSRC] = len(fslots), off_fslot, off_fsrc
+        hdr[HDR_OFF_WB] = off_wb
+        block = (hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b] +
+                 [v for g in groups for v in g] + gen_idx + mnt_idx + [0] * pad)
         assert len(block) == blk_len
+        fold_off.append(fold_off[-1] + len(fslots))
+        ftab.extend([v for sl in fslots for v in sl] + [v for e in fsrc for v in e])
+        ftab_off.append(len(ftab))
         itab.extend(block)
         for src in dp_local:
             cm.dpar_sources.append(src)
@@ -380,7 +441,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         comp_off.append(len(itab))
         dpar_off.append(len(dpar))
         coef_off.append(coef_off[-1] + len(nm_terms) + len(mon_terms))
-        nslots.append(len(bfuns) + 1)
+        nslots.append(len(bfuns) + 1 if len(mnt_idx) else 0)
+        nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
         n_mon_all.append(len(mon_terms))
         cm.descriptors_mon.append([_descriptor(t) for t in mon_terms])
@@ -394,6 +456,11 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.dpar_off = np.asarray(dpar_off, dtype=np.int32)
     cm.coef_off = np.asarray(coef_off, dtype=np.int32)
     cm.nslots = np.asarray(nslots, dtype=np.int32)
+    cm.nb1 = np.asarray(nb1, dtype=np.int32)
+    cm.fold_off = np.asarray(fold_off, dtype=np.int32)
+    cm.ftab = np.asarray(ftab if len(ftab) else [0], dtype=np.int32)
+    cm.ftab_off = np.asarray(ftab_off, dtype=np.int32)
+    cm.offsets = np.concatenate((cm.comp_off, cm.dpar_off, cm.coef_off, cm.fold_off, cm.ftab_off)).astype(np.int32)
     cm.n_nm = np.asarray(n_nm_all, dtype=np.int32)
     cm.n_mon = np.asarray(n_mon_all, dtype=np.int32)
     return cm

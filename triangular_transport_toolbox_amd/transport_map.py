@@ -157,11 +157,14 @@ class transport_map():
             self.optimization_constraints_ub = [np.asarray([b[1] for b in bk]) for bk in self._cm.bounds]
 
         self._itab_d = self._to_dev(self._cm.itab, dtype=torch.int32)
+        self._ftab_d = self._to_dev(self._cm.ftab, dtype=torch.int32)
+        self._off_d = self._to_dev(self._cm.offsets, dtype=torch.int32)
         self._dpar_d = self._to_dev(self._cm.dpar)
         self._qx_d = self._to_dev(np.asarray(self.quadrature_input['xis'], dtype=float))
         self._qw_d = self._to_dev(np.asarray(self.quadrature_input['Ws'], dtype=float))
-        self._prog = _capi.make_program(self._cm, self._itab_d.data_ptr(), self._dpar_d.data_ptr(),
-                                        self._qx_d.data_ptr(), self._qw_d.data_ptr(), self._qx_d.numel(),
+        self._prog = _capi.make_program(self._cm, self._itab_d.data_ptr(), self._ftab_d.data_ptr(), self._dpar_d.data_ptr(),
+                                        self._qx_d.data_ptr(), self._qw_d.data_ptr(), self._off_d.data_ptr(),
+                                        self._qx_d.numel(),
                                         self.monotonicity, self.rectifier_type, self.delta)
         self._pp = ctypes.byref(self._prog)
         self._work = None
@@ -348,7 +351,12 @@ class transport_map():
                 raise ValueError('component %d expects %d nonmonotone and %d monotone coefficients, got %d and %d'
                                  % (k, self._cm.n_nm[k], self._cm.n_mon[k], len(cn), len(cm)))
             parts += [cn, cm]
-        return self._to_dev(np.concatenate(parts))
+        coef = self._to_dev(np.concatenate(parts))
+        # folded coefficients (device pre-pass, include/ttm.h "Folded coefficients"); kept with the vector
+        fold = self._empty(max(int(self._cm.fold_off[-1]), 1))
+        _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
+        coef._ttm_fold = fold
+        return coef
 
     # ------------------------------------------------------------------------
     # forward map
@@ -368,7 +376,7 @@ class transport_map():
         Xs, N = self._samples_for(X)
         coef = self._pack_coeffs()
         Z = self._empty(self.D, N)
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
                                           self._ptr(Z), N, None, None, None, self._stream()))
         return self._export(Z, N, 0, self.D, False)
 
@@ -377,7 +385,7 @@ class transport_map():
         """S(x) for a standardised column-major device matrix Xs (d x N) -> Z (D x N)."""
         coef = self._pack_coeffs() if coef is None else coef
         Z = self._empty(self.D, N) if Z is None else Z
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
                                           self._ptr(Z), Z.shape[1], self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq),
                                           self._stream()))
         return Z
@@ -405,7 +413,7 @@ class transport_map():
             Xs, N = self._import(x, False), x.shape[0]
         coef = self._pack_coeffs(k, coeffs_nonmon, coeffs_mon)
         Z = self._empty(1, N)
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, int(k), int(k) + 1,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, int(k), int(k) + 1,
                                           self._ptr(Z), N, None, None, None, self._stream()))
         return Z[0].cpu().numpy()
 
@@ -439,7 +447,7 @@ class transport_map():
         sigma = self._to_dev(np.asarray(self.X_std[off:off + self.D], dtype=float))
         coef = self._pack_coeffs()
         ld = self._empty(N)
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xraw), N, N, 0, self.D, None, N,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xraw), N, N, 0, self.D, None, N,
                                           self._ptr(ld), self._ptr(sigma), None, self._stream()))
         return ld
 
@@ -453,7 +461,7 @@ class transport_map():
         Xs, N = self._samples_for(X)
         coef = self._pack_coeffs()
         ss = self._empty(N)
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
                                           None, N, None, None, self._ptr(ss), self._stream()))
         ld = self._log_determinant_raw(X, skip_in_std=False)
         log_ref = -0.5 * (self.D * np.log(2 * np.pi) + ss.cpu().numpy())
@@ -517,28 +525,50 @@ class transport_map():
         return X[:, skip:]
 
     def _inverse_table(self, coef, k0, k1, Zs, Xs, N, resolution=1001, start_distance=10):
-        """TM:3987-4084 for all components: tabulate on the device, apply
-        interp1d's stable sort on the (tiny) tables, look up on the device."""
+        """TM:3987-4084 for all components: tabulate, index and look up on the device.  interp1d sorts its
+        abscissae (stable) first; monotone tables are already sorted, which the index kernel verifies -
+        only an unsorted table (flat, noisy tails) takes the host detour that applies the sort."""
+        torch = _torch()
         ncomp = k1 - k0
-        pts = np.linspace(-start_distance, start_distance, resolution)
-        pts_d = self._to_dev(pts)
+        nb = 512
+        key = (resolution, start_distance)
+        if getattr(self, '_pts_key', None) != key:
+            self._pts = np.linspace(-start_distance, start_distance, resolution)
+            self._pts_d = self._to_dev(self._pts)
+            self._pts_key = key
         out_d = self._empty(ncomp, resolution)
-        _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), k0, k1, self._ptr(pts_d), resolution,
-                                                      self._ptr(out_d), self._stream()))
+        tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
+        bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
+        uns_d = self._empty(ncomp, dtype=torch.int32)
+        st = self._stream()
+        _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                      self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
+        _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
+                                                      self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
+                                                      ctypes.c_void_p(uns_d.data_ptr()), st))
+        trunc = 1 if self.root_search_truncation else 0
+        _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(out_d),
+                                                self._ptr(self._pts_d), 0, resolution, self._ptr(tmin_d),
+                                                self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
+        if int(uns_d.max().item()) == 0:
+            return
+        # rare: some table is not non-decreasing -> reproduce interp1d's stable sort on the host and redo
         out = out_d.cpu().numpy()
-        order = np.argsort(out, axis=1, kind='mergesort')              # interp1d(assume_sorted=False)
-        if np.array_equal(order, np.broadcast_to(np.arange(resolution), order.shape)):
-            tab_x_d, tab_y = out_d, np.broadcast_to(pts, out.shape)
-        else:
-            tab_x_d = self._to_dev(np.take_along_axis(out, order, axis=1))
-            tab_y = pts[order]
-        tab_y_d = self._to_dev(np.ascontiguousarray(tab_y))
-        tmin_d = self._to_dev(np.min(out, axis=1))
-        tmax_d = self._to_dev(np.max(out, axis=1))
-        _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, N,
-                                                self._ptr(tab_x_d), self._ptr(tab_y_d), resolution, self._ptr(tmin_d),
-                                                self._ptr(tmax_d), 1 if self.root_search_truncation else 0,
-                                                self._stream()))
+        order = np.argsort(out, axis=1, kind='mergesort')
+        tab_x = np.take_along_axis(out, order, axis=1)
+        tmin, tmax = np.min(out, axis=1), np.max(out, axis=1)
+        with np.errstate(invalid='ignore'):
+            edges = tmin[:, None] + np.arange(nb + 1)[None, :] * ((tmax - tmin) / nb)[:, None]
+        bkt = np.stack([np.searchsorted(tab_x[i], edges[i], side='left') for i in range(ncomp)]).astype(np.int32)
+        bkt[:, 0], bkt[:, -1] = 0, resolution
+        tab_x_d, tab_y_d = self._to_dev(tab_x), self._to_dev(np.ascontiguousarray(self._pts[order]))
+        bkt_d = self._to_dev(bkt, dtype=torch.int32)
+        tmin_d, tmax_d = self._to_dev(tmin), self._to_dev(tmax)
+        _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(tab_x_d),
+                                                self._ptr(tab_y_d), resolution, resolution, self._ptr(tmin_d),
+                                                self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
 
     def _inverse_bisect(self, coef, k0, k1, Zs, Xs, N):
         """TM:3798-3985.  Samples 1..N-1 run to convergence and record the largest
@@ -552,13 +582,13 @@ class transport_map():
         owns_first = dist is None or dist.get_rank() == 0
         first = 1 if owns_first else 0
         if N - first > 0:
-            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs, first), N,
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs, first), N,
                                                      self._ptr(Xs, first), N, N - first,
                                                      ctypes.c_void_p(iters.data_ptr()), None, self._stream()))
         self._allreduce(iters, op='max')
         if owns_first:
             dummy = self._zeros(ncomp, dtype=torch.int32)
-            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, 1,
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, 1,
                                                      ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(iters.data_ptr()),
                                                      self._stream()))
         if self.verbose and int(iters.max().item()) >= 100:
