@@ -415,14 +415,13 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
     }
 }
 
-// One sample per thread; per tile the thread walks the components in order, so its column cache
-// (VarCache) serves the just-solved x_j to the following components without touching HBM again.
-// The table of component k+1 and the sample's z_{k+1} are fetched (into registers) while component k
-// is being solved and written to the other LDS buffer afterwards: one barrier per component and no
-// exposed global-memory latency.
-// LDS image: [erf table | cache | ys (T) | xs A (T) | xs B (T) | bucket index A, B (nb+1 int32 each)]
-#define TTM_TAB_MAXPT 4       // table points per thread (T <= 4 * 256)
-#define TTM_TAB_MAXBK 4       // bucket entries per thread (nb + 1 <= 4 * 256)
+// One sample per thread, no workgroup-level staging: the 1001-point tables of all components stay in
+// L2 / L1 (8 KB each, shared by every wave) and each sample gathers the handful of entries its search
+// needs: one 16-byte gather of the bucket index narrows the range to a few entries, two or three
+// gathers bisect it, one 16-byte gather fetches the bracketing pair.  Waves never synchronise, so the
+// gather latency is hidden by occupancy instead of barriers and prefetch registers.  The thread walks
+// the components in order; its column cache serves the just-solved x_j to the following components.
+template <int NS>
 __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1, const double* __restrict__ coef,
                                                        const double* __restrict__ fold,
                                                        const double* __restrict__ Z, int64_t ldz,
@@ -431,103 +430,68 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                                                        int64_t ldy, int T,
                                                        const double* __restrict__ tmin, const double* __restrict__ tmax,
                                                        const int* __restrict__ bkt, int nb, int truncate) {
-    double* base;
-    CacheStore<double> cst;
-    const Prog g = make_prog_lds(P, cst, base);
+    typedef typename real_of<NS>::type R;
+    double* unused;
+    CacheStore<R> cst;
+    const Prog g = make_prog_lds(P, cst, unused);
     const int bd = blockDim.x, tid = threadIdx.x;
     const int nbk = nb + 1;
-    double* ysA = base;
-    double* xsA = ysA + T;
-    double* xsB = xsA + T;
-    int* bkA = reinterpret_cast<int*>(xsB + T);
-    int* bkB = bkA + nbk + (nbk & 1);
-    double* ysB = reinterpret_cast<double*>(bkB + nbk + (nbk & 1));   // only present when ldy != 0
-    for (int64_t tile = (int64_t)blockIdx.x * bd; tile < N; tile += (int64_t)gridDim.x * bd) {
-        const int64_t n = tile + tid;
-        const bool act = n < N;
-        const XSoA xa{X, ldx, act ? n : 0};
-        VarCache<XSoA, double> x(xa, cst);
-        // stage the first table
-        __syncthreads();
-        for (int i = tid; i < T; i += bd) {
-            xsA[i] = tab_x[i];
-            ysA[i] = tab_y[i];
+    for (int64_t tile = (int64_t)blockIdx.x * NS * bd; tile < N; tile += (int64_t)gridDim.x * NS * bd) {
+        XSoAN<NS> xa;
+        xa.X = X; xa.ld = ldx;
+        bool act[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            const int64_t n = tile + (int64_t)e * bd + tid;
+            act[e] = n < N;
+            xa.n[e] = act[e] ? n : N - 1;
         }
-        for (int i = tid; i < nbk; i += bd) bkA[i] = bkt[i];
-        double z_next = act ? Z[n] : 0.0;
-        __syncthreads();
+        VarCache<XSoAN<NS>, R> x(xa, cst);
+        R z_next;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) set_elem(z_next, e, Z[xa.n[e]]);
         for (int k = k0; k < k1; ++k) {
-            const int par = (k - k0) & 1;
-            double* xs = par ? xsB : xsA;
-            double* ys = (ldy != 0 && par) ? ysB : ysA;
-            int* bk = par ? bkB : bkA;
-            // prefetch table k+1 and z_{k+1} into registers
-            const bool more = k + 1 < k1;
-            double px[TTM_TAB_MAXPT], py[TTM_TAB_MAXPT];
-            int pb[TTM_TAB_MAXBK];
-            const double zk = z_next;
-            if (more) {
-                const double* nx = tab_x + (int64_t)(k + 1 - k0) * T;
-                const double* ny = tab_y + (int64_t)(k + 1 - k0) * ldy;
-                const int* nbp = bkt + (int64_t)(k + 1 - k0) * nbk;
+            const R zk = z_next;
+            if (k + 1 < k1) {
 #pragma unroll
-                for (int j = 0; j < TTM_TAB_MAXPT; ++j) {
-                    const int i = tid + j * bd;
-                    px[j] = i < T ? nx[i] : 0.0;
-                    py[j] = (ldy != 0 && i < T) ? ny[i] : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < TTM_TAB_MAXBK; ++j) {
-                    const int i = tid + j * bd;
-                    pb[j] = i < nbk ? nbp[i] : 0;
-                }
-                if (act) z_next = Z[(int64_t)(k + 1 - k0) * ldz + n];
+                for (int e = 0; e < NS; ++e) set_elem(z_next, e, Z[(int64_t)(k + 1 - k0) * ldz + xa.n[e]]);
             }
-            if (act) {
-                const Comp c = comp_at(P, k, 0, coef, fold);
-                const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
-                const double off = nonmon_sum<double>(c, g, x);
-                double target = -off + zk;
+            const Comp c = comp_at(P, k, 0, coef, fold);
+            const double* xs = tab_x + (int64_t)(k - k0) * T;
+            const double* ys = tab_y + (int64_t)(k - k0) * ldy;
+            const int* bk = bkt + (int64_t)(k - k0) * nbk;
+            const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
+            const double scale = (double)nb / (hi - lo);
+            const bool use_bkt = scale > 0.0 && scale < 1.0e300 && nb >= 4;
+            const R off = nonmon_sum<R>(c, g, x);
+            R r;
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                double target = -elem(off, e) + elem(zk, e);
                 if (truncate) {                      // TM:4074-4076 (comparisons keep NaN untouched)
                     if (target < lo) target = lo;
                     if (target > hi) target = hi;
                 }
                 // np.searchsorted(xs, target) (left): bisect inside the buckets around the target only
                 int a = 0, b = T;
-                const double scale = (double)nb / (hi - lo);
-                if (scale > 0.0 && scale < 1.0e300) {
+                if (use_bkt) {
                     int q = (int)((target - lo) * scale);
-                    q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
-                    a = bk[q > 0 ? q - 1 : 0];
-                    b = bk[q + 2 < nb ? q + 2 : nb];
+                    q = q < 1 ? 1 : (q > nb - 2 ? nb - 2 : q);
+                    a = bk[q - 1];                   // bucket edges q-1 .. q+2 bracket the target
+                    b = bk[q + 2];
                 }
                 while (a < b) {
                     const int mid = (a + b) >> 1;
                     if (xs[mid] < target) a = mid + 1; else b = mid;
                 }
                 const int i = a < 1 ? 1 : (a > T - 1 ? T - 1 : a);
-                const double x_lo = xs[i - 1], y_lo = ys[i - 1];
-                const double slope = fast_div(ys[i] - y_lo, xs[i] - x_lo);        // interp1d slope form (TM:4062-4065)
-                const double r = slope * (target - x_lo) + y_lo;
-                X[(int64_t)c.kc * ldx + n] = r;
-                x.put(c.kc, r);
+                const double x_lo = xs[i - 1], x_hi = xs[i], y_lo = ys[i - 1], y_hi = ys[i];
+                const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
+                const double re = slope * (target - x_lo) + y_lo;
+                set_elem(r, e, re);
+                if (act[e]) X[(int64_t)c.kc * ldx + xa.n[e]] = re;
             }
-            if (more) {
-                double* xn = par ? xsA : xsB;
-                double* yn = par ? ysA : ysB;
-                int* bn = par ? bkA : bkB;
-#pragma unroll
-                for (int j = 0; j < TTM_TAB_MAXPT; ++j) {
-                    const int i = tid + j * bd;
-                    if (i < T) { xn[i] = px[j]; if (ldy != 0) yn[i] = py[j]; }
-                }
-#pragma unroll
-                for (int j = 0; j < TTM_TAB_MAXBK; ++j) {
-                    const int i = tid + j * bd;
-                    if (i < nbk) bn[i] = pb[j];
-                }
-            }
-            __syncthreads();
+            x.put(c.kc, r);
         }
     }
 }
@@ -859,12 +823,14 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
     int rc = validate(p, k0, k1);
     if (rc) return rc;
     if (!coef || !fold || !Zsoa || !Xsoa || !tab_x || !tab_y || !tmin || !tmax || !bkt || N < 1 || ldx < N || ldz < N || T < 2 ||
-        T > TTM_TAB_MAXPT * 256 || nb < 1 || nb + 1 > TTM_TAB_MAXBK * 256 || (ldy != 0 && ldy < T))
+        T > 65536 || nb < 1 || nb > 65536 || (ldy != 0 && ldy < T))
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
     const int bd = 256;
-    const int extra = (ldy != 0 ? 4 : 3) * T + (nb + 2);
-    hipLaunchKernelGGL(k_inverse_table, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(0, bd, extra), (hipStream_t)stream, dev_prog(p),
+    int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)
+    if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob
+    auto kern = NS == 2 ? k_inverse_table<2> : k_inverse_table<1>;
+    hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), lds_bytes(0, bd, 0, NS), (hipStream_t)stream, dev_prog(p),
                        (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, tmin, tmax, bkt, (int)nb,
                        (int)truncate);
     return check_launch("k_inverse_table");
