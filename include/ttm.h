@@ -173,6 +173,15 @@ int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, con
 int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t dout,
                const double* mean, const double* std, double* Xrow, void* stream);
 
+/* ---- K9: exact order statistics of one column (radix select) -----------------------
+ * np.quantile (method 'linear') of TM:775-778 (quantile standardisation) and TM:2266-2296 (special-term
+ * centres) interpolates between two order statistics; this entry point returns them exactly:
+ * out[j] = ranks[j]-th smallest value of col[0..N) (0-based).  ranks: device int64[nr], nr <= 16.
+ * work: device, ttm_select_work_size(nr) bytes.  Eight histogram passes over the column, no host sync. */
+int64_t ttm_select_work_size(int32_t nr);
+int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out,
+                         void* work, void* stream);
+
 /* ---- folded coefficients -------------------------------------------------------
  * The map kernels evaluate the nonmonotone part per variable with summed ("folded") coefficients
  * and the monotone part through per-function weights (layout: "Folded coefficients" above).

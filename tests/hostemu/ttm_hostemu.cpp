@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_eval.h"
@@ -107,6 +108,17 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
             if (mean) v = v * sd[j0 + j] + mean[j0 + j];
             Xrow[n * dout + j] = v;
         }
+    return 0;
+}
+
+int64_t ttm_select_work_size(int32_t) { return 8; }
+
+int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void*, void*) {
+    std::vector<double> v(col, col + N);
+    for (int j = 0; j < nr; ++j) {
+        std::nth_element(v.begin(), v.begin() + ranks[j], v.end());
+        out[j] = v[ranks[j]];
+    }
     return 0;
 }
 

@@ -277,6 +277,74 @@ __global__ __launch_bounds__(64) void k_colfinish(const double* __restrict__ par
 }
 
 // ---------------------------------------------------------------------------
+// K9: exact order statistics by radix select (8 passes of 8 bits over order-preserving 64-bit keys)
+// state per requested rank: prefix (determined high bits), remaining rank; hist: nr x 256 counters
+// ---------------------------------------------------------------------------
+
+#define TTM_SEL_MAX 16
+
+__device__ __forceinline__ unsigned long long f64_key(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);      // total order: -inf < ... < -0 < +0 < ... < +inf < NaN
+}
+
+struct SelState {
+    unsigned long long prefix[TTM_SEL_MAX];
+    long long rank[TTM_SEL_MAX];
+};
+
+__global__ __launch_bounds__(256) void k_select_init(const long long* __restrict__ ranks, int nr, SelState* st,
+                                                     unsigned int* __restrict__ hist) {
+    for (int i = threadIdx.x; i < nr * 256; i += blockDim.x) hist[i] = 0u;
+    if (threadIdx.x < nr) { st->prefix[threadIdx.x] = 0ull; st->rank[threadIdx.x] = ranks[threadIdx.x]; }
+}
+
+// histogram of byte `shift/8` over the elements whose higher bytes equal the rank's prefix
+__global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ col, int64_t N, int nr, int shift,
+                                                     const SelState* __restrict__ st, unsigned int* __restrict__ hist) {
+    __shared__ unsigned int lh[TTM_SEL_MAX * 256];
+    __shared__ unsigned long long pf[TTM_SEL_MAX];
+    for (int i = threadIdx.x; i < nr * 256; i += blockDim.x) lh[i] = 0u;
+    if (threadIdx.x < nr) pf[threadIdx.x] = st->prefix[threadIdx.x];
+    __syncthreads();
+    const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long key = f64_key(col[n]);
+        const unsigned int bin = (unsigned int)((key >> shift) & 255ull);
+        for (int j = 0; j < nr; ++j)
+            if (((key ^ pf[j]) & himask) == 0ull) atomicAdd(&lh[j * 256 + bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * 256; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// choose the bin that holds the requested rank, extend the prefix, clear the histogram
+__global__ __launch_bounds__(64) void k_select_pick(int nr, int shift, SelState* st, unsigned int* __restrict__ hist,
+                                                    double* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (j < nr) {
+        long long r = st->rank[j];
+        unsigned int* h = hist + j * 256;
+        int bin = 0;
+        for (; bin < 255; ++bin) {
+            const long long c = (long long)h[bin];
+            if (r < c) break;
+            r -= c;
+        }
+        st->rank[j] = r;
+        const unsigned long long pfx = st->prefix[j] | ((unsigned long long)bin << shift);
+        st->prefix[j] = pfx;
+        if (shift == 0) {
+            const unsigned long long u = (pfx >> 63) ? (pfx & 0x7fffffffffffffffull) : ~pfx;
+            out[j] = __longlong_as_double((long long)u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * 256; i += blockDim.x) hist[i] = 0u;
+}
+
+// ---------------------------------------------------------------------------
 // K2/K3: forward map (+ fused log-determinant / squared norm)
 // ---------------------------------------------------------------------------
 
@@ -741,6 +809,24 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
     dim3 grid((unsigned)((N + 63) / 64), (dout + 63) / 64);
     hipLaunchKernelGGL(k_export, grid, dim3(256), 0, (hipStream_t)stream, Xsoa, ldx, N, (int)j0, (int)dout, mean, sd, Xrow);
     return check_launch("k_export");
+}
+
+int64_t ttm_select_work_size(int32_t nr) { (void)nr; return (int64_t)sizeof(SelState) + (int64_t)TTM_SEL_MAX * 256 * 4; }
+
+int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void* work,
+                         void* stream) {
+    if (!col || !ranks || !out || !work || N < 1 || nr < 1 || nr > TTM_SEL_MAX)
+        return set_err(TTM_E_ARG, "ttm_order_statistics: bad arguments%s");
+    hipStream_t s = (hipStream_t)stream;
+    SelState* st = (SelState*)work;
+    unsigned int* hist = (unsigned int*)((char*)work + sizeof(SelState));
+    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
+    const int nb = grid_for(N, 256 * 8);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
+        hipLaunchKernelGGL(k_select_pick, dim3(1), dim3(64), 0, s, (int)nr, shift, st, hist, out);
+    }
+    return check_launch("k_select");
 }
 
 int64_t ttm_fold_size(const ttm_program* p) { return (p && p->h_fold_off) ? p->h_fold_off[p->D] : -1; }

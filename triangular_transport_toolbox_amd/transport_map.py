@@ -33,7 +33,7 @@ import ctypes
 
 import numpy as np
 
-from . import _capi, termtable
+from . import _capi, quantile, termtable
 
 __all__ = ['transport_map']
 
@@ -77,7 +77,8 @@ class transport_map():
                  adaptation_max_order=10,
                  adaptation_skip_dimensions=0,
                  adaptation_max_iterations=25,
-                 shard_samples=False):
+                 shard_samples=False,
+                 shard_components=False):
 
         self._lib = _capi.load()
         if self._DEVICE == 'cuda':
@@ -138,6 +139,8 @@ class transport_map():
         self.standardize_samples = standardize_samples
         self.adaptation = adaptation
         self.shard_samples = bool(shard_samples)
+        self.shard_components = bool(shard_components)
+        self.objective_total = None
 
         X = np.asarray(X)
         if X.ndim != 2:
@@ -297,29 +300,72 @@ class transport_map():
             self.X_mean = mean.cpu().numpy()
             self.X_std = sd.cpu().numpy()
         elif self.standardization.lower() in ('quantile', 'quantiles'):
-            if self._dist() is not None:
-                raise NotImplementedError('quantile standardisation with sharded samples')
-            self.X_mean = np.quantile(X, q=0.5, axis=0)
-            self.X_std = (np.quantile(X - self.X_mean, q=0.8413447460685429, axis=0) -
-                          np.quantile(X - self.X_mean, q=0.15865525393145707, axis=0)) / 2
+            # median / quantile spread per column (TM:775-778) from device order statistics; the
+            # quantiles of X - median are the quantiles of X minus the median (monotone shift)
+            Xraw = self._empty(d, N)
+            Xrow = self._to_dev(X)
+            _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, None, None, self._ptr(Xraw), N, self._stream()))
+            med, spread = np.empty(d), np.empty(d)
+            for j in range(d):
+                med[j] = self._device_quantile(Xraw[j], [0.5])[0]
+                qs = self._device_quantile(Xraw[j], [0.8413447460685429, 0.15865525393145707], shift=med[j])
+                spread[j] = (qs[0] - qs[1]) / 2
+            self.X_mean, self.X_std = med, spread
         else:
             raise ValueError("'standardization' must be either 'standard' or 'quantiles'.")
         self._mean_d = self._to_dev(self.X_mean)
         self._std_d = self._to_dev(self.X_std)
+
+    def _order_statistics(self, col, ranks):
+        """Exact order statistics of a device column (K9 radix select); sharded ensembles gather the
+        column first (rank order = sample order)."""
+        torch = _torch()
+        dist = self._dist()
+        if dist is not None:
+            sizes = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=self._dev)
+            sizes[dist.get_rank()] = col.numel()
+            dist.all_reduce(sizes)
+            nmax = int(sizes.max().item())
+            pad = torch.zeros(nmax, dtype=col.dtype, device=self._dev)
+            pad[:col.numel()] = col
+            parts = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, pad)
+            col = torch.cat([p_[:int(n_)] for p_, n_ in zip(parts, sizes.tolist())])
+        col = col.contiguous()
+        ranks = np.asarray(ranks, dtype=np.int64)
+        out = np.empty(len(ranks))
+        work = torch.empty(int(self._lib.ttm_select_work_size(16)), dtype=torch.uint8, device=self._dev)
+        for i in range(0, len(ranks), 16):
+            r = self._to_dev(ranks[i:i + 16])
+            o = self._empty(len(ranks[i:i + 16]))
+            _capi.check(self._lib.ttm_order_statistics(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()),
+                                                       r.numel(), self._ptr(o), ctypes.c_void_p(work.data_ptr()),
+                                                       self._stream()))
+            out[i:i + 16] = o.cpu().numpy()
+        return out, col.numel()
+
+    def _device_quantile(self, col, q, shift=None):
+        """np.quantile(col - shift, q) (method 'linear'), bit-identical, from device order statistics."""
+        dist = self._dist()
+        n = col.numel()
+        if dist is not None:
+            t = _torch().tensor([n], dtype=_torch().int64, device=self._dev)
+            dist.all_reduce(t)
+            n = int(t.item())
+        return quantile.quantile_from_order_statistics(n, q, lambda ranks: self._order_statistics(col, ranks)[0], shift)
 
     def determine_special_term_locations(self, k=None):
         """TM:2219-2389: centres = quantiles of the standardised training columns."""
         req = termtable.quantile_requests(self.special_terms)
         if len(req) == 0:
             return
-        if self._dist() is not None:
-            raise NotImplementedError('special-term placement with sharded samples needs a distributed quantile')
-        cache = {}
+        memo = {}
 
         def column_quantiles(var, q):
-            if var not in cache:
-                cache[var] = self._Xs[var].cpu().numpy()
-            return np.quantile(cache[var], q)
+            key = (var, tuple(np.asarray(q, dtype=float).tolist()))
+            if key not in memo:
+                memo[key] = self._device_quantile(self._Xs[var], q)
+            return memo[key]
         termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
         self._cm.fill_special_terms(self.special_terms)
         self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
@@ -711,8 +757,16 @@ class transport_map():
         from scipy.optimize import minimize
         if K is None:
             K = np.arange(self.D)
-        for k in K:
-            k = int(k)
+        K = [int(k) for k in K]
+        import torch.distributed as tdist
+        part = self.shard_components and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+        if part and self.shard_samples:
+            raise ValueError('shard_components needs the full ensemble on every rank (shard_samples=False)')
+        # components are independent problems (TM:2746-2786): with shard_components every rank optimises a
+        # strided subset (most expensive, i.e. last, components first as TM:2814-2822) on its replica of X
+        K_local = list(reversed(K))[tdist.get_rank()::tdist.get_world_size()] if part else K
+        J_local = 0.0
+        for k in K_local:
             if self.monotonicity == "integrated rectifier":
                 div = len(self.coeffs_nonmon[k])
                 x0 = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float),
@@ -729,7 +783,31 @@ class transport_map():
                                x0=np.asarray(self.coeffs_mon[k], dtype=float), jac=True, bounds=bounds, args=(A, k))
                 self.coeffs_mon[k] = copy.deepcopy(opt.x)
                 self.coeffs_nonmon[k] = solve_nonmon(opt.x)
+            J_local += float(opt.fun)
             if self.verbose:
                 string = '\r' + 'Progress: |' + (k + 1) * '█' + (len(K) - k - 1) * ' ' + '|'
                 print(string, end='\r')
+        if part:
+            # exchange: coefficients of every component from its owner (a few KB) and ONE scalar all-reduce
+            # of the summed objective - the only collective of the partitioned optimisation
+            torch = _torch()
+            world, rank = tdist.get_world_size(), tdist.get_rank()
+            owner = {k: i % world for i, k in enumerate(reversed(K))}
+            n_tot = int(self._cm.coef_off[-1])
+            buf = torch.zeros(n_tot, dtype=torch.float64, device=self._dev)
+            for k in K_local:
+                o = int(self._cm.coef_off[k])
+                ck = np.concatenate((self.coeffs_nonmon[k], self.coeffs_mon[k]))
+                buf[o:o + len(ck)] = torch.from_numpy(ck).to(self._dev)
+            tdist.all_reduce(buf)                      # disjoint supports: sum == gather
+            allc = buf.cpu().numpy()
+            for k in K:
+                o, nn, nm = int(self._cm.coef_off[k]), int(self._cm.n_nm[k]), int(self._cm.n_mon[k])
+                self.coeffs_nonmon[k] = allc[o:o + nn].copy()
+                self.coeffs_mon[k] = allc[o + nn:o + nn + nm].copy()
+            jt = torch.tensor([J_local], dtype=torch.float64, device=self._dev)
+            tdist.all_reduce(jt)
+            self.objective_total = float(jt.item())
+        else:
+            self.objective_total = J_local
         return
