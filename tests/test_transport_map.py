@@ -254,3 +254,18 @@ def test_argument_errors(backend):
     tm2 = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, standardize_samples=False,
                         quadrature_input={'order': 10})
     assert tm2.map(X[:7]).shape == (50, 2)
+
+
+def test_entf_cycles_match_reference(backend):
+    """Three full assimilation cycles of the Example-06 filter (N = 500, all random draws replayed from the
+    fixture): the ensemble after every cycle stays within 1e-6 of the reference's."""
+    from triangular_transport_toolbox_amd import entf
+    npz, desc = load_case('entf')
+    ens = npz['ens0']
+    tm = entf.make_filter_map(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
+    for t in range(3):
+        noises = [npz['noise_%d_%d' % (t, i)] for i in range(3)]
+        Xa = entf.assimilate(tm, ens, npz['obs'][t], noises)
+        assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
+        ens = entf.rk4(Xa, 0.05, 2)
+        assert relerr(ens, npz['forecast_%d' % t]) < 1e-6

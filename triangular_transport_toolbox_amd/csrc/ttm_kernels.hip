@@ -320,28 +320,34 @@ __global__ __launch_bounds__(256) void k_select_hist(const double* __restrict__ 
 }
 
 // choose the bin that holds the requested rank, extend the prefix, clear the histogram
-__global__ __launch_bounds__(64) void k_select_pick(int nr, int shift, SelState* st, unsigned int* __restrict__ hist,
-                                                    double* __restrict__ out) {
-    const int j = threadIdx.x;
-    if (j < nr) {
-        long long r = st->rank[j];
-        unsigned int* h = hist + j * 256;
-        int bin = 0;
-        for (; bin < 255; ++bin) {
-            const long long c = (long long)h[bin];
-            if (r < c) break;
-            r -= c;
-        }
-        st->rank[j] = r;
-        const unsigned long long pfx = st->prefix[j] | ((unsigned long long)bin << shift);
+// (one workgroup per requested rank, one thread per bin, LDS inclusive scan)
+__global__ __launch_bounds__(256) void k_select_pick(int nr, int shift, SelState* st, unsigned int* __restrict__ hist,
+                                                     double* __restrict__ out) {
+    __shared__ long long cum[256];
+    const int j = blockIdx.x, t = threadIdx.x;
+    unsigned int* h = hist + j * 256;
+    const long long mine = (long long)h[t];
+    cum[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const long long add = t >= d ? cum[t - d] : 0;
+        __syncthreads();
+        cum[t] += add;
+        __syncthreads();
+    }
+    const long long r = st->rank[j];
+    const long long before = cum[t] - mine;
+    const bool last_nonempty_guard = (t == 255);
+    if ((r >= before && r < cum[t]) || (last_nonempty_guard && r >= cum[255])) {
+        st->rank[j] = r - before;
+        const unsigned long long pfx = st->prefix[j] | ((unsigned long long)t << shift);
         st->prefix[j] = pfx;
         if (shift == 0) {
             const unsigned long long u = (pfx >> 63) ? (pfx & 0x7fffffffffffffffull) : ~pfx;
             out[j] = __longlong_as_double((long long)u);
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nr * 256; i += blockDim.x) hist[i] = 0u;
+    h[t] = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -824,7 +830,7 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     const int nb = grid_for(N, 256 * 8);
     for (int shift = 56; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
-        hipLaunchKernelGGL(k_select_pick, dim3(1), dim3(64), 0, s, (int)nr, shift, st, hist, out);
+        hipLaunchKernelGGL(k_select_pick, dim3(nr), dim3(256), 0, s, (int)nr, shift, st, hist, out);
     }
     return check_launch("k_select");
 }
