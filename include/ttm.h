@@ -86,7 +86,8 @@ extern "C" {
  * and, in the separate table ttm_program.ftab (block k at ftab[h_ftab_off[k] ..), read once per launch:
  *   fslots  : 2 int32 each  {src0, nsrc}             recipe of each folded coefficient
  *   fsrc    : 2 int32 each  {ci, p0}                 coefficient index within [nonmon | mon] and an
- *                                                    optional dpar multiplier (-1: none)
+ *                                                    optional dpar multiplier (-1: none); ci = -1: the
+ *                                                    source is the constant dpar[p0] itself
  * f0 indexes the component's factor list, b its bfun list (-1: term has no x_kc factor), ci the
  * coefficient inside coeffs_nonmon[k] / coeffs_mon[k], p0 the component's slice of dpar
  * (HF: a_n ; special term: centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)).
@@ -123,11 +124,29 @@ extern "C" {
 #define TTM_HDR_RSV0     26
 #define TTM_HDR_RSV1     27
 #define TTM_ST_NPAR       5   /* dpar doubles per special term                                 */
+/* fast-path descriptor of a component (components whose terms are all univariate: no table walking,
+ * every record is at a known offset so the scalar loads can be issued ahead of use) */
+#define TTM_FDESC_LEN    12
+#define TTM_FD_KC         0
+#define TTM_FD_N_GRP      1
+#define TTM_FD_N_ST       2
+#define TTM_FD_MAXP_HF    3
+#define TTM_FD_MAXP_POLY  4
+#define TTM_FD_COMPLEX    5   /* 1: has cross / generic terms -> generic interpreter              */
+#define TTM_FD_FINT_OFF   6   /* offset into fints                                             */
+#define TTM_FD_FOLD_OFF   7   /* offset of the component's folded coefficients                 */
+#define TTM_FD_STREAM     8   /* offset (within the component's fold) of the stream section:
+                                 wHF[maxP_hf] | wPoly[maxP_poly] | per special term {w, centre,
+                                 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}     */
+#define TTM_FD_NB         9
+#define TTM_FD_OFF_WB    10
 
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
     const int32_t* ftab;        /* fold recipes of all components, back to back    */
+    const int32_t* fdesc;       /* fast-path descriptors, TTM_FDESC_LEN int32 per component */
+    const int32_t* fints;       /* fast-path int stream (groups {var,P,alpha offset,has_hf}, special-term kinds) */
     const double*  dpar;        /* HF constants and special-term (centre, scale)   */
     const double*  quad_x;      /* Gauss-Legendre nodes   (TM:199-225), length Q   */
     const double*  quad_w;      /* Gauss-Legendre weights,               length Q   */

@@ -70,9 +70,12 @@ class EmuMap:
         self.dpar = np.ascontiguousarray(cm.dpar)
         self.ftab = np.ascontiguousarray(cm.ftab)
         self.offsets = np.ascontiguousarray(cm.offsets)
+        self.fdesc = np.ascontiguousarray(cm.fdesc)
+        self.fints = np.ascontiguousarray(cm.fints)
         self.qx, self.qw = termtable.gauss_legendre(quad_order)
         self.qx, self.qw = np.ascontiguousarray(self.qx), np.ascontiguousarray(self.qw)
-        self.prog = _capi.make_program(cm, self.itab.ctypes.data, self.ftab.ctypes.data, self.dpar.ctypes.data, self.qx.ctypes.data,
+        self.prog = _capi.make_program(cm, self.itab.ctypes.data, self.ftab.ctypes.data, self.fdesc.ctypes.data,
+                                       self.fints.ctypes.data, self.dpar.ctypes.data, self.qx.ctypes.data,
                                        self.qw.ctypes.data, self.offsets.ctypes.data, len(self.qx), monotonicity, rectifier, delta)
         self.pp = ctypes.byref(self.prog)
 

@@ -145,12 +145,17 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
             double S, dS;
-            if (logdet) {
+            const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+            if (!fd[TTM_FD_COMPLEX]) {          // same dispatch as the kernel: flat-stream fast path
+                const FastComp f = make_fast(fd, p->fints, fold, 0);
+                if (logdet) sample_forward_fast<-1, true>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, Z || sumsq, S, dS);
+                else sample_forward_fast<-1, false>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
+            } else if (logdet) {
                 sample_forward<-1, true>(c, g, x, w, Z || sumsq, S, dS);
-                ld += fast_log(sigma ? dS / sigma[k - k0] : dS);
             } else {
                 sample_forward<-1, false>(c, g, x, w, true, S, dS);
             }
+            if (logdet) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
             if (Z) Z[(int64_t)(k - k0) * ldz + n] = S;
             ss = fma(S, S, ss);
         }
@@ -188,7 +193,11 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
             const Comp& c = hc[k - k0].c;
             VecSlots2 w{scr.data()};
             VecD<2> S, dS;
-            sample_forward<-1, true>(c, g, x, w, true, S, dS);
+            const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+            if (!fd[TTM_FD_COMPLEX])
+                sample_forward_fast<-1, true>(make_fast(fd, p->fints, fold, 0), g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
+            else
+                sample_forward<-1, true>(c, g, x, w, true, S, dS);
             ld += fast_log(dS);
             Z[(int64_t)(k - k0) * ldz + n] = S.v[0];
             Z[(int64_t)(k - k0) * ldz + n1] = S.v[1];
@@ -307,7 +316,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         for (int64_t n = 0; n < N; ++n) {
             XSoA xa{X, ldx, n};
             double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
-            const double off = nonmon_sum<double>(c, g, x);
+            const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+            const double off = !fd[TTM_FD_COMPLEX] ? nonmon_sum_fast<double>(make_fast(fd, p->fints, fold, 0), g, x)
+                                                   : nonmon_sum<double>(c, g, x);
             double target = -off + Z[(int64_t)(k - k0) * ldz + n];
             if (truncate) {
                 if (target < tmin[k - k0]) target = tmin[k - k0];

@@ -126,7 +126,7 @@ TTM_HD void fold_coeffs(const int* cb, const int* fb, const double* dpar, const 
         double acc = 0.0;
         for (int j = 0; j < ns; ++j) {
             const int ci = src[2 * (s0 + j)], p0 = src[2 * (s0 + j) + 1];
-            acc += (p0 >= 0) ? coef[ci] * dpar[p0] : coef[ci];
+            acc += (ci < 0) ? dpar[p0] : ((p0 >= 0) ? coef[ci] * dpar[p0] : coef[ci]);
         }
         fold[s] = acc;
     }
@@ -611,6 +611,162 @@ TTM_HD void sample_objective_sep(const Comp& c, const Prog& p, VarCache<XA, doub
         const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
         acc.add(1 + TTM_UNI(T[3]), a * dB.get(b) * inv);
     }
+}
+
+// ---------------------------------------------------------------------------
+// fast path: components whose terms are all univariate (no cross terms, no special terms in the
+// nonmonotone list).  Everything is read from two flat streams at offsets known from one 12-int
+// descriptor, so the scalar loads of the next record are issued before the current record's
+// arithmetic (the generic interpreter chases header -> record -> parameters pointers instead).
+// ---------------------------------------------------------------------------
+
+struct FastComp {
+    cint_p gi;        // groups {var, P, alpha offset, has_hf}, then the special-term kinds
+    cdbl_p fold;      // the component's folded coefficients
+    cdbl_p stream;    // wHF | wPoly | special-term records
+    int kc, n_grp, n_st, maxP_hf, maxP_poly;
+};
+
+TTM_HD FastComp make_fast(cint_p fd, cint_p fints, cdbl_p fold_all, int fold_base) {
+    FastComp f;
+    f.kc = fd[TTM_FD_KC];
+    f.n_grp = fd[TTM_FD_N_GRP];
+    f.n_st = fd[TTM_FD_N_ST];
+    f.maxP_hf = fd[TTM_FD_MAXP_HF];
+    f.maxP_poly = fd[TTM_FD_MAXP_POLY];
+    f.gi = fints + fd[TTM_FD_FINT_OFF];
+    f.fold = fold_all + (fd[TTM_FD_FOLD_OFF] - fold_base);
+    f.stream = f.fold + fd[TTM_FD_STREAM];
+    return f;
+}
+
+template <class R, class XA>
+TTM_HD R nonmon_sum_fast(const FastComp& f, const Prog& p, VarCache<XA, R>& x) {
+    R s(f.fold[0]);
+    // software-pipelined over the groups: record g+1 is loaded while group g is evaluated
+    int var = 0, P = 0, has_hf = 0, aoff = 0;
+    if (f.n_grp > 0) { var = f.gi[0]; P = f.gi[1]; aoff = f.gi[2]; has_hf = f.gi[3]; }
+    for (int g = 0; g < f.n_grp; ++g) {
+        const int cvar = var, cP = P, chf = has_hf;
+        cdbl_p al = f.fold + aoff;
+        cdbl_p be = al + cP;
+        if (g + 1 < f.n_grp) { cint_p G = f.gi + 4 * (g + 1); var = G[0]; P = G[1]; aoff = G[2]; has_hf = G[3]; }
+        R xv, e(0.0);
+        if (chf) x.get_e(cvar, xv, e); else xv = x.get(cvar);
+        R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
+        poly_first(p.family, xv, pn, dp);
+        for (int n = 1; n <= cP; ++n) {
+            accp = vfma(al[n - 1], pn, accp);
+            if (chf) acch = vfma(be[n - 1], pn, acch);
+            if (n < cP) poly_next<false>(p.family, n, xv, pm, pn, dpm, dp);
+        }
+        s = s + accp;
+        if (chf) s = vfma(e, acch, s);
+    }
+    return s;
+}
+
+// g(t) = w_none + sum_n wHF[n] P_n(t) e^{-t^2/4} + sum_n wPoly[n] P_n(t) + sum_s w_s ST_s(t), and dg/dt
+template <bool DER, class R>
+TTM_HD void g_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, const R& t, R& g, R& dg) {
+    R acc(f.fold[off_wb + nB]), dacc(0.0);
+    cdbl_p w = f.stream;
+    if (f.maxP_hf > 0) {
+        const R E = fast_exp(-0.25 * (t * t));
+        R pm(1.0), dpm(0.0), pn, dp, a(0.0), da(0.0);
+        poly_first(p.family, t, pn, dp);
+        for (int n = 1; n <= f.maxP_hf; ++n) {
+            const double wn = w[n - 1];                      // a_n already folded in
+            a = vfma(wn, pn, a);
+            if (DER) da = vfma(wn, dp, da);
+            if (n < f.maxP_hf) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
+        }
+        acc = vfma(a, E, acc);
+        if (DER) dacc = vfma(E, da - 0.5 * (t * a), dacc);   // d/dt [P e^{-t^2/4}] = e^{-t^2/4} (P' - t P / 2)
+        w += f.maxP_hf;
+    }
+    if (f.maxP_poly > 0) {
+        R pm(1.0), dpm(0.0), pn, dp;
+        poly_first(p.family, t, pn, dp);
+        for (int n = 1; n <= f.maxP_poly; ++n) {
+            const double wn = w[n - 1];
+            acc = vfma(wn, pn, acc);
+            if (DER) dacc = vfma(wn, dp, dacc);
+            if (n < f.maxP_poly) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
+        }
+        w += f.maxP_poly;
+    }
+    // special terms: record s+1 {w, centre, 1/(sqrt2 scale), k1, k2} is loaded while s is evaluated
+    cint_p kinds = f.gi + 4 * f.n_grp;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0;
+    int kind = 0;
+    if (f.n_st > 0) { r0 = w[0]; r1 = w[1]; r2 = w[2]; r3 = w[3]; r4 = w[4]; kind = kinds[0]; }
+    for (int s = 0; s < f.n_st; ++s) {
+        const double ws = r0, mu = r1, inv = r2, k1 = r3, k2 = r4;
+        const int ck = kind;
+        if (s + 1 < f.n_st) {
+            cdbl_p nx = w + 5 * (s + 1);
+            r0 = nx[0]; r1 = nx[1]; r2 = nx[2]; r3 = nx[3]; r4 = nx[4];
+            kind = kinds[s + 1];
+        }
+        const R d = t - mu;
+        const R tt = d * inv;
+        R e, gs;
+        if (ck == TTM_KIND_LET || ck == TTM_KIND_RET) {
+            erf_gauss_tab<true>(p.erf_tab, tt, e, gs);
+            const R h = (ck == TTM_KIND_LET) ? vfma(e, -0.5, 0.5) : vfma(e, 0.5, 0.5);
+            const R gg = (0.5 * k1) * gs;
+            const R v = (ck == TTM_KIND_LET) ? vfma(d, h, -gg) : vfma(d, h, gg);
+            acc = vfma(ws, v, acc);
+            if (DER) dacc = vfma(ws, h, dacc);
+        } else if (ck == TTM_KIND_RBF) {
+            erf_gauss_tab<true>(p.erf_tab, tt, e, gs);
+            const R gg = gs * k2;
+            acc = vfma(ws, gg, acc);
+            if (DER) dacc = vfma(ws, (-2.0 * inv) * tt * gg, dacc);
+        } else {
+            if (DER) erf_gauss_tab<true>(p.erf_tab, tt, e, gs); else erf_gauss_tab<false>(p.erf_tab, tt, e, gs);
+            acc = vfma(ws, vfma(e, 0.5, 0.5), acc);
+            if (DER) dacc = vfma(ws, k2 * gs, dacc);
+        }
+    }
+    g = acc; dg = dacc;
+}
+
+template <int MONO, bool DER, class R>
+TTM_HD void mon_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, const R& t, R& m, R& dm) {
+    const int mono = (MONO >= 0) ? MONO : p.mono;
+    if (mono == TTM_MONO_SEPARABLE) {
+        g_eval_fast<DER>(f, p, nB, off_wb, t, m, dm);
+    } else {
+        const R half = t * 0.5;
+        R res(0.0);
+        for (int q = 0; q < p.Q; ++q) {
+            const R tq = half * p.qx[q] + half;
+            R g, dg;
+            g_eval_fast<false>(f, p, nB, off_wb, tq, g, dg);
+            const R fr = rect_eval(p.rect, g) + p.delta;
+            const R term = half * (p.qw[q] * fr);
+            res = (q == 0) ? term : res + term;
+        }
+        m = res;
+        dm = R(0.0);
+        if (DER) {
+            R g, dg;
+            g_eval_fast<false>(f, p, nB, off_wb, t, g, dg);
+            dm = rect_eval(p.rect, g) + p.delta;
+        }
+    }
+}
+
+template <int MONO, bool DER, class R, class XA>
+TTM_HD void sample_forward_fast(const FastComp& f, const Prog& p, int nB, int off_wb, VarCache<XA, R>& x, bool want_value,
+                                R& S, R& dS) {
+    R m, dm;
+    const R xk = x.get(f.kc);
+    mon_eval_fast<MONO, DER>(f, p, nB, off_wb, xk, m, dm);
+    S = want_value ? nonmon_sum_fast<R>(f, p, x) + m : m;
+    dS = dm;
 }
 
 // Bisection root search of one sample for one component (TM:3842-3976).

@@ -54,6 +54,8 @@ static int check_launch(const char* what) {
 struct DevProg {             // by-value kernel argument (all pointers are global memory)
     const int* itab;
     const int* ftab;
+    const int* fdesc;
+    const int* fints;
     const double* dpar;
     const double* qx;
     const double* qw;
@@ -385,18 +387,23 @@ __global__ __launch_bounds__(256) void k_forward(DevProg P, int k0, int k1, cons
         R ld(0.0), ss(0.0);
         // the component's own column is fetched one component ahead, so its HBM latency overlaps
         // the arithmetic of the current component
-        R xk_next = xa(itab[off[k0] + TTM_HDR_KC]);
+        R xk_next = xa(((cint_p)P.fdesc)[k0 * TTM_FDESC_LEN + TTM_FD_KC]);
         for (int k = k0; k < k1; ++k) {
-            const Comp c = comp_at(P, k, 0, coef, fold);
-            x.put(c.kc, xk_next);
-            if (k + 1 < k1) xk_next = xa(itab[off[k + 1] + TTM_HDR_KC]);
+            cint_p fd = (cint_p)P.fdesc + k * TTM_FDESC_LEN;
+            x.put(fd[TTM_FD_KC], xk_next);
+            if (k + 1 < k1) xk_next = xa(fd[TTM_FDESC_LEN + TTM_FD_KC]);
             R S, dS;
-            if (WANT_LD) {
-                sample_forward<MONO, true>(c, g, x, w, want_val, S, dS);
-                ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+            if (!fd[TTM_FD_COMPLEX]) {
+                // all terms univariate: flat streams, records prefetched by scalar loads
+                const FastComp f = make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0);
+                if (WANT_LD) sample_forward_fast<MONO, true>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, want_val, S, dS);
+                else sample_forward_fast<MONO, false>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
             } else {
-                sample_forward<MONO, false>(c, g, x, w, true, S, dS);
+                const Comp c = comp_at(P, k, 0, coef, fold);
+                if (WANT_LD) sample_forward<MONO, true>(c, g, x, w, want_val, S, dS);
+                else sample_forward<MONO, false>(c, g, x, w, true, S, dS);
             }
+            if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
             if (Z) {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
@@ -530,14 +537,21 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
 #pragma unroll
                 for (int e = 0; e < NS; ++e) set_elem(z_next, e, Z[(int64_t)(k + 1 - k0) * ldz + xa.n[e]]);
             }
-            const Comp c = comp_at(P, k, 0, coef, fold);
+            cint_p fd = (cint_p)P.fdesc + k * TTM_FDESC_LEN;
+            const int kc = fd[TTM_FD_KC];
             const double* xs = tab_x + (int64_t)(k - k0) * T;
             const double* ys = tab_y + (int64_t)(k - k0) * ldy;
             const int* bk = bkt + (int64_t)(k - k0) * nbk;
             const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
             const double scale = (double)nb / (hi - lo);
             const bool use_bkt = scale > 0.0 && scale < 1.0e300 && nb >= 4;
-            const R off = nonmon_sum<R>(c, g, x);
+            R off;
+            if (!fd[TTM_FD_COMPLEX]) {
+                off = nonmon_sum_fast<R>(make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0), g, x);
+            } else {
+                const Comp c = comp_at(P, k, 0, coef, fold);
+                off = nonmon_sum<R>(c, g, x);
+            }
             R r;
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
@@ -563,9 +577,9 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                 const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
                 const double re = slope * (target - x_lo) + y_lo;
                 set_elem(r, e, re);
-                if (act[e]) X[(int64_t)c.kc * ldx + xa.n[e]] = re;
+                if (act[e]) X[(int64_t)kc * ldx + xa.n[e]] = re;
             }
-            x.put(c.kc, r);
+            x.put(kc, r);
         }
     }
 }
@@ -729,13 +743,13 @@ static int grid_for(int64_t N, int per_block) {
 
 static DevProg dev_prog(const ttm_program* p) {
     DevProg P;
-    P.itab = p->itab; P.ftab = p->ftab; P.dpar = p->dpar; P.qx = p->quad_x; P.qw = p->quad_w; P.off = p->d_offsets;
+    P.itab = p->itab; P.ftab = p->ftab; P.fdesc = p->fdesc; P.fints = p->fints; P.dpar = p->dpar; P.qx = p->quad_x; P.qw = p->quad_w; P.off = p->d_offsets;
     P.D = p->D; P.Q = p->Q; P.family = p->family; P.mono = p->monotonicity; P.rect = p->rectifier; P.delta = p->delta;
     return P;
 }
 
 static int validate(const ttm_program* p, int k0, int k1) {
-    if (!p || !p->itab || !p->ftab || !p->dpar || !p->d_offsets || !p->h_comp_off || !p->h_dpar_off || !p->h_coef_off ||
+    if (!p || !p->itab || !p->ftab || !p->fdesc || !p->fints || !p->dpar || !p->d_offsets || !p->h_comp_off || !p->h_dpar_off || !p->h_coef_off ||
         !p->h_nslots || !p->h_n_nm || !p->h_fold_off || !p->h_ftab_off || !p->h_nb1)
         return set_err(TTM_E_ARG, "ttm_program has null tables%s");
     if (k0 < 0 || k1 > p->D || k0 >= k1) return set_err(TTM_E_ARG, "component range [%s%lld,%lld) invalid", "", k0, k1);

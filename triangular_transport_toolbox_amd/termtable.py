@@ -168,6 +168,8 @@ class CompiledMap:
         self.fold_off = None
         self.ftab = None
         self.ftab_off = None
+        self.fdesc = None
+        self.fints = None
         self.n_nm = None
         self.n_mon = None
         self.dpar_sources = []     # per dpar entry: ('hf', value) | ('st', kc, cross, var, index, which)
@@ -245,7 +247,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.family, cm.D, cm.d_cols = family, D, d_cols
     itab, dpar = [], []
     comp_off, dpar_off, coef_off, fold_off, ftab_off = [0], [0], [0], [0], [0]
-    ftab = []
+    ftab, fdesc, fints = [], [], []
     nslots, nb1, n_nm_all, n_mon_all = [], [], [], []
 
     for k in range(D):
@@ -394,10 +396,38 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
                 fold_slots[off_wb + (tr[2] if tr[2] >= 0 else len(bfuns))].append((len(nm_terms) + ci, -1))
             else:
                 mnt_idx.append(ci)
+        # "stream" section for the fast path (components without cross / generic terms): weights indexed
+        # densely by polynomial order and one 5-double record per special-term B function
+        # {w_b, centre, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}; a source (-1, p) copies dpar[p]
+        maxP_hf = max([b[1] for b in b_hf], default=0)
+        maxP_poly = max([b[1] for b in b_poly], default=0)
+        stream_rel = len(fold_slots)
+        fold_slots.extend([] for _ in range(maxP_hf + maxP_poly + 5 * len(b_st)))
+        for bi, b in enumerate(blist):
+            trivial_src = list(fold_slots[off_wb + bi])
+            if b[0] == 'hf':
+                fold_slots[stream_rel + b[1] - 1] = [(ci_, dp_hf(b[1])) for ci_, _ in trivial_src]
+            elif b[0] == 'poly':
+                fold_slots[stream_rel + maxP_hf + b[1] - 1] = trivial_src
+            else:
+                si = bi - len(b_hf) - len(b_poly)
+                rec = stream_rel + maxP_hf + maxP_poly + 5 * si
+                p0 = bfuns[bi][2]
+                fold_slots[rec] = trivial_src
+                for j_, which in enumerate((0, 2, 3, 4)):
+                    fold_slots[rec + 1 + j_] = [(-1, p0 + which)]
         fslots, fsrc = [], []
         for sl in fold_slots:
             fslots.append([len(fsrc), len(sl)])
             fsrc.extend([list(e) for e in sl])
+        # fast-path descriptor (12 int32) and int stream {per group: var, P, alpha offset, has_hf | ST kinds}
+        complex_comp = 1 if (len(gen_idx) or len(mnt_idx) or maxP_hf > 16 or maxP_poly > 16) else 0
+        fdesc.extend([kc, len(groups), len(b_st), maxP_hf, maxP_poly, complex_comp, len(fints), fold_off[-1], stream_rel,
+                      len(bfuns), off_wb, 0])
+        for g_ in groups:
+            fints.extend(g_)
+        fints.extend(bf[0] for bf in bfuns[len(b_hf) + len(b_poly):])
+        fints.extend([0] * ((-len(fints)) % 4))
         # ---- assemble the block ---------------------------------------------
         hdr = [0] * HDR_LEN
         off_nm = HDR_LEN
@@ -460,6 +490,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.fold_off = np.asarray(fold_off, dtype=np.int32)
     cm.ftab = np.asarray(ftab if len(ftab) else [0], dtype=np.int32)
     cm.ftab_off = np.asarray(ftab_off, dtype=np.int32)
+    cm.fdesc = np.asarray(fdesc, dtype=np.int32)
+    cm.fints = np.asarray(fints if len(fints) else [0], dtype=np.int32)
     cm.offsets = np.concatenate((cm.comp_off, cm.dpar_off, cm.coef_off, cm.fold_off, cm.ftab_off)).astype(np.int32)
     cm.n_nm = np.asarray(n_nm_all, dtype=np.int32)
     cm.n_mon = np.asarray(n_mon_all, dtype=np.int32)

@@ -162,10 +162,13 @@ class transport_map():
         self._itab_d = self._to_dev(self._cm.itab, dtype=torch.int32)
         self._ftab_d = self._to_dev(self._cm.ftab, dtype=torch.int32)
         self._off_d = self._to_dev(self._cm.offsets, dtype=torch.int32)
+        self._fdesc_d = self._to_dev(self._cm.fdesc, dtype=torch.int32)
+        self._fints_d = self._to_dev(self._cm.fints, dtype=torch.int32)
         self._dpar_d = self._to_dev(self._cm.dpar)
         self._qx_d = self._to_dev(np.asarray(self.quadrature_input['xis'], dtype=float))
         self._qw_d = self._to_dev(np.asarray(self.quadrature_input['Ws'], dtype=float))
-        self._prog = _capi.make_program(self._cm, self._itab_d.data_ptr(), self._ftab_d.data_ptr(), self._dpar_d.data_ptr(),
+        self._prog = _capi.make_program(self._cm, self._itab_d.data_ptr(), self._ftab_d.data_ptr(),
+                                        self._fdesc_d.data_ptr(), self._fints_d.data_ptr(), self._dpar_d.data_ptr(),
                                         self._qx_d.data_ptr(), self._qw_d.data_ptr(), self._off_d.data_ptr(),
                                         self._qx_d.numel(),
                                         self.monotonicity, self.rectifier_type, self.delta)
