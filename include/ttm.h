@@ -234,6 +234,8 @@ int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa
  *   scipy.interpolate.interp1d semantics (searchsorted-left, clip to [1,T-1], slope form).
  *   tab_x: (k1-k0) x T, non-decreasing (the host applies interp1d's stable sort); tab_y: the matching
  *   abscissae, row k at tab_y + (k-k0)*ldy (ldy = 0: one shared row, e.g. the unpermuted linspace).
+ *   h_y_affine (host, nullable): {y0, step, y_last} when ldy = 0 and tab_y[i] == i*step + y0 (i < T-1),
+ *   tab_y[T-1] == y_last bit for bit (np.linspace): the abscissae are then computed instead of gathered.
  *   bkt (int32, (k1-k0) x (nb+1)): search accelerator, bkt[b] = searchsorted_left(tab_x, tmin + b (tmax-tmin)/nb);
  *   the kernel bisects only inside the buckets around the target - same index as the full search.
  *   Xsoa holds the conditioning columns on entry and receives column kc of every component.       */
@@ -248,6 +250,7 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                       const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,
+                      const double* h_y_affine,
                       const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
                       int32_t truncate, void* stream);
 

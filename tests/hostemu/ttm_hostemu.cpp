@@ -304,8 +304,9 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
                       int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
-                      int32_t T, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb, int32_t truncate, void*) {
-    (void)bkt; (void)nb;   // the host double does the full search; the accelerated search must give the same index
+                      int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
+                      int32_t truncate, void*) {
+    (void)bkt; (void)nb; (void)h_y_affine;   // the host double does the full search; the accelerated search must give the same index
     const Prog g = make_prog(p);
     for (int k = k0; k < k1; ++k) {
         HostComp h;

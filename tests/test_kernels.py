@@ -116,3 +116,33 @@ def test_large_ensemble_properties(backend):
     tm.coeffs_mon = [2 * c for c in tm.coeffs_mon]
     tm.coeffs_nonmon = [2 * c for c in tm.coeffs_nonmon]
     assert relerr(tm.map(X[idx]), 2 * Z[idx]) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['c3_sep', 'c1_int', 'misc_sep'])
+def test_nan_and_inf_samples_propagate(backend, name):
+    """A NaN in a sample makes exactly the components that read it NaN (as NumPy does in the reference); the
+    other samples are untouched.  +-inf inputs stay finite or inf, never crash."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case(name)
+    X = case_X(name, npz)[:300].copy()
+    tm = transport_map(X=case_X(name, npz), monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False,
+                       **ctor_kwargs(desc))
+    tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
+    om = make_oracle(name, npz, desc)
+    Zc = tm.map(X)
+    Xn = X.copy()
+    Xn[5, 0] = np.nan
+    Xn[9, -1] = np.nan
+    Z = tm.map(Xn)
+    with np.errstate(all='ignore'):
+        Zo = om.map(Xn)
+    assert np.array_equal(np.isnan(Z), np.isnan(Zo))
+    ok = ~np.isnan(Zo)
+    assert relerr(Z[ok], Zo[ok]) < 1e-11
+    rows = np.ones(len(X), dtype=bool)
+    rows[[5, 9]] = False
+    assert np.array_equal(Z[rows], Zc[rows])
+    Xi = X.copy()
+    Xi[7, 0] = np.inf
+    Zi = tm.map(Xi)
+    assert np.array_equal(Zi[rows & (np.arange(len(X)) != 7)], Zc[rows & (np.arange(len(X)) != 7)])

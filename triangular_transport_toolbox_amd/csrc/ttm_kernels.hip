@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                                                        const double* __restrict__ Z, int64_t ldz,
                                                        double* X, int64_t ldx, int64_t N,
                                                        const double* __restrict__ tab_x, const double* __restrict__ tab_y,
-                                                       int64_t ldy, int T,
+                                                       int64_t ldy, int T, int yreg, double y0, double ystep, double ylast,
                                                        const double* __restrict__ tmin, const double* __restrict__ tmax,
                                                        const int* __restrict__ bkt, int nb, int truncate) {
     typedef typename real_of<NS>::type R;
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                     if (target > hi) target = hi;
                 }
                 // np.searchsorted(xs, target) (left): bisect inside the buckets around the target only
+                // (a 64-byte window + count variant was measured slower than these 2-3 dependent gathers)
                 int a = 0, b = T;
                 if (use_bkt) {
                     int q = (int)((target - lo) * scale);
@@ -573,7 +574,14 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                     if (xs[mid] < target) a = mid + 1; else b = mid;
                 }
                 const int i = a < 1 ? 1 : (a > T - 1 ? T - 1 : a);
-                const double x_lo = xs[i - 1], x_hi = xs[i], y_lo = ys[i - 1], y_hi = ys[i];
+                const double x_lo = xs[i - 1], x_hi = xs[i];
+                double y_lo, y_hi;
+                if (yreg) {                          // np.linspace: y_i = i*step + y0, last point exact
+                    y_lo = (double)(i - 1) * ystep + y0;
+                    y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
+                } else {
+                    y_lo = ys[i - 1]; y_hi = ys[i];
+                }
                 const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
                 const double re = slope * (target - x_lo) + y_lo;
                 set_elem(r, e, re);
@@ -924,12 +932,12 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,
                       int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
-                      int32_t T, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb, int32_t truncate,
-                      void* stream) {
+                      int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
+                      int32_t truncate, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
     if (!coef || !fold || !Zsoa || !Xsoa || !tab_x || !tab_y || !tmin || !tmax || !bkt || N < 1 || ldx < N || ldz < N || T < 2 ||
-        T > 65536 || nb < 1 || nb > 65536 || (ldy != 0 && ldy < T))
+        T < 8 || T > 65536 || nb < 4 || nb > 65536 || (ldy != 0 && ldy < T) || (h_y_affine && ldy != 0))
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
     const int bd = 256;
@@ -937,8 +945,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
     if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob
     auto kern = NS == 2 ? k_inverse_table<2> : k_inverse_table<1>;
     hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), lds_bytes(0, bd, 0, NS), (hipStream_t)stream, dev_prog(p),
-                       (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, tmin, tmax, bkt, (int)nb,
-                       (int)truncate);
+                       (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, h_y_affine ? 1 : 0,
+                       h_y_affine ? h_y_affine[0] : 0.0, h_y_affine ? h_y_affine[1] : 0.0, h_y_affine ? h_y_affine[2] : 0.0, tmin,
+                       tmax, bkt, (int)nb, (int)truncate);
     return check_launch("k_inverse_table");
 }
 

@@ -585,6 +585,13 @@ class transport_map():
             self._pts = np.linspace(-start_distance, start_distance, resolution)
             self._pts_d = self._to_dev(self._pts)
             self._pts_key = key
+            # np.linspace is i*step + start with the end point forced: let the kernel compute it when the
+            # restatement reproduces every bit
+            step = (2.0 * start_distance) / (resolution - 1)
+            regen = np.arange(0, resolution) * step + (-float(start_distance))
+            regen[-1] = float(start_distance)
+            self._pts_affine = ((ctypes.c_double * 3)(-float(start_distance), step, float(start_distance))
+                                if np.array_equal(regen, self._pts) else None)
         out_d = self._empty(ncomp, resolution)
         tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
         bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
@@ -598,7 +605,7 @@ class transport_map():
         trunc = 1 if self.root_search_truncation else 0
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                 self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(out_d),
-                                                self._ptr(self._pts_d), 0, resolution, self._ptr(tmin_d),
+                                                self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
                                                 self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
         if int(uns_d.max().item()) == 0:
             return
@@ -616,7 +623,7 @@ class transport_map():
         tmin_d, tmax_d = self._to_dev(tmin), self._to_dev(tmax)
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                 self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(tab_x_d),
-                                                self._ptr(tab_y_d), resolution, resolution, self._ptr(tmin_d),
+                                                self._ptr(tab_y_d), resolution, resolution, None, self._ptr(tmin_d),
                                                 self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
 
     def _inverse_bisect(self, coef, k0, k1, Zs, Xs, N):
