@@ -205,7 +205,8 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
  * The map kernels evaluate the nonmonotone part per variable with summed ("folded") coefficients
  * and the monotone part through per-function weights (layout: "Folded coefficients" above).
  * ttm_fold computes them for all components from the coefficient vector
- * coef = [nonmon_0 | mon_0 | nonmon_1 | ...]; fold has ttm_fold_size(p) doubles.  Call it whenever
+ * coef = [nonmon_0 | mon_0 | nonmon_1 | ...]; fold has ttm_fold_size(p) doubles (the folded coefficients
+ * plus 8 doubles of read-ahead padding; the kernels load coefficients four at a time).  Call it whenever
  * the coefficients change, before ttm_forward / ttm_inverse_*.                                    */
 int64_t ttm_fold_size(const ttm_program* p);
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream);

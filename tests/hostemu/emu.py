@@ -20,8 +20,9 @@ from triangular_transport_toolbox_amd import _capi, termtable
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'ttm_hostemu.cpp')
 LIB = os.path.join(HERE, 'libttm_hostemu.so')
-DEPS = [SRC, os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc', 'ttm_eval.h'),
-        os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
+CSRC = os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc')
+DEPS = [SRC, os.path.join(CSRC, 'ttm_eval.h'), os.path.join(CSRC, 'ttm_math.h'), os.path.join(CSRC, 'ttm_vec.h'),
+        os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
 
 _lib = None
 
@@ -29,7 +30,9 @@ _lib = None
 def build():
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in DEPS):
         return LIB
-    subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', LIB, SRC], check=True)
+    tmp = '%s.tmp.%d' % (LIB, os.getpid())
+    subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', tmp, SRC], check=True)
+    os.replace(tmp, LIB)
     return LIB
 
 
@@ -82,7 +85,7 @@ class EmuMap:
     def pack(self, coeffs_nonmon, coeffs_mon):
         coef = np.ascontiguousarray(np.concatenate([np.concatenate((np.asarray(n, float), np.asarray(m, float)))
                                                     for n, m in zip(coeffs_nonmon, coeffs_mon)]))
-        self.fold = np.zeros(max(int(self.cm.fold_off[-1]), 1))
+        self.fold = np.zeros(int(self.cm.fold_off[-1]) + 8)
         lib().ttm_fold(self.pp, ptr(coef), ptr(self.fold), None)
         return coef
 

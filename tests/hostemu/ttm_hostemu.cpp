@@ -122,7 +122,7 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     return 0;
 }
 
-int64_t ttm_fold_size(const ttm_program* p) { return p->h_fold_off[p->D]; }
+int64_t ttm_fold_size(const ttm_program* p) { return p->h_fold_off[p->D] + 8; }
 
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
     for (int k = 0; k < p->D; ++k)

@@ -62,13 +62,17 @@ def library_path():
 
 
 def load():
-    """Load libttm.so (never builds, never falls back): raises if it is missing."""
+    """Load libttm.so.  A missing or out-of-date library is (re)built in-tree with hipcc first; if that is
+    impossible the call raises - there is no fallback implementation."""
     global _lib
     if _lib is None:
         path = library_path()
-        if not os.path.exists(path):
-            raise RuntimeError('libttm.so is not built (%s); run `python -c "import __graft_entry__ as g; g.build()"` '
-                               'or `python -m triangular_transport_toolbox_amd.build`' % path)
+        if _build.is_stale():
+            try:
+                _build.build_lib()
+            except Exception as exc:          # no hipcc / compile error
+                if not os.path.exists(path):
+                    raise RuntimeError('libttm.so is not built (%s) and could not be built: %s' % (path, exc))
         # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It has to be
         # loaded first so that libttm.so binds to that one runtime: two runtimes in a process
         # cannot share streams / allocations (and the second one finds no GPU).

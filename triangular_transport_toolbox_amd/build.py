@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libttm.so')
 SOURCES = ['ttm_kernels.hip']
-HEADERS = ['ttm_eval.h', os.path.join('..', '..', 'include', 'ttm.h')]
+HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', os.path.join('..', '..', 'include', 'ttm.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
          '-DNDEBUG']
 
@@ -31,12 +31,16 @@ def build_lib(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -shared ... -> triangular_transport_toolbox_amd/libttm.so"""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + ['-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = '%s.tmp.%d' % (LIB, os.getpid())        # atomic replace: several ranks may build at the same time
+    cmd = [hipcc_path()] + FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+    os.replace(tmp, LIB)
     return LIB
 
 

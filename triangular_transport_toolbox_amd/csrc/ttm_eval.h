@@ -643,25 +643,44 @@ TTM_HD FastComp make_fast(cint_p fd, cint_p fints, cdbl_p fold_all, int fold_bas
 template <class R, class XA>
 TTM_HD R nonmon_sum_fast(const FastComp& f, const Prog& p, VarCache<XA, R>& x) {
     R s(f.fold[0]);
-    // software-pipelined over the groups: record g+1 is loaded while group g is evaluated
-    int var = 0, P = 0, has_hf = 0, aoff = 0;
-    if (f.n_grp > 0) { var = f.gi[0]; P = f.gi[1]; aoff = f.gi[2]; has_hf = f.gi[3]; }
+    if (f.n_grp == 0) return s;
+    // software-pipelined over the groups: while group g is evaluated, the record of group g+1 has been
+    // loaded and its column (and exp(-x^2/4)) fetched from the per-thread cache - independent work that
+    // fills the latency of the current group's dependent FMA chain
+    int var = f.gi[0], P = f.gi[1], aoff = f.gi[2], has_hf = f.gi[3];
+    R xv, e(0.0);
+    if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
     for (int g = 0; g < f.n_grp; ++g) {
-        const int cvar = var, cP = P, chf = has_hf;
+        const int cP = P, chf = has_hf;
         cdbl_p al = f.fold + aoff;
         cdbl_p be = al + cP;
-        if (g + 1 < f.n_grp) { cint_p G = f.gi + 4 * (g + 1); var = G[0]; P = G[1]; aoff = G[2]; has_hf = G[3]; }
-        R xv, e(0.0);
-        if (chf) x.get_e(cvar, xv, e); else xv = x.get(cvar);
+        const R cx = xv, ce = e;
+        if (g + 1 < f.n_grp) {
+            cint_p G = f.gi + 4 * (g + 1);
+            var = G[0]; P = G[1]; aoff = G[2]; has_hf = G[3];
+            if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+        }
         R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
-        poly_first(p.family, xv, pn, dp);
-        for (int n = 1; n <= cP; ++n) {
-            accp = vfma(al[n - 1], pn, accp);
-            if (chf) acch = vfma(be[n - 1], pn, acch);
-            if (n < cP) poly_next<false>(p.family, n, xv, pm, pn, dpm, dp);
+        poly_first(p.family, cx, pn, dp);
+        // coefficients in chunks of four: the scalar loads of a chunk are independent of the recurrence
+        for (int n0 = 0; n0 < cP; n0 += 4) {
+            const double a0 = al[n0], a1 = al[n0 + 1], a2 = al[n0 + 2], a3 = al[n0 + 3];   // (fold is padded)
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+            if (chf) { b0 = be[n0]; b1 = be[n0 + 1]; b2 = be[n0 + 2]; b3 = be[n0 + 3]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + j + 1;
+                if (n <= cP) {
+                    const double aj = j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3));
+                    const double bj = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
+                    accp = vfma(aj, pn, accp);
+                    if (chf) acch = vfma(bj, pn, acch);
+                    if (n < cP) poly_next<false>(p.family, n, cx, pm, pn, dpm, dp);
+                }
+            }
         }
         s = s + accp;
-        if (chf) s = vfma(e, acch, s);
+        if (chf) s = vfma(ce, acch, s);
     }
     return s;
 }

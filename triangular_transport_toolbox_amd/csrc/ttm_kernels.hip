@@ -857,7 +857,7 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     return check_launch("k_select");
 }
 
-int64_t ttm_fold_size(const ttm_program* p) { return (p && p->h_fold_off) ? p->h_fold_off[p->D] : -1; }
+int64_t ttm_fold_size(const ttm_program* p) { return (p && p->h_fold_off) ? p->h_fold_off[p->D] + 8 : -1; }   // + read-ahead padding
 
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream) {
     int rc = validate(p, 0, p ? p->D : 0);

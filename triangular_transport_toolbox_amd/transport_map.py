@@ -402,7 +402,7 @@ class transport_map():
             parts += [cn, cm]
         coef = self._to_dev(np.concatenate(parts))
         # folded coefficients (device pre-pass, include/ttm.h "Folded coefficients"); kept with the vector
-        fold = self._empty(max(int(self._cm.fold_off[-1]), 1))
+        fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
         _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
         coef._ttm_fold = fold
         return coef
