@@ -126,7 +126,7 @@ extern "C" {
 #define TTM_ST_NPAR       5   /* dpar doubles per special term                                 */
 /* fast-path descriptor of a component (components whose terms are all univariate: no table walking,
  * every record is at a known offset so the scalar loads can be issued ahead of use) */
-#define TTM_FDESC_LEN    12
+#define TTM_FDESC_LEN    16
 #define TTM_FD_KC         0
 #define TTM_FD_N_GRP      1
 #define TTM_FD_N_ST       2
@@ -140,13 +140,35 @@ extern "C" {
                                  1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}     */
 #define TTM_FD_NB         9
 #define TTM_FD_OFF_WB    10
+#define TTM_FD_ST8       11   /* offset (within the component's fold) of the unified special-term section written
+                                 by the second stage of ttm_fold: 8 doubles {g0 = w_none + sum A0, 7 pad}, then
+                                 one 8-double record per special term {centre, 1/(sqrt2 scale), A1, B0, B1, G,
+                                 DG, DT}: value += A1 erf + d (B0 + B1 erf) + G gauss, d/dx += (B0 + B1 erf) +
+                                 (DG + DT t) gauss with d = x - centre, t = d/(sqrt2 scale), gauss = exp(-t^2);
+                                 records that need the Gaussian for their VALUE (LET/RET/RBF) come first    */
+#define TTM_FD_N_STA     12   /* how many of the N_ST records need the Gaussian for the value            */
+#define TTM_FD_KC_SLOT   13   /* planned column cache: slot that keeps x_kc for later components (-1: none) */
+#define TTM_FD_PLAN_OFF  14   /* offset into fints of the TTM_PLAN_WAYS entry-state words of the planned
+                                 cache (what the cache holds when a sweep reaches this component: column |
+                                 TTM_PLAN_E if exp(-x^2/4) is held too; -1: slot empty)                   */
+/* planned column cache (fast kernels): the access sequence of a sweep over the components is static, so
+ * hit / miss / replacement (Belady) decisions are made when the program is compiled; a group record's
+ * flag word says where its column lives */
+#define TTM_PLAN_WAYS     4
+#define TTM_PLAN_HF       1   /* group has Hermite-function terms (needs exp(-x^2/4))           */
+#define TTM_PLAN_XHIT     2   /* column value is in the slot                                   */
+#define TTM_PLAN_EHIT     4   /* exp(-x^2/4) is in the slot too                                */
+#define TTM_PLAN_SLOT(f) (((f) >> 8) & 255)     /* 255: bypass (do not keep)                   */
+#define TTM_PLAN_E       (1 << 30)
 
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
     const int32_t* ftab;        /* fold recipes of all components, back to back    */
     const int32_t* fdesc;       /* fast-path descriptors, TTM_FDESC_LEN int32 per component */
-    const int32_t* fints;       /* fast-path int stream (groups {var,P,alpha offset,has_hf}, special-term kinds) */
+    const int32_t* fints;       /* fast-path int stream per component: groups {var, P, alpha offset, TTM_PLAN_* flags},
+                                   special-term kinds (bfun order), order of the unified records (indices into
+                                   the bfun order), planned-cache entry state                              */
     const double*  dpar;        /* HF constants and special-term (centre, scale)   */
     const double*  quad_x;      /* Gauss-Legendre nodes   (TM:199-225), length Q   */
     const double*  quad_w;      /* Gauss-Legendre weights,               length Q   */
@@ -160,6 +182,7 @@ typedef struct ttm_program {
     const int32_t* h_fold_off;  /* length D+1: prefix offsets of folded coefficients */
     const int32_t* h_ftab_off;  /* length D+1: prefix offsets into ftab              */
     const int32_t* h_nb1;       /* length D: nB+1 (distinct x_k functions + 1)      */
+    const int32_t* h_complex;   /* length D: 1 = component needs the generic interpreter (cross / generic terms) */
     /* device copy of the five prefix tables, 5 x (D+1) int32:
        [comp_off | dpar_off | coef_off | fold_off | ftab_off]                        */
     const int32_t* d_offsets;

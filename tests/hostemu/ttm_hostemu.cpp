@@ -68,6 +68,35 @@ void comp_of(const ttm_program* p, int k, const double* coef_k, HostComp& h, con
     h.c = make_comp(cb, dp, coef_k, fold_k);
 }
 
+// same dispatch rule as the library: planned-cache fast path when every component of the range is simple
+bool all_fast(const ttm_program* p, int ka, int kb) {
+    if (getenv("TTM_NO_PLAN")) return false;
+    for (int k = ka; k < kb; ++k)
+        if (p->h_complex[k]) return false;
+    return true;
+}
+
+template <int FAM, class R, class XA>
+void forward_plan(const ttm_program* p, const Prog& g, const double* fold, const XA& xa, int k0, int k1, bool want_ld,
+                  bool want_val, R* S_out, R& ld, R& ss, const double* sigma) {
+    double cbuf[8 * lanes_of<R>::value];
+    PlanCache<XA, R> x(xa, CacheStore<R>{cbuf, 1});
+    if (k0 > 0) x.warm(p->fints + p->fdesc[k0 * TTM_FDESC_LEN + TTM_FD_PLAN_OFF]);
+    ld = R(0.0); ss = R(0.0);
+    for (int k = k0; k < k1; ++k) {
+        const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+        const FastComp f = make_fast(fd, p->fints, fold, 0);
+        const R xk = xa(fd[TTM_FD_KC]);
+        R S, dS;
+        if (want_ld) sample_forward_fast<-1, FAM, true>(f, g, xk, x, want_val, S, dS);
+        else sample_forward_fast<-1, FAM, false>(f, g, xk, x, true, S, dS);
+        x.put(fd[TTM_FD_KC_SLOT], xk);
+        if (want_ld) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
+        S_out[k - k0] = S;
+        ss = vfma(S, S, ss);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,12 +157,28 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
     for (int k = 0; k < p->D; ++k)
         fold_coeffs(p->itab + p->h_comp_off[k], p->ftab + p->h_ftab_off[k], p->dpar + p->h_dpar_off[k],
                     coef + p->h_coef_off[k], fold + p->h_fold_off[k], 0, 1);
+    for (int k = 0; k < p->D; ++k) fold_st8(p->fdesc + k * TTM_FDESC_LEN, p->fints, fold + p->h_fold_off[k], 0, 1);
     return 0;
 }
 
 int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
                 int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void*) {
     const Prog g = make_prog(p);
+    if (all_fast(p, k0, k1)) {
+        std::vector<double> S(k1 - k0);
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+            double ld, ss;
+            if (p->family == TTM_FAM_HERMITE_E)
+                forward_plan<TTM_FAM_HERMITE_E, double>(p, g, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma);
+            else
+                forward_plan<-1, double>(p, g, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma);
+            if (Z) for (int k = k0; k < k1; ++k) Z[(int64_t)(k - k0) * ldz + n] = S[k - k0];
+            if (logdet) logdet[n] = ld;
+            if (sumsq) sumsq[n] = ss;
+        }
+        return 0;
+    }
     std::vector<double> scr(4096);
     std::vector<HostComp> hc(k1 - k0);
     for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
@@ -148,8 +193,10 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             const int* fd = p->fdesc + k * TTM_FDESC_LEN;
             if (!fd[TTM_FD_COMPLEX]) {          // same dispatch as the kernel: flat-stream fast path
                 const FastComp f = make_fast(fd, p->fints, fold, 0);
-                if (logdet) sample_forward_fast<-1, true>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, Z || sumsq, S, dS);
-                else sample_forward_fast<-1, false>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
+                TaggedFetch<XSoA, double> xf{x};
+                const double xk = x.get(f.kc);
+                if (logdet) sample_forward_fast<-1, -1, true>(f, g, xk, xf, Z || sumsq, S, dS);
+                else sample_forward_fast<-1, -1, false>(f, g, xk, xf, true, S, dS);
             } else if (logdet) {
                 sample_forward<-1, true>(c, g, x, w, Z || sumsq, S, dS);
             } else {
@@ -180,6 +227,25 @@ struct XSoA2 {
 int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
                      int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet) {
     const Prog g = make_prog(p);
+    if (all_fast(p, k0, k1)) {
+        std::vector<VecD<2>> S(k1 - k0);
+        for (int64_t n = 0; n < N; n += 2) {
+            const int64_t n1 = n + 1 < N ? n + 1 : n;
+            XSoA2 xa{X, ldx, n, n1};
+            VecD<2> ld, ss;
+            if (p->family == TTM_FAM_HERMITE_E)
+                forward_plan<TTM_FAM_HERMITE_E, VecD<2>>(p, g, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
+            else
+                forward_plan<-1, VecD<2>>(p, g, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
+            for (int k = k0; k < k1; ++k) {
+                Z[(int64_t)(k - k0) * ldz + n] = S[k - k0].v[0];
+                Z[(int64_t)(k - k0) * ldz + n1] = S[k - k0].v[1];
+            }
+            logdet[n] = ld.v[0];
+            logdet[n1] = ld.v[1];
+        }
+        return 0;
+    }
     std::vector<double> scr(8192);
     std::vector<HostComp> hc(k1 - k0);
     for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
@@ -194,9 +260,11 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
             VecSlots2 w{scr.data()};
             VecD<2> S, dS;
             const int* fd = p->fdesc + k * TTM_FDESC_LEN;
-            if (!fd[TTM_FD_COMPLEX])
-                sample_forward_fast<-1, true>(make_fast(fd, p->fints, fold, 0), g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
-            else
+            if (!fd[TTM_FD_COMPLEX]) {
+                TaggedFetch<XSoA2, VecD<2>> xf{x};
+                const FastComp f = make_fast(fd, p->fints, fold, 0);
+                sample_forward_fast<-1, -1, true>(f, g, x.get(f.kc), xf, true, S, dS);
+            } else
                 sample_forward<-1, true>(c, g, x, w, true, S, dS);
             ld += fast_log(dS);
             Z[(int64_t)(k - k0) * ldz + n] = S.v[0];
@@ -308,6 +376,29 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                       int32_t truncate, void*) {
     (void)bkt; (void)nb; (void)h_y_affine;   // the host double does the full search; the accelerated search must give the same index
     const Prog g = make_prog(p);
+    if (all_fast(p, k0, k1)) {               // planned column cache, one sample at a time through all components
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+            double cbuf[8];
+            PlanCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
+            if (k0 > 0) x.warm(p->fints + p->fdesc[k0 * TTM_FDESC_LEN + TTM_FD_PLAN_OFF]);
+            for (int k = k0; k < k1; ++k) {
+                const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+                const FastComp f = make_fast(fd, p->fints, fold, 0);
+                const double off = p->family == TTM_FAM_HERMITE_E ? nonmon_sum_fast<TTM_FAM_HERMITE_E, double>(f, g, x)
+                                                                  : nonmon_sum_fast<-1, double>(f, g, x);
+                double target = -off + Z[(int64_t)(k - k0) * ldz + n];
+                if (truncate) {
+                    if (target < tmin[k - k0]) target = tmin[k - k0];
+                    if (target > tmax[k - k0]) target = tmax[k - k0];
+                }
+                const double r = table_lookup(tab_x + (int64_t)(k - k0) * T, tab_y + (int64_t)(k - k0) * ldy, T, target);
+                X[(int64_t)fd[TTM_FD_KC] * ldx + n] = r;
+                x.put(fd[TTM_FD_KC_SLOT], r);
+            }
+        }
+        return 0;
+    }
     for (int k = k0; k < k1; ++k) {
         HostComp h;
         comp_of(p, k, coef + p->h_coef_off[k], h, fold + p->h_fold_off[k]);
@@ -318,7 +409,8 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
             XSoA xa{X, ldx, n};
             double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
             const int* fd = p->fdesc + k * TTM_FDESC_LEN;
-            const double off = !fd[TTM_FD_COMPLEX] ? nonmon_sum_fast<double>(make_fast(fd, p->fints, fold, 0), g, x)
+            TaggedFetch<XSoA, double> xf{x};
+            const double off = !fd[TTM_FD_COMPLEX] ? nonmon_sum_fast<-1, double>(make_fast(fd, p->fints, fold, 0), g, xf)
                                                    : nonmon_sum<double>(c, g, x);
             double target = -off + Z[(int64_t)(k - k0) * ldz + n];
             if (truncate) {

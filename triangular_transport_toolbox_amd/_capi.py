@@ -18,7 +18,7 @@ c_i32, c_i64, c_dbl, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, cty
 class ttm_program(ctypes.Structure):
     """Mirror of `struct ttm_program` (include/ttm.h)."""
     _fields_ = [('itab', c_vp), ('ftab', c_vp), ('fdesc', c_vp), ('fints', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
-                ('h_comp_off', c_vp), ('h_dpar_off', c_vp), ('h_coef_off', c_vp), ('h_nslots', c_vp), ('h_n_nm', c_vp), ('h_fold_off', c_vp), ('h_ftab_off', c_vp), ('h_nb1', c_vp), ('d_offsets', c_vp),
+                ('h_comp_off', c_vp), ('h_dpar_off', c_vp), ('h_coef_off', c_vp), ('h_nslots', c_vp), ('h_n_nm', c_vp), ('h_fold_off', c_vp), ('h_ftab_off', c_vp), ('h_nb1', c_vp), ('h_complex', c_vp), ('d_offsets', c_vp),
                 ('D', c_i32), ('d_cols', c_i32), ('family', c_i32), ('monotonicity', c_i32), ('rectifier', c_i32),
                 ('Q', c_i32), ('delta', c_dbl)]
 
@@ -117,10 +117,10 @@ def make_program(cm, itab_ptr, ftab_ptr, fdesc_ptr, fints_ptr, dpar_ptr, qx_ptr,
     returned object keeps the host offset arrays alive."""
     p = ttm_program()
     p._keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (cm.comp_off, cm.dpar_off, cm.coef_off, cm.nslots, cm.n_nm, cm.fold_off, cm.ftab_off,
-                                                                 cm.nb1)]
+                                                                 cm.nb1, cm.complex)]
     p.itab, p.ftab, p.fdesc, p.fints = itab_ptr, ftab_ptr, fdesc_ptr, fints_ptr
     p.dpar, p.quad_x, p.quad_w = dpar_ptr, qx_ptr, qw_ptr
-    (p.h_comp_off, p.h_dpar_off, p.h_coef_off, p.h_nslots, p.h_n_nm, p.h_fold_off, p.h_ftab_off, p.h_nb1) = \
+    (p.h_comp_off, p.h_dpar_off, p.h_coef_off, p.h_nslots, p.h_n_nm, p.h_fold_off, p.h_ftab_off, p.h_nb1, p.h_complex) = \
         [a.ctypes.data for a in p._keep]
     p.d_offsets = offsets_ptr
     p.D, p.d_cols, p.family = int(cm.D), int(cm.d_cols), int(cm.family)

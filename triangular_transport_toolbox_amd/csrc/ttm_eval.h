@@ -132,6 +132,35 @@ TTM_HD void fold_coeffs(const int* cb, const int* fb, const double* dpar, const 
     }
 }
 
+// second stage of the fold (after every slot of fold_coeffs is written): the unified special-term section
+// of the fast path, TTM_FD_ST8.  fd = the component's fast-path descriptor, fold = its folded array.
+TTM_HD void fold_st8(const int* fd, const int* fints, double* fold, int first, int stride) {
+    const int n_st = fd[TTM_FD_N_ST];
+    const int* kinds = fints + fd[TTM_FD_FINT_OFF] + 4 * fd[TTM_FD_N_GRP];
+    const int* order = kinds + n_st;
+    const double* rec5 = fold + fd[TTM_FD_STREAM] + fd[TTM_FD_MAXP_HF] + fd[TTM_FD_MAXP_POLY];
+    double* out = fold + fd[TTM_FD_ST8];
+    for (int s = first; s < n_st; s += stride) {
+        const int src = order[s], kind = kinds[src];
+        const double w = rec5[5 * src], mu = rec5[5 * src + 1], inv = rec5[5 * src + 2], k1 = rec5[5 * src + 3],
+                     k2 = rec5[5 * src + 4];
+        double A1 = 0.0, B0 = 0.0, B1 = 0.0, G = 0.0, DG = 0.0, DT = 0.0;
+        if (kind == TTM_KIND_LET) { B0 = 0.5 * w; B1 = -0.5 * w; G = -(w * (0.5 * k1)); }
+        else if (kind == TTM_KIND_RET) { B0 = 0.5 * w; B1 = 0.5 * w; G = w * (0.5 * k1); }
+        else if (kind == TTM_KIND_RBF) { G = w * k2; DT = (-2.0 * inv) * (w * k2); }
+        else { A1 = 0.5 * w; DG = w * k2; }
+        double* r = out + 8 + 8 * s;
+        r[0] = mu; r[1] = inv; r[2] = A1; r[3] = B0; r[4] = B1; r[5] = G; r[6] = DG; r[7] = DT;
+    }
+    if (first == 0) {
+        double g0 = fold[fd[TTM_FD_OFF_WB] + fd[TTM_FD_NB]];
+        for (int s = 0; s < n_st; ++s)
+            if (kinds[s] == TTM_KIND_IRBF) g0 += 0.5 * rec5[5 * s];
+        out[0] = g0;
+        for (int j = 1; j < 8; ++j) out[j] = 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // polynomial families: three-term recurrences with derivative propagation
 //   P_{n+1} = (a x + b) P_n - c P_{n-1}
@@ -621,10 +650,11 @@ TTM_HD void sample_objective_sep(const Comp& c, const Prog& p, VarCache<XA, doub
 // ---------------------------------------------------------------------------
 
 struct FastComp {
-    cint_p gi;        // groups {var, P, alpha offset, has_hf}, then the special-term kinds
+    cint_p gi;        // groups {var, P, alpha offset, TTM_PLAN_* flags}, then the special-term kinds
     cdbl_p fold;      // the component's folded coefficients
-    cdbl_p stream;    // wHF | wPoly | special-term records
-    int kc, n_grp, n_st, maxP_hf, maxP_poly;
+    cdbl_p stream;    // wHF | wPoly | special-term records (5 doubles, fold stage 1)
+    cdbl_p st8;       // unified special-term section (fold stage 2)
+    int kc, n_grp, n_st, n_stA, maxP_hf, maxP_poly;
 };
 
 TTM_HD FastComp make_fast(cint_p fd, cint_p fints, cdbl_p fold_all, int fold_base) {
@@ -632,73 +662,176 @@ TTM_HD FastComp make_fast(cint_p fd, cint_p fints, cdbl_p fold_all, int fold_bas
     f.kc = fd[TTM_FD_KC];
     f.n_grp = fd[TTM_FD_N_GRP];
     f.n_st = fd[TTM_FD_N_ST];
+    f.n_stA = fd[TTM_FD_N_STA];
     f.maxP_hf = fd[TTM_FD_MAXP_HF];
     f.maxP_poly = fd[TTM_FD_MAXP_POLY];
     f.gi = fints + fd[TTM_FD_FINT_OFF];
     f.fold = fold_all + (fd[TTM_FD_FOLD_OFF] - fold_base);
     f.stream = f.fold + fd[TTM_FD_STREAM];
+    f.st8 = f.fold + fd[TTM_FD_ST8];
     return f;
 }
 
-template <class R, class XA>
-TTM_HD R nonmon_sum_fast(const FastComp& f, const Prog& p, VarCache<XA, R>& x) {
+// run-time tagged cache (VarCache) behind the interface the group evaluator wants
+template <class XA, class R>
+struct TaggedFetch {
+    VarCache<XA, R>& c;
+    TTM_HD void fetch(int var, int fl, R& x, R& e) {
+        if (fl & TTM_PLAN_HF) c.get_e(var, x, e); else x = c.get(var);
+    }
+};
+
+// statically planned cache (termtable.py:_plan_column_cache): the flag word of the group record says where
+// the column lives, no tag compares.  Slots 0..3 hold columns, 4..7 their exp(-x^2/4).
+template <class XA, class R>
+struct PlanCache {
+    const XA& xa;
+    CacheStore<R> st;
+    TTM_HD PlanCache(const XA& x, const CacheStore<R>& store) : xa(x), st(store) {}
+    // contents on entry to a component (state words: column | TTM_PLAN_E, -1 = empty)
+    TTM_HD void warm(cint_p state) {
+        for (int w = 0; w < TTM_PLAN_WAYS; ++w) {
+            const int v = state[w];
+            if (v >= 0) {
+                const R x = xa(v & ~TTM_PLAN_E);
+                st.set(w, x);
+                if (v & TTM_PLAN_E) st.set(TTM_PLAN_WAYS + w, fast_exp(-0.25 * (x * x)));
+            }
+        }
+    }
+    TTM_HD void put(int slot, const R& x) { if (slot >= 0) st.set(slot, x); }
+    TTM_HD void fetch(int var, int fl, R& x, R& e) {
+        const int slot = TTM_PLAN_SLOT(fl);
+        if (fl & TTM_PLAN_XHIT) {
+            x = st.get(slot);
+        } else {
+            x = xa(var);
+            if (slot != 255) st.set(slot, x);
+        }
+        if (fl & TTM_PLAN_HF) {
+            if (fl & TTM_PLAN_EHIT) {
+                e = st.get(TTM_PLAN_WAYS + slot);
+            } else {
+                e = fast_exp(-0.25 * (x * x));
+                if (slot != 255) st.set(TTM_PLAN_WAYS + slot, e);
+            }
+        }
+    }
+};
+
+// sum_n alpha_n P_n(x) + e * sum_n beta_n P_n(x) for a group of PN orders, straight-line
+// (FAM >= 0: polynomial family known at compile time)
+template <int FAM, int PN, bool HF, class R>
+TTM_HD void group_fixed(int fam, cdbl_p al, const R& x, const R& e, R& s) {
+    const int F = (FAM >= 0) ? FAM : fam;
+    double a[PN], b[PN];
+#pragma unroll
+    for (int j = 0; j < PN; ++j) { a[j] = al[j]; b[j] = HF ? al[PN + j] : 0.0; }
+    R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
+    poly_first(F, x, pn, dp);
+#pragma unroll
+    for (int n = 1; n <= PN; ++n) {
+        accp = vfma(a[n - 1], pn, accp);
+        if (HF) acch = vfma(b[n - 1], pn, acch);
+        if (n < PN) poly_next<false>(F, n, x, pm, pn, dpm, dp);
+    }
+    s = s + accp;
+    if (HF) s = vfma(e, acch, s);
+}
+
+// nonmonotone part of a fast-path component: constant + univariate groups
+template <int FAM, class R, class Fetch>
+TTM_HD R nonmon_sum_fast(const FastComp& f, const Prog& p, Fetch& x) {
     R s(f.fold[0]);
     if (f.n_grp == 0) return s;
     // software-pipelined over the groups: while group g is evaluated, the record of group g+1 has been
     // loaded and its column (and exp(-x^2/4)) fetched from the per-thread cache - independent work that
     // fills the latency of the current group's dependent FMA chain
-    int var = f.gi[0], P = f.gi[1], aoff = f.gi[2], has_hf = f.gi[3];
+    int var = f.gi[0], P = f.gi[1], aoff = f.gi[2], fl = f.gi[3];
     R xv, e(0.0);
-    if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+    x.fetch(var, fl, xv, e);
     for (int g = 0; g < f.n_grp; ++g) {
-        const int cP = P, chf = has_hf;
+        const int cP = P, chf = fl & TTM_PLAN_HF;
         cdbl_p al = f.fold + aoff;
-        cdbl_p be = al + cP;
         const R cx = xv, ce = e;
         if (g + 1 < f.n_grp) {
             cint_p G = f.gi + 4 * (g + 1);
-            var = G[0]; P = G[1]; aoff = G[2]; has_hf = G[3];
-            if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+            var = G[0]; P = G[1]; aoff = G[2]; fl = G[3];
+            x.fetch(var, fl, xv, e);
         }
-        R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
-        poly_first(p.family, cx, pn, dp);
-        // coefficients in chunks of four: the scalar loads of a chunk are independent of the recurrence
-        for (int n0 = 0; n0 < cP; n0 += 4) {
-            const double a0 = al[n0], a1 = al[n0 + 1], a2 = al[n0 + 2], a3 = al[n0 + 3];   // (fold is padded)
-            double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-            if (chf) { b0 = be[n0]; b1 = be[n0 + 1]; b2 = be[n0 + 2]; b3 = be[n0 + 3]; }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + j + 1;
-                if (n <= cP) {
-                    const double aj = j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3));
-                    const double bj = j == 0 ? b0 : (j == 1 ? b1 : (j == 2 ? b2 : b3));
-                    accp = vfma(aj, pn, accp);
-                    if (chf) acch = vfma(bj, pn, acch);
-                    if (n < cP) poly_next<false>(p.family, n, cx, pm, pn, dpm, dp);
+        switch (cP + (chf ? 8 : 0)) {
+            case 1: group_fixed<FAM, 1, false>(p.family, al, cx, ce, s); break;
+            case 2: group_fixed<FAM, 2, false>(p.family, al, cx, ce, s); break;
+            case 3: group_fixed<FAM, 3, false>(p.family, al, cx, ce, s); break;
+            case 4: group_fixed<FAM, 4, false>(p.family, al, cx, ce, s); break;
+            case 9: group_fixed<FAM, 1, true>(p.family, al, cx, ce, s); break;
+            case 10: group_fixed<FAM, 2, true>(p.family, al, cx, ce, s); break;
+            case 11: group_fixed<FAM, 3, true>(p.family, al, cx, ce, s); break;
+            case 12: group_fixed<FAM, 4, true>(p.family, al, cx, ce, s); break;
+            default: {
+                const int F = (FAM >= 0) ? FAM : p.family;
+                cdbl_p be = al + cP;
+                R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
+                poly_first(F, cx, pn, dp);
+                for (int n = 1; n <= cP; ++n) {
+                    accp = vfma(al[n - 1], pn, accp);
+                    if (chf) acch = vfma(be[n - 1], pn, acch);
+                    if (n < cP) poly_next<false>(F, n, cx, pm, pn, dpm, dp);
                 }
+                s = s + accp;
+                if (chf) s = vfma(ce, acch, s);
             }
         }
-        s = s + accp;
-        if (chf) s = vfma(ce, acch, s);
     }
     return s;
 }
 
+// unified special-term records {centre, 1/(sqrt2 scale), A1, B0, B1, G, DG, DT} (TTM_FD_ST8):
+// branch-free; the next record is loaded while the current one is evaluated (the folded array is padded
+// by one record, so the read-ahead of the last iteration stays inside the allocation).
+// EDGE: records of LET / RET / RBF (value needs the Gaussian); otherwise iRBF records (A1, DG only).
+template <bool EDGE, bool DER, class R>
+TTM_HD void st8_accumulate(const Prog& p, cdbl_p rec, int n, const R& t, R& acc, R& dacc) {
+    if (n <= 0) return;
+    double mu = rec[0], inv = rec[1], A1 = rec[2], B0 = rec[3], B1 = rec[4], G = rec[5], DG = rec[6], DT = rec[7];
+    for (int s = 0; s < n; ++s) {
+        const double cmu = mu, cinv = inv, cA1 = A1, cB0 = B0, cB1 = B1, cG = G, cDG = DG, cDT = DT;
+        cdbl_p nx = rec + 8 * (s + 1);
+        mu = nx[0]; inv = nx[1]; A1 = nx[2]; B0 = nx[3]; B1 = nx[4]; G = nx[5]; DG = nx[6]; DT = nx[7];
+        const R d = t - cmu;
+        const R tt = d * cinv;
+        R e, gs;
+        erf_gauss_tab<(EDGE || DER)>(p.erf_tab, tt, e, gs);
+        if (EDGE) {
+            const R h = vfma(e, cB1, cB0);
+            acc = vfma(d, h, acc);
+            acc = vfma(cG, gs, acc);
+            if (DER) {
+                dacc = dacc + h;
+                dacc = vfma(vfma(tt, cDT, cDG), gs, dacc);
+            }
+        } else {
+            acc = vfma(cA1, e, acc);
+            if (DER) dacc = vfma(cDG, gs, dacc);
+        }
+    }
+}
+
 // g(t) = w_none + sum_n wHF[n] P_n(t) e^{-t^2/4} + sum_n wPoly[n] P_n(t) + sum_s w_s ST_s(t), and dg/dt
-template <bool DER, class R>
-TTM_HD void g_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, const R& t, R& g, R& dg) {
-    R acc(f.fold[off_wb + nB]), dacc(0.0);
+template <int FAM, bool DER, class R>
+TTM_HD void g_eval_fast(const FastComp& f, const Prog& p, const R& t, R& g, R& dg) {
+    const int F = (FAM >= 0) ? FAM : p.family;
+    R acc(f.st8[0]), dacc(0.0);
     cdbl_p w = f.stream;
     if (f.maxP_hf > 0) {
         const R E = fast_exp(-0.25 * (t * t));
         R pm(1.0), dpm(0.0), pn, dp, a(0.0), da(0.0);
-        poly_first(p.family, t, pn, dp);
+        poly_first(F, t, pn, dp);
         for (int n = 1; n <= f.maxP_hf; ++n) {
             const double wn = w[n - 1];                      // a_n already folded in
             a = vfma(wn, pn, a);
             if (DER) da = vfma(wn, dp, da);
-            if (n < f.maxP_hf) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
+            if (n < f.maxP_hf) poly_next<DER>(F, n, t, pm, pn, dpm, dp);
         }
         acc = vfma(a, E, acc);
         if (DER) dacc = vfma(E, da - 0.5 * (t * a), dacc);   // d/dt [P e^{-t^2/4}] = e^{-t^2/4} (P' - t P / 2)
@@ -706,64 +839,31 @@ TTM_HD void g_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, co
     }
     if (f.maxP_poly > 0) {
         R pm(1.0), dpm(0.0), pn, dp;
-        poly_first(p.family, t, pn, dp);
+        poly_first(F, t, pn, dp);
         for (int n = 1; n <= f.maxP_poly; ++n) {
             const double wn = w[n - 1];
             acc = vfma(wn, pn, acc);
             if (DER) dacc = vfma(wn, dp, dacc);
-            if (n < f.maxP_poly) poly_next<DER>(p.family, n, t, pm, pn, dpm, dp);
-        }
-        w += f.maxP_poly;
-    }
-    // special terms: record s+1 {w, centre, 1/(sqrt2 scale), k1, k2} is loaded while s is evaluated
-    cint_p kinds = f.gi + 4 * f.n_grp;
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, r4 = 0.0;
-    int kind = 0;
-    if (f.n_st > 0) { r0 = w[0]; r1 = w[1]; r2 = w[2]; r3 = w[3]; r4 = w[4]; kind = kinds[0]; }
-    for (int s = 0; s < f.n_st; ++s) {
-        const double ws = r0, mu = r1, inv = r2, k1 = r3, k2 = r4;
-        const int ck = kind;
-        if (s + 1 < f.n_st) {
-            cdbl_p nx = w + 5 * (s + 1);
-            r0 = nx[0]; r1 = nx[1]; r2 = nx[2]; r3 = nx[3]; r4 = nx[4];
-            kind = kinds[s + 1];
-        }
-        const R d = t - mu;
-        const R tt = d * inv;
-        R e, gs;
-        if (ck == TTM_KIND_LET || ck == TTM_KIND_RET) {
-            erf_gauss_tab<true>(p.erf_tab, tt, e, gs);
-            const R h = (ck == TTM_KIND_LET) ? vfma(e, -0.5, 0.5) : vfma(e, 0.5, 0.5);
-            const R gg = (0.5 * k1) * gs;
-            const R v = (ck == TTM_KIND_LET) ? vfma(d, h, -gg) : vfma(d, h, gg);
-            acc = vfma(ws, v, acc);
-            if (DER) dacc = vfma(ws, h, dacc);
-        } else if (ck == TTM_KIND_RBF) {
-            erf_gauss_tab<true>(p.erf_tab, tt, e, gs);
-            const R gg = gs * k2;
-            acc = vfma(ws, gg, acc);
-            if (DER) dacc = vfma(ws, (-2.0 * inv) * tt * gg, dacc);
-        } else {
-            if (DER) erf_gauss_tab<true>(p.erf_tab, tt, e, gs); else erf_gauss_tab<false>(p.erf_tab, tt, e, gs);
-            acc = vfma(ws, vfma(e, 0.5, 0.5), acc);
-            if (DER) dacc = vfma(ws, k2 * gs, dacc);
+            if (n < f.maxP_poly) poly_next<DER>(F, n, t, pm, pn, dpm, dp);
         }
     }
+    st8_accumulate<true, DER>(p, f.st8 + 8, f.n_stA, t, acc, dacc);
+    st8_accumulate<false, DER>(p, f.st8 + 8 + 8 * f.n_stA, f.n_st - f.n_stA, t, acc, dacc);
     g = acc; dg = dacc;
 }
 
-template <int MONO, bool DER, class R>
-TTM_HD void mon_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, const R& t, R& m, R& dm) {
+template <int MONO, int FAM, bool DER, class R>
+TTM_HD void mon_eval_fast(const FastComp& f, const Prog& p, const R& t, R& m, R& dm) {
     const int mono = (MONO >= 0) ? MONO : p.mono;
     if (mono == TTM_MONO_SEPARABLE) {
-        g_eval_fast<DER>(f, p, nB, off_wb, t, m, dm);
+        g_eval_fast<FAM, DER>(f, p, t, m, dm);
     } else {
         const R half = t * 0.5;
         R res(0.0);
         for (int q = 0; q < p.Q; ++q) {
             const R tq = half * p.qx[q] + half;
             R g, dg;
-            g_eval_fast<false>(f, p, nB, off_wb, tq, g, dg);
+            g_eval_fast<FAM, false>(f, p, tq, g, dg);
             const R fr = rect_eval(p.rect, g) + p.delta;
             const R term = half * (p.qw[q] * fr);
             res = (q == 0) ? term : res + term;
@@ -772,19 +872,18 @@ TTM_HD void mon_eval_fast(const FastComp& f, const Prog& p, int nB, int off_wb, 
         dm = R(0.0);
         if (DER) {
             R g, dg;
-            g_eval_fast<false>(f, p, nB, off_wb, t, g, dg);
+            g_eval_fast<FAM, false>(f, p, t, g, dg);
             dm = rect_eval(p.rect, g) + p.delta;
         }
     }
 }
 
-template <int MONO, bool DER, class R, class XA>
-TTM_HD void sample_forward_fast(const FastComp& f, const Prog& p, int nB, int off_wb, VarCache<XA, R>& x, bool want_value,
-                                R& S, R& dS) {
+// S and dS/dx_k of a fast-path component; xk = this thread's x_kc, x = column cache (TaggedFetch / PlanCache)
+template <int MONO, int FAM, bool DER, class R, class Fetch>
+TTM_HD void sample_forward_fast(const FastComp& f, const Prog& p, const R& xk, Fetch& x, bool want_value, R& S, R& dS) {
     R m, dm;
-    const R xk = x.get(f.kc);
-    mon_eval_fast<MONO, DER>(f, p, nB, off_wb, xk, m, dm);
-    S = want_value ? nonmon_sum_fast<R>(f, p, x) + m : m;
+    mon_eval_fast<MONO, FAM, DER>(f, p, xk, m, dm);
+    S = want_value ? nonmon_sum_fast<FAM, R>(f, p, x) + m : m;
     dS = dm;
 }
 

@@ -182,6 +182,8 @@ __global__ __launch_bounds__(64) void k_fold(DevProg P, int kfirst, int kbase, c
     fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k],
                 coef + (off[2 * D1 + k] - off[2 * D1 + kbase]), fold + (off[3 * D1 + k] - off[3 * D1 + kbase]),
                 threadIdx.x, blockDim.x);
+    __syncthreads();
+    fold_st8(P.fdesc + k * TTM_FDESC_LEN, P.fints, fold + (off[3 * D1 + k] - off[3 * D1 + kbase]), threadIdx.x, blockDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -396,13 +398,74 @@ __global__ __launch_bounds__(256) void k_forward(DevProg P, int k0, int k1, cons
             if (!fd[TTM_FD_COMPLEX]) {
                 // all terms univariate: flat streams, records prefetched by scalar loads
                 const FastComp f = make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0);
-                if (WANT_LD) sample_forward_fast<MONO, true>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, want_val, S, dS);
-                else sample_forward_fast<MONO, false>(f, g, fd[TTM_FD_NB], fd[TTM_FD_OFF_WB], x, true, S, dS);
+                TaggedFetch<XSoAN<NS>, R> xf{x};
+                const R xk = x.get(f.kc);
+                if (WANT_LD) sample_forward_fast<MONO, -1, true>(f, g, xk, xf, want_val, S, dS);
+                else sample_forward_fast<MONO, -1, false>(f, g, xk, xf, true, S, dS);
             } else {
                 const Comp c = comp_at(P, k, 0, coef, fold);
                 if (WANT_LD) sample_forward<MONO, true>(c, g, x, w, want_val, S, dS);
                 else sample_forward<MONO, false>(c, g, x, w, true, S, dS);
             }
+            if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+            if (Z) {
+#pragma unroll
+                for (int e = 0; e < NS; ++e)
+                    if (act[e]) Z[(int64_t)(k - k0) * ldz + xa.n[e]] = elem(S, e);
+            }
+            ss = vfma(S, S, ss);
+        }
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            if (act[e]) {
+                if (WANT_LD) logdet[xa.n[e]] = elem(ld, e);
+                if (sumsq) sumsq[xa.n[e]] = elem(ss, e);
+            }
+        }
+    }
+}
+
+// Forward map of a range of components that all take the fast path (univariate terms only): no generic
+// interpreter in the kernel, the column cache is statically planned (PlanCache), the polynomial family is
+// a template parameter (FAM = -1: run-time), special terms come as unified branch-free records.
+template <int MONO, bool WANT_LD, int NS, int FAM>
+__global__ __launch_bounds__(256) void k_forward_plan(DevProg P, int k0, int k1, const double* __restrict__ fold,
+                                                      const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                      double* __restrict__ Z, int64_t ldz,
+                                                      double* __restrict__ logdet, const double* __restrict__ sigma,
+                                                      double* __restrict__ sumsq) {
+    typedef typename real_of<NS>::type R;
+    double* unused;
+    CacheStore<R> cst;
+    const Prog g = make_prog_lds(P, cst, unused);
+    const int bd = blockDim.x;
+    const bool want_val = (Z != nullptr) || (sumsq != nullptr);
+    cint_p fd0 = (cint_p)P.fdesc + k0 * TTM_FDESC_LEN;
+    for (int64_t tile = (int64_t)blockIdx.x * NS * bd; tile < N; tile += (int64_t)gridDim.x * NS * bd) {
+        XSoAN<NS> xa;
+        xa.X = X; xa.ld = ldx;
+        bool act[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            const int64_t n = tile + (int64_t)e * bd + threadIdx.x;
+            act[e] = n < N;
+            xa.n[e] = act[e] ? n : N - 1;
+        }
+        PlanCache<XSoAN<NS>, R> x(xa, cst);
+        if (k0 > 0) x.warm((cint_p)P.fints + fd0[TTM_FD_PLAN_OFF]);
+        R ld(0.0), ss(0.0);
+        // the component's own column is fetched one component ahead, so its HBM latency overlaps
+        // the arithmetic of the current component
+        R xk_next = xa(fd0[TTM_FD_KC]);
+        for (int k = k0; k < k1; ++k) {
+            cint_p fd = (cint_p)P.fdesc + k * TTM_FDESC_LEN;
+            const R xk = xk_next;
+            if (k + 1 < k1) xk_next = xa(fd[TTM_FDESC_LEN + TTM_FD_KC]);
+            const FastComp f = make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0);
+            R S, dS;
+            if (WANT_LD) sample_forward_fast<MONO, FAM, true>(f, g, xk, x, want_val, S, dS);
+            else sample_forward_fast<MONO, FAM, false>(f, g, xk, x, true, S, dS);
+            x.put(fd[TTM_FD_KC_SLOT], xk);
             if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
             if (Z) {
 #pragma unroll
@@ -502,7 +565,8 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
 // gathers bisect it, one 16-byte gather fetches the bracketing pair.  Waves never synchronise, so the
 // gather latency is hidden by occupancy instead of barriers and prefetch registers.  The thread walks
 // the components in order; its column cache serves the just-solved x_j to the following components.
-template <int NS>
+// PLAN: every component of [k0,k1) takes the fast path -> statically planned column cache, family FAM.
+template <int NS, bool PLAN, int FAM>
 __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1, const double* __restrict__ coef,
                                                        const double* __restrict__ fold,
                                                        const double* __restrict__ Z, int64_t ldz,
@@ -528,6 +592,8 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
             xa.n[e] = act[e] ? n : N - 1;
         }
         VarCache<XSoAN<NS>, R> x(xa, cst);
+        PlanCache<XSoAN<NS>, R> xp(xa, cst);
+        if (PLAN && k0 > 0) xp.warm((cint_p)P.fints + ((cint_p)P.fdesc)[k0 * TTM_FDESC_LEN + TTM_FD_PLAN_OFF]);
         R z_next;
 #pragma unroll
         for (int e = 0; e < NS; ++e) set_elem(z_next, e, Z[xa.n[e]]);
@@ -546,8 +612,11 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
             const double scale = (double)nb / (hi - lo);
             const bool use_bkt = scale > 0.0 && scale < 1.0e300 && nb >= 4;
             R off;
-            if (!fd[TTM_FD_COMPLEX]) {
-                off = nonmon_sum_fast<R>(make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0), g, x);
+            if (PLAN) {
+                off = nonmon_sum_fast<FAM, R>(make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0), g, xp);
+            } else if (!fd[TTM_FD_COMPLEX]) {
+                TaggedFetch<XSoAN<NS>, R> xf{x};
+                off = nonmon_sum_fast<-1, R>(make_fast(fd, (cint_p)P.fints, (cdbl_p)fold, 0), g, xf);
             } else {
                 const Comp c = comp_at(P, k, 0, coef, fold);
                 off = nonmon_sum<R>(c, g, x);
@@ -587,7 +656,7 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                 set_elem(r, e, re);
                 if (act[e]) X[(int64_t)kc * ldx + xa.n[e]] = re;
             }
-            x.put(kc, r);
+            if (PLAN) xp.put(fd[TTM_FD_KC_SLOT], r); else x.put(kc, r);
         }
     }
 }
@@ -758,13 +827,21 @@ static DevProg dev_prog(const ttm_program* p) {
 
 static int validate(const ttm_program* p, int k0, int k1) {
     if (!p || !p->itab || !p->ftab || !p->fdesc || !p->fints || !p->dpar || !p->d_offsets || !p->h_comp_off || !p->h_dpar_off || !p->h_coef_off ||
-        !p->h_nslots || !p->h_n_nm || !p->h_fold_off || !p->h_ftab_off || !p->h_nb1)
+        !p->h_nslots || !p->h_n_nm || !p->h_fold_off || !p->h_ftab_off || !p->h_nb1 || !p->h_complex)
         return set_err(TTM_E_ARG, "ttm_program has null tables%s");
     if (k0 < 0 || k1 > p->D || k0 >= k1) return set_err(TTM_E_ARG, "component range [%s%lld,%lld) invalid", "", k0, k1);
     if (p->Q < 0 || p->Q > 4096) return set_err(TTM_E_ARG, "quadrature order %s%lld out of range", "", p->Q);
     if (p->monotonicity == TTM_MONO_INTEGRATED && (p->Q < 1 || !p->quad_x || !p->quad_w))
         return set_err(TTM_E_ARG, "integrated rectifier needs quadrature nodes%s");
     return TTM_OK;
+}
+
+// do all components of [ka,kb) take the fast path (planned-cache kernels)?
+static bool all_fast(const ttm_program* p, int ka, int kb) {
+    if (getenv("TTM_NO_PLAN")) return false;                              // tuning / test knob: generic kernels
+    for (int k = ka; k < kb; ++k)
+        if (p->h_complex[k]) return false;
+    return true;
 }
 
 // per-thread scratch slots the map kernels need for components [ka,kb)
@@ -883,6 +960,23 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const int bd = pick_block(nsl, 0, NS);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_forward: %s%lld scratch slots per sample do not fit the LDS budget", "", nsl);
     const bool sep = p->monotonicity == TTM_MONO_SEPARABLE;
+    if (all_fast(p, k0, k1)) {
+        typedef void (*pkern_t)(DevProg, int, int, const double*, const double*, int64_t, int64_t, double*, int64_t, double*,
+                                const double*, double*);
+        pkern_t pk;
+        const bool he = p->family == TTM_FAM_HERMITE_E;
+#define TTM_FWDP_PICK2(M, L, NSV) (he ? k_forward_plan<M, L, NSV, TTM_FAM_HERMITE_E> : k_forward_plan<M, L, NSV, -1>)
+#define TTM_FWDP_PICK(NSV)                                                                                              \
+    (sep ? (logdet ? TTM_FWDP_PICK2(TTM_MONO_SEPARABLE, true, NSV) : TTM_FWDP_PICK2(TTM_MONO_SEPARABLE, false, NSV))     \
+         : (logdet ? TTM_FWDP_PICK2(TTM_MONO_INTEGRATED, true, NSV) : TTM_FWDP_PICK2(TTM_MONO_INTEGRATED, false, NSV)))
+        if (NS >= 2) { NS = 2; pk = TTM_FWDP_PICK(2); } else pk = TTM_FWDP_PICK(1);
+#undef TTM_FWDP_PICK
+#undef TTM_FWDP_PICK2
+        const int pbd = pick_block(0, 0, NS);
+        hipLaunchKernelGGL(pk, dim3(grid_for(N, NS * pbd)), dim3(pbd), lds_bytes(0, pbd, 0, NS), (hipStream_t)stream, dev_prog(p),
+                           (int)k0, (int)k1, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);
+        return check_launch("k_forward_plan");
+    }
     typedef void (*kern_t)(DevProg, int, int, const double*, const double*, const double*, int64_t, int64_t, double*, int64_t,
                            double*, const double*, double*);
     kern_t kern;
@@ -943,7 +1037,11 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
     const int bd = 256;
     int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)
     if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob
-    auto kern = NS == 2 ? k_inverse_table<2> : k_inverse_table<1>;
+    auto kern = NS == 2 ? k_inverse_table<2, false, -1> : k_inverse_table<1, false, -1>;
+    if (all_fast(p, k0, k1)) {
+        if (p->family == TTM_FAM_HERMITE_E) kern = NS == 2 ? k_inverse_table<2, true, TTM_FAM_HERMITE_E> : k_inverse_table<1, true, TTM_FAM_HERMITE_E>;
+        else kern = NS == 2 ? k_inverse_table<2, true, -1> : k_inverse_table<1, true, -1>;
+    }
     hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), lds_bytes(0, bd, 0, NS), (hipStream_t)stream, dev_prog(p),
                        (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, h_y_affine ? 1 : 0,
                        h_y_affine ? h_y_affine[0] : 0.0, h_y_affine ? h_y_affine[1] : 0.0, h_y_affine ? h_y_affine[2] : 0.0, tmin,

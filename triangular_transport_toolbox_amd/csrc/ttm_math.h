@@ -53,44 +53,45 @@ static const double g_exp_coef[12] = {
     2.7557319223985893e-06, 2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889,
     0.008333333333333333, 0.041666666666666664, 0.16666666666666666, 0.5};
 
-TTM_HD double fast_exp(double y) {
+// exp(y); R = double or VecD<N> (the Horner steps of the N samples interleave: independent FMA chains)
+template <class R>
+TTM_HD R fast_exp(const R& y) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const __attribute__((address_space(4))) double* kc = (const __attribute__((address_space(4))) double*)g_exp_coef;
 #else
     const double* kc = g_exp_coef;
 #endif
-    const double yc = fmin(fmax(y, -800.0), 800.0);
-    const double k = rint(yc * 1.4426950408889634);
-    double r = fma(-k, 6.93147180369123816490e-01, yc);
-    r = fma(-k, 1.90821492927058770002e-10, r);
-    double p = kc[0];
+    const R yc = vmin(vmax(y, -800.0), 800.0);
+    const R k = vrint(yc * 1.4426950408889634);
+    R r = vfma(-k, 6.93147180369123816490e-01, yc);
+    r = vfma(-k, 1.90821492927058770002e-10, r);
+    R p(kc[0]);
 #pragma unroll
-    for (int j = 1; j < 12; ++j) p = fma(p, r, kc[j]);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const double res = ldexp(p, (int)k);
-    return (y != y) ? y : res;
+    for (int j = 1; j < 12; ++j) p = vfma(p, r, kc[j]);
+    p = vfma(p, r, 1.0);
+    p = vfma(p, r, 1.0);
+    const R res = vldexp(p, vtoint(k));
+    return vnan_to(y, y, res);
 }
 
 // erf(t) and exp(-t^2) from the staged Taylor table (TTM_ERF_TABLE_LEN doubles, [coefficient][interval]).
 // The Gaussian is the derivative of the same local polynomial (erf' = 2/sqrt(pi) exp(-t^2)): no exp call.
 // abs errors: erf 2.3e-16, exp(-t^2) 9e-16 (relative 2.5e-12 up to |t| < 4); |t| >= 6 returns erf = +-1 and
-// exp(-t^2) = 2.3e-16.
-template <bool GAUSS>
-TTM_HD void erf_gauss_tab(const double* tab, double t, double& erfv, double& gauss) {
-    const double a = fmin(fabs(t), 5.9999999);
-    const int i = (int)(a * 16.0);
-    const double d = fma(-((double)i + 0.5), 0.0625, a);
-    const double* c = tab + i;
-    double p = c[9 * TTM_ERF_NINT], dp = 0.0;
+// exp(-t^2) = 2.3e-16.  R = double or VecD<N>.
+template <bool GAUSS, class R>
+TTM_HD void erf_gauss_tab(const double* tab, const R& t, R& erfv, R& gauss) {
+    const R a = vmin(vabs(t), 5.9999999);
+    const typename int_of<R>::type i = vtoint(a * 16.0);
+    const R d = vfma(-(vfromint(i) + 0.5), 0.0625, a);
+    R p = vgather(tab + 9 * TTM_ERF_NINT, i), dp(0.0);
 #pragma unroll
     for (int j = 8; j >= 0; --j) {
-        if (GAUSS) dp = fma(dp, d, p);
-        p = fma(p, d, c[j * TTM_ERF_NINT]);
+        const R cj = vgather(tab + j * TTM_ERF_NINT, i);
+        if (GAUSS) dp = vfma(dp, d, p);
+        p = vfma(p, d, cj);
     }
-    const double res = copysign(p, t);
-    erfv = (t != t) ? t : res;
-    gauss = GAUSS ? ((t != t) ? t : 0.88622692545275801365 * dp) : 0.0;      // sqrt(pi)/2
+    erfv = vnan_to(t, t, vcopysign(p, t));
+    gauss = GAUSS ? vnan_to(t, t, 0.88622692545275801365 * dp) : R(0.0);      // sqrt(pi)/2
 }
 
 TTM_HD double erf_tab(const double* tab, double t) {
@@ -141,22 +142,10 @@ template <int N> TTM_HD VecD<N> fast_div(const VecD<N>& a, double b) {
     for (int i = 0; i < N; ++i) r.v[i] = fast_div(a.v[i], b);
     return r;
 }
-template <int N> TTM_HD VecD<N> fast_exp(const VecD<N>& y) {
-    VecD<N> r;
-#pragma unroll
-    for (int i = 0; i < N; ++i) r.v[i] = fast_exp(y.v[i]);
-    return r;
-}
 template <int N> TTM_HD VecD<N> fast_log(const VecD<N>& x) {
     VecD<N> r;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.v[i] = fast_log(x.v[i]);
     return r;
 }
-template <bool GAUSS, int N>
-TTM_HD void erf_gauss_tab(const double* tab, const VecD<N>& t, VecD<N>& erfv, VecD<N>& gauss) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) erf_gauss_tab<GAUSS>(tab, t.v[i], erfv.v[i], gauss.v[i]);
-}
-
 }  // namespace ttm

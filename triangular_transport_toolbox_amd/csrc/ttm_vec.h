@@ -192,6 +192,15 @@ template <int N> TTM_HD VecD<N> vldexp(const VecD<N>& a, const VecI<N>& e) {
     return r;
 }
 
+// table gather: base[i] per element
+TTM_HD double vgather(const double* base, int i) { return base[i]; }
+template <int N> TTM_HD VecD<N> vgather(const double* base, const VecI<N>& i) {
+    VecD<N> r;
+#pragma unroll
+    for (int e = 0; e < N; ++e) r.v[e] = base[i.v[e]];
+    return r;
+}
+
 // integer vector type matching a value type
 template <class R> struct int_of { typedef int type; };
 template <int N> struct int_of<VecD<N>> { typedef VecI<N> type; };

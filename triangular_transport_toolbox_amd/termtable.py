@@ -230,6 +230,88 @@ def _descriptor(term):
     return out
 
 
+PLAN_WAYS = 4            # TTM_PLAN_WAYS
+PLAN_HF, PLAN_XHIT, PLAN_EHIT, PLAN_E = 1, 2, 4, 1 << 30
+FD_LEN, FD_KC_SLOT = 16, 13
+
+
+def _plan_column_cache(plan_seq, fdesc, fints):
+    """Static schedule of the per-thread column cache of the fast kernels.
+
+    A sweep over the components touches the columns in an order that is known when the map is compiled:
+    per component the columns of its univariate nonmonotone groups, then its own column x_kc (which
+    later components read).  So hit / miss / replacement are decided here, with Belady's rule (evict the
+    column whose next use is farthest away, bypass when the new column's next use is farther than all
+    of them) instead of run-time tag compares: each group record gets a flag word (TTM_PLAN_*: slot,
+    column already there, exp(-x^2/4) already there), each component the slot for its own column, and
+    the cache contents on entry to every component are recorded so that a sweep can start anywhere
+    (conditional inverse, component shards): the kernel preloads that state.  Components that need the
+    generic interpreter do not use the planned cache; they leave the state untouched."""
+    # flat access list: (component, column, wants_e, fints index of the flag word or None for the own column)
+    acc = []
+    for k, (groups, kc, fint_off) in enumerate(plan_seq):
+        if groups is None:
+            continue
+        for gi, (var, hf) in enumerate(groups):
+            acc.append((k, var, hf, fint_off + 4 * gi + 3))
+        acc.append((k, kc, False, None))
+    # next use of the same column after access i (reads only: the own-column put is not a use)
+    nxt, last = [None] * len(acc), {}
+    for i in range(len(acc) - 1, -1, -1):
+        k, var, hf, fi = acc[i]
+        nxt[i] = last.get(var, 1 << 60)
+        if fi is not None:
+            last[var] = i
+    slots = [None] * PLAN_WAYS          # [column, e_valid, next use]
+    state_at = {}
+    cur_k = -1
+
+    def snapshot(k_from, k_to):
+        for kk in range(k_from, k_to):
+            state_at[kk] = [(-1 if sl is None else (sl[0] | (PLAN_E if sl[1] else 0))) for sl in slots]
+
+    def place(var, nuse):
+        """slot for a column that is not cached, or 255 to bypass"""
+        for w in range(PLAN_WAYS):
+            if slots[w] is None:
+                return w
+        far = max(range(PLAN_WAYS), key=lambda w_: slots[w_][2])
+        if slots[far][2] <= nuse:
+            return 255
+        return far
+
+    for i, (k, var, hf, fi) in enumerate(acc):
+        if k != cur_k:
+            snapshot(cur_k + 1, k + 1)
+            cur_k = k
+        where = next((w for w in range(PLAN_WAYS) if slots[w] is not None and slots[w][0] == var), None)
+        if fi is None:                  # own column: keep it if somebody reads it later
+            if where is not None:       # (cannot happen: groups only read columns < kc)
+                slots[where] = None
+            w = place(var, nxt[i]) if nxt[i] < (1 << 60) else 255
+            if w != 255:
+                slots[w] = [var, False, nxt[i]]
+            fdesc[k * FD_LEN + FD_KC_SLOT] = -1 if w == 255 else w
+            continue
+        flags = PLAN_HF if hf else 0
+        if where is not None:
+            flags |= PLAN_XHIT | (where << 8)
+            if hf and slots[where][1]:
+                flags |= PLAN_EHIT
+            slots[where][1] = slots[where][1] or hf
+            slots[where][2] = nxt[i]
+        else:
+            w = place(var, nxt[i]) if nxt[i] < (1 << 60) else 255
+            flags |= w << 8
+            if w != 255:
+                slots[w] = [var, hf, nxt[i]]
+        fints[fi] = flags
+    snapshot(cur_k + 1, len(plan_seq))
+    for k, (groups, kc, fint_off) in enumerate(plan_seq):
+        po = fdesc[k * FD_LEN + 14]
+        fints[po:po + PLAN_WAYS] = state_at[k]
+
+
 def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function',
                 monotonicity='integrated rectifier'):
     """Compile the specification lists into device tables (special-term
@@ -248,6 +330,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     itab, dpar = [], []
     comp_off, dpar_off, coef_off, fold_off, ftab_off = [0], [0], [0], [0], [0]
     ftab, fdesc, fints = [], [], []
+    plan_seq, complex_all = [], []
     nslots, nb1, n_nm_all, n_mon_all = [], [], [], []
 
     for k in range(D):
@@ -420,14 +503,27 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         for sl in fold_slots:
             fslots.append([len(fsrc), len(sl)])
             fsrc.extend([list(e) for e in sl])
-        # fast-path descriptor (12 int32) and int stream {per group: var, P, alpha offset, has_hf | ST kinds}
+        # fast-path descriptor (TTM_FDESC_LEN int32) and int stream {per group: var, P, alpha offset, flags |
+        # ST kinds | order of the unified ST records | planned-cache entry state}
         complex_comp = 1 if (len(gen_idx) or len(mnt_idx) or maxP_hf > 16 or maxP_poly > 16) else 0
-        fdesc.extend([kc, len(groups), len(b_st), maxP_hf, maxP_poly, complex_comp, len(fints), fold_off[-1], stream_rel,
-                      len(bfuns), off_wb, 0])
+        st_kinds = [bf[0] for bf in bfuns[len(b_hf) + len(b_poly):]]
+        # unified special-term records: those whose VALUE needs the Gaussian (LET / RET / RBF) first
+        st_order = ([i for i, kd in enumerate(st_kinds) if kd != KIND_IRBF] +
+                    [i for i, kd in enumerate(st_kinds) if kd == KIND_IRBF])
+        n_stA = sum(1 for kd in st_kinds if kd != KIND_IRBF)
+        st8_rel = len(fslots) + ((-len(fslots)) % 8)
+        fold_len = st8_rel + 8 + 8 * len(b_st)
+        fint_off = len(fints)
         for g_ in groups:
             fints.extend(g_)
-        fints.extend(bf[0] for bf in bfuns[len(b_hf) + len(b_poly):])
+        fints.extend(st_kinds)
+        fints.extend(st_order)
         fints.extend([0] * ((-len(fints)) % 4))
+        plan_off = len(fints)
+        fints.extend([-1] * PLAN_WAYS)
+        fdesc.extend([kc, len(groups), len(b_st), maxP_hf, maxP_poly, complex_comp, fint_off, fold_off[-1], stream_rel,
+                      len(bfuns), off_wb, st8_rel, n_stA, -1, plan_off, 0])
+        plan_seq.append(([(g_[0], bool(g_[3])) for g_ in groups] if not complex_comp else None, kc, fint_off))
         # ---- assemble the block ---------------------------------------------
         hdr = [0] * HDR_LEN
         off_nm = HDR_LEN
@@ -461,7 +557,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         block = (hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b] +
                  [v for g in groups for v in g] + gen_idx + mnt_idx + [0] * pad)
         assert len(block) == blk_len
-        fold_off.append(fold_off[-1] + len(fslots))
+        fold_off.append(fold_off[-1] + fold_len)
         ftab.extend([v for sl in fslots for v in sl] + [v for e in fsrc for v in e])
         ftab_off.append(len(ftab))
         itab.extend(block)
@@ -472,6 +568,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         dpar_off.append(len(dpar))
         coef_off.append(coef_off[-1] + len(nm_terms) + len(mon_terms))
         nslots.append(len(bfuns) + 1 if len(mnt_idx) else 0)
+        complex_all.append(complex_comp)
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
         n_mon_all.append(len(mon_terms))
@@ -490,6 +587,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.fold_off = np.asarray(fold_off, dtype=np.int32)
     cm.ftab = np.asarray(ftab if len(ftab) else [0], dtype=np.int32)
     cm.ftab_off = np.asarray(ftab_off, dtype=np.int32)
+    _plan_column_cache(plan_seq, fdesc, fints)
+    cm.complex = np.asarray(complex_all, dtype=np.int32)
     cm.fdesc = np.asarray(fdesc, dtype=np.int32)
     cm.fints = np.asarray(fints if len(fints) else [0], dtype=np.int32)
     cm.offsets = np.concatenate((cm.comp_off, cm.dpar_off, cm.coef_off, cm.fold_off, cm.ftab_off)).astype(np.int32)
