@@ -154,7 +154,7 @@ extern "C" {
 /* planned column cache (fast kernels): the access sequence of a sweep over the components is static, so
  * hit / miss / replacement (Belady) decisions are made when the program is compiled; a group record's
  * flag word says where its column lives */
-#define TTM_PLAN_WAYS     4
+#define TTM_PLAN_WAYS     4   /* at most; ttm_program.plan_ways are used (slot w: x at 2w, exp(-x^2/4) at 2w+1) */
 #define TTM_PLAN_HF       1   /* group has Hermite-function terms (needs exp(-x^2/4))           */
 #define TTM_PLAN_XHIT     2   /* column value is in the slot                                   */
 #define TTM_PLAN_EHIT     4   /* exp(-x^2/4) is in the slot too                                */
@@ -192,6 +192,8 @@ typedef struct ttm_program {
     int32_t monotonicity;       /* TTM_MONO_*                                      */
     int32_t rectifier;          /* TTM_RECT_*                                      */
     int32_t Q;                  /* quadrature order                                */
+    int32_t plan_ways;          /* ways of the planned column cache (1..TTM_PLAN_WAYS) the fints plan was made for */
+    int32_t reserved;
     double  delta;              /* TM:34, added to the rectifier / to dS           */
 } ttm_program;
 

@@ -276,6 +276,23 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
     return 0;
 }
 
+// TEST ONLY: the elementary functions of csrc/ttm_math.h on arrays (which: 0 exp, 1 erf, 2 exp(-t^2) from the
+// erf table, 3 log, 4 reciprocal, 5 a/b with b = second array)
+int emu_math(int which, const double* a, const double* b, int64_t n, double* out) {
+    for (int64_t i = 0; i < n; ++i) {
+        double e, g;
+        switch (which) {
+            case 0: out[i] = fast_exp(a[i]); break;
+            case 1: erf_gauss_tab<true>(kErfTab, a[i], e, g); out[i] = e; break;
+            case 2: erf_gauss_tab<true>(kErfTab, a[i], e, g); out[i] = g; break;
+            case 3: out[i] = fast_log(a[i]); break;
+            case 4: out[i] = fast_rcp(a[i]); break;
+            default: out[i] = fast_div(a[i], b[i]); break;
+        }
+    }
+    return 0;
+}
+
 int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* X, int64_t ldx, int64_t N, double* out, int64_t ldo, void*) {
     const Prog g = make_prog(p);
     HostComp h;

@@ -27,7 +27,7 @@ def test_library_builds_and_exports_all_symbols():
 
 def test_struct_layout_matches_header():
     # 16 pointers + 6 int32 + 1 double on LP64
-    assert ctypes.sizeof(_capi.ttm_program) == 17 * 8 + 6 * 4 + 8
+    assert ctypes.sizeof(_capi.ttm_program) == 17 * 8 + 8 * 4 + 8
 
 
 def test_no_device_fails_loudly():

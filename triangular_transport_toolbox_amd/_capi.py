@@ -20,7 +20,7 @@ class ttm_program(ctypes.Structure):
     _fields_ = [('itab', c_vp), ('ftab', c_vp), ('fdesc', c_vp), ('fints', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
                 ('h_comp_off', c_vp), ('h_dpar_off', c_vp), ('h_coef_off', c_vp), ('h_nslots', c_vp), ('h_n_nm', c_vp), ('h_fold_off', c_vp), ('h_ftab_off', c_vp), ('h_nb1', c_vp), ('h_complex', c_vp), ('d_offsets', c_vp),
                 ('D', c_i32), ('d_cols', c_i32), ('family', c_i32), ('monotonicity', c_i32), ('rectifier', c_i32),
-                ('Q', c_i32), ('delta', c_dbl)]
+                ('Q', c_i32), ('plan_ways', c_i32), ('reserved', c_i32), ('delta', c_dbl)]
 
 
 MONO = {'integrated rectifier': 0, 'separable monotonicity': 1}
@@ -127,5 +127,6 @@ def make_program(cm, itab_ptr, ftab_ptr, fdesc_ptr, fints_ptr, dpar_ptr, qx_ptr,
     p.monotonicity = MONO[monotonicity.lower()]
     p.rectifier = RECT[rectifier]
     p.Q = int(Q)
+    p.plan_ways = int(cm.plan_ways)
     p.delta = float(delta)
     return p

@@ -682,7 +682,7 @@ struct TaggedFetch {
 };
 
 // statically planned cache (termtable.py:_plan_column_cache): the flag word of the group record says where
-// the column lives, no tag compares.  Slots 0..3 hold columns, 4..7 their exp(-x^2/4).
+// the column lives, no tag compares.  Way w keeps its column in slot 2w and exp(-x^2/4) in slot 2w+1.
 template <class XA, class R>
 struct PlanCache {
     const XA& xa;
@@ -694,26 +694,26 @@ struct PlanCache {
             const int v = state[w];
             if (v >= 0) {
                 const R x = xa(v & ~TTM_PLAN_E);
-                st.set(w, x);
-                if (v & TTM_PLAN_E) st.set(TTM_PLAN_WAYS + w, fast_exp(-0.25 * (x * x)));
+                st.set(2 * w, x);
+                if (v & TTM_PLAN_E) st.set(2 * w + 1, fast_exp(-0.25 * (x * x)));
             }
         }
     }
-    TTM_HD void put(int slot, const R& x) { if (slot >= 0) st.set(slot, x); }
+    TTM_HD void put(int slot, const R& x) { if (slot >= 0) st.set(2 * slot, x); }
     TTM_HD void fetch(int var, int fl, R& x, R& e) {
         const int slot = TTM_PLAN_SLOT(fl);
         if (fl & TTM_PLAN_XHIT) {
-            x = st.get(slot);
+            x = st.get(2 * slot);
         } else {
             x = xa(var);
-            if (slot != 255) st.set(slot, x);
+            if (slot != 255) st.set(2 * slot, x);
         }
         if (fl & TTM_PLAN_HF) {
             if (fl & TTM_PLAN_EHIT) {
-                e = st.get(TTM_PLAN_WAYS + slot);
+                e = st.get(2 * slot + 1);
             } else {
                 e = fast_exp(-0.25 * (x * x));
-                if (slot != 255) st.set(TTM_PLAN_WAYS + slot, e);
+                if (slot != 255) st.set(2 * slot + 1, e);
             }
         }
     }

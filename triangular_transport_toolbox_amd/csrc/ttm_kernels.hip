@@ -7,7 +7,7 @@
 // rule - is read through constant-address-space pointers, i.e. by scalar loads
 // into SGPRs (the scalar unit runs the table interpreter, the VALU only does
 // per-sample fp64 math).  LDS holds what lanes index individually: the erf
-// Taylor table (6.9 KB) and per-sample scratch in per-thread columns
+// interpolation table (3 KB) and per-sample scratch in per-thread columns
 // `slot*blockDim + tid` (weights w_b of the x_k-univariate functions for
 // components with cross terms, quadrature partials, gradient accumulators),
 // plus the 1001-point inverse table of the table root search.
@@ -855,6 +855,13 @@ static size_t lds_bytes(int nslots, int bd, int extra_doubles, int ns = 1) {
     return ((size_t)TTM_ERF_TABLE_LEN + (size_t)(TTM_CACHE_SLOTS + nslots) * ns * bd + extra_doubles) * 8;
 }
 
+// LDS image of the planned-cache kernels: erf table + 2 slots per way
+static size_t lds_bytes_plan(const ttm_program* p, int bd, int ns) {
+    int ways = p->plan_ways;
+    if (ways < 1 || ways > TTM_PLAN_WAYS) ways = TTM_PLAN_WAYS;
+    return ((size_t)TTM_ERF_TABLE_LEN + (size_t)2 * ways * ns * bd) * 8;
+}
+
 // largest block size whose LDS image fits; 0 if none
 static int pick_block(int nslots, int extra_doubles, int ns = 1) {
     for (int bd = 256; bd >= 64; bd >>= 1)
@@ -972,8 +979,8 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         if (NS >= 2) { NS = 2; pk = TTM_FWDP_PICK(2); } else pk = TTM_FWDP_PICK(1);
 #undef TTM_FWDP_PICK
 #undef TTM_FWDP_PICK2
-        const int pbd = pick_block(0, 0, NS);
-        hipLaunchKernelGGL(pk, dim3(grid_for(N, NS * pbd)), dim3(pbd), lds_bytes(0, pbd, 0, NS), (hipStream_t)stream, dev_prog(p),
+        const int pbd = 256;
+        hipLaunchKernelGGL(pk, dim3(grid_for(N, NS * pbd)), dim3(pbd), lds_bytes_plan(p, pbd, NS), (hipStream_t)stream, dev_prog(p),
                            (int)k0, (int)k1, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);
         return check_launch("k_forward_plan");
     }
@@ -1037,13 +1044,14 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
     const int bd = 256;
     int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)
     if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob
+    const bool planned = all_fast(p, k0, k1);
     auto kern = NS == 2 ? k_inverse_table<2, false, -1> : k_inverse_table<1, false, -1>;
-    if (all_fast(p, k0, k1)) {
+    if (planned) {
         if (p->family == TTM_FAM_HERMITE_E) kern = NS == 2 ? k_inverse_table<2, true, TTM_FAM_HERMITE_E> : k_inverse_table<1, true, TTM_FAM_HERMITE_E>;
         else kern = NS == 2 ? k_inverse_table<2, true, -1> : k_inverse_table<1, true, -1>;
     }
-    hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), lds_bytes(0, bd, 0, NS), (hipStream_t)stream, dev_prog(p),
-                       (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, h_y_affine ? 1 : 0,
+    hipLaunchKernelGGL(kern, dim3(grid_for(N, NS * bd)), dim3(bd), planned ? lds_bytes_plan(p, bd, NS) : lds_bytes(0, bd, 0, NS),
+                       (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, tab_x, tab_y, ldy, (int)T, h_y_affine ? 1 : 0,
                        h_y_affine ? h_y_affine[0] : 0.0, h_y_affine ? h_y_affine[1] : 0.0, h_y_affine ? h_y_affine[2] : 0.0, tmin,
                        tmax, bkt, (int)nb, (int)truncate);
     return check_launch("k_inverse_table");

@@ -5,9 +5,9 @@
 // gfx950 with two divergent paths inside erf.  The map kernels are bound by
 // exactly these (profiles/r01_v1_*), so they get branch-free replacements:
 //   fast_exp : Cody-Waite reduction + degree-13 Taylor/Horner, ~22 instructions, <= 1 ulp
-//   erf_tab  : piecewise degree-9 Taylor table (96 intervals on [0,6), 7.7 KB, staged in
-//              LDS), 9 FMA + 10 LDS reads, max abs error 2.3e-16; the same coefficients give
-//              exp(-t^2) as the polynomial's derivative (9 more FMA, no exp call)
+//   erf_tab  : piecewise degree-11 interpolants (32 intervals on [0,6), 3 KB, staged in
+//              LDS, bank-conflict free), 11 FMA + 12 LDS reads, max abs error 1.1e-16; the same
+//              coefficients give exp(-t^2) as the polynomial's derivative (11 more FMA, no exp call)
 //   fast_log : fdlibm-style log with a Newton reciprocal, ~35 instructions, <= 2 ulp
 //   fast_div : v_rcp_f64 + 2 Newton steps + residual correction (not IEEE-exact, <= 1 ulp)
 // Accuracy is tested against NumPy/SciPy in tests/test_math.py (host build of the same code).
@@ -74,18 +74,19 @@ TTM_HD R fast_exp(const R& y) {
     return vnan_to(y, y, res);
 }
 
-// erf(t) and exp(-t^2) from the staged Taylor table (TTM_ERF_TABLE_LEN doubles, [coefficient][interval]).
-// The Gaussian is the derivative of the same local polynomial (erf' = 2/sqrt(pi) exp(-t^2)): no exp call.
-// abs errors: erf 2.3e-16, exp(-t^2) 9e-16 (relative 2.5e-12 up to |t| < 4); |t| >= 6 returns erf = +-1 and
-// exp(-t^2) = 2.3e-16.  R = double or VecD<N>.
+// erf(t) and exp(-t^2) from the staged table (TTM_ERF_TABLE_LEN doubles, [coefficient][interval]; see
+// tools/gen_erf_table.py for the geometry and why it is bank-conflict free).  The Gaussian is the derivative of
+// the same local polynomial (erf' = 2/sqrt(pi) exp(-t^2)): no exp call.
+// abs errors: erf 1.1e-16, exp(-t^2) 3.4e-16 (relative 2e-13 up to |t| < 4); |t| >= 6 is clamped to 6 (erf = +-1 within
+// 1.2e-16, exp(-t^2) = 2.3e-16).  R = double or VecD<N>.
 template <bool GAUSS, class R>
 TTM_HD void erf_gauss_tab(const double* tab, const R& t, R& erfv, R& gauss) {
     const R a = vmin(vabs(t), 5.9999999);
-    const typename int_of<R>::type i = vtoint(a * 16.0);
-    const R d = vfma(-(vfromint(i) + 0.5), 0.0625, a);
-    R p = vgather(tab + 9 * TTM_ERF_NINT, i), dp(0.0);
+    const typename int_of<R>::type i = vtoint(a * TTM_ERF_INV_WIDTH);
+    const R d = vfma(-(vfromint(i) + 0.5), TTM_ERF_WIDTH, a);
+    R p = vgather(tab + TTM_ERF_DEG * TTM_ERF_NINT, i), dp(0.0);
 #pragma unroll
-    for (int j = 8; j >= 0; --j) {
+    for (int j = TTM_ERF_DEG - 1; j >= 0; --j) {
         const R cj = vgather(tab + j * TTM_ERF_NINT, i);
         if (GAUSS) dp = vfma(dp, d, p);
         p = vfma(p, d, cj);

@@ -235,7 +235,7 @@ PLAN_HF, PLAN_XHIT, PLAN_EHIT, PLAN_E = 1, 2, 4, 1 << 30
 FD_LEN, FD_KC_SLOT = 16, 13
 
 
-def _plan_column_cache(plan_seq, fdesc, fints):
+def _plan_column_cache(plan_seq, fdesc, fints, ways=None):
     """Static schedule of the per-thread column cache of the fast kernels.
 
     A sweep over the components touches the columns in an order that is known when the map is compiled:
@@ -246,7 +246,16 @@ def _plan_column_cache(plan_seq, fdesc, fints):
     column already there, exp(-x^2/4) already there), each component the slot for its own column, and
     the cache contents on entry to every component are recorded so that a sweep can start anywhere
     (conditional inverse, component shards): the kernel preloads that state.  Components that need the
-    generic interpreter do not use the planned cache; they leave the state untouched."""
+    generic interpreter do not use the planned cache; they leave the state untouched.
+
+    ways = None: the number of ways (<= PLAN_WAYS) is chosen here - the smallest one whose column loads
+    stay within 10 % (+2) of what PLAN_WAYS ways need - because the cache lives in LDS and fewer ways mean
+    more resident waves.  Returns (ways, column loads of a full sweep)."""
+    if ways is None:
+        trial = {}
+        for w in range(1, PLAN_WAYS + 1):
+            trial[w] = _plan_column_cache(plan_seq, list(fdesc), list(fints), w)[1]
+        ways = next(w for w in range(1, PLAN_WAYS + 1) if trial[w] <= 1.1 * trial[PLAN_WAYS] + 2)
     # flat access list: (component, column, wants_e, fints index of the flag word or None for the own column)
     acc = []
     for k, (groups, kc, fint_off) in enumerate(plan_seq):
@@ -262,20 +271,22 @@ def _plan_column_cache(plan_seq, fdesc, fints):
         nxt[i] = last.get(var, 1 << 60)
         if fi is not None:
             last[var] = i
-    slots = [None] * PLAN_WAYS          # [column, e_valid, next use]
+    slots = [None] * ways               # [column, e_valid, next use]
+    loads = 0
     state_at = {}
     cur_k = -1
 
     def snapshot(k_from, k_to):
         for kk in range(k_from, k_to):
-            state_at[kk] = [(-1 if sl is None else (sl[0] | (PLAN_E if sl[1] else 0))) for sl in slots]
+            state_at[kk] = ([(-1 if sl is None else (sl[0] | (PLAN_E if sl[1] else 0))) for sl in slots] +
+                            [-1] * (PLAN_WAYS - ways))
 
     def place(var, nuse):
         """slot for a column that is not cached, or 255 to bypass"""
-        for w in range(PLAN_WAYS):
+        for w in range(ways):
             if slots[w] is None:
                 return w
-        far = max(range(PLAN_WAYS), key=lambda w_: slots[w_][2])
+        far = max(range(ways), key=lambda w_: slots[w_][2])
         if slots[far][2] <= nuse:
             return 255
         return far
@@ -284,7 +295,7 @@ def _plan_column_cache(plan_seq, fdesc, fints):
         if k != cur_k:
             snapshot(cur_k + 1, k + 1)
             cur_k = k
-        where = next((w for w in range(PLAN_WAYS) if slots[w] is not None and slots[w][0] == var), None)
+        where = next((w for w in range(ways) if slots[w] is not None and slots[w][0] == var), None)
         if fi is None:                  # own column: keep it if somebody reads it later
             if where is not None:       # (cannot happen: groups only read columns < kc)
                 slots[where] = None
@@ -301,6 +312,7 @@ def _plan_column_cache(plan_seq, fdesc, fints):
             slots[where][1] = slots[where][1] or hf
             slots[where][2] = nxt[i]
         else:
+            loads += 1
             w = place(var, nxt[i]) if nxt[i] < (1 << 60) else 255
             flags |= w << 8
             if w != 255:
@@ -310,6 +322,7 @@ def _plan_column_cache(plan_seq, fdesc, fints):
     for k, (groups, kc, fint_off) in enumerate(plan_seq):
         po = fdesc[k * FD_LEN + 14]
         fints[po:po + PLAN_WAYS] = state_at[k]
+    return ways, loads
 
 
 def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function',
@@ -587,7 +600,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.fold_off = np.asarray(fold_off, dtype=np.int32)
     cm.ftab = np.asarray(ftab if len(ftab) else [0], dtype=np.int32)
     cm.ftab_off = np.asarray(ftab_off, dtype=np.int32)
-    _plan_column_cache(plan_seq, fdesc, fints)
+    cm.plan_ways, cm.plan_loads = _plan_column_cache(plan_seq, fdesc, fints)
     cm.complex = np.asarray(complex_all, dtype=np.int32)
     cm.fdesc = np.asarray(fdesc, dtype=np.int32)
     cm.fints = np.asarray(fints if len(fints) else [0], dtype=np.int32)
