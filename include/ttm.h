@@ -161,6 +161,47 @@ extern "C" {
 #define TTM_PLAN_SLOT(f) (((f) >> 8) & 255)     /* 255: bypass (do not keep)                   */
 #define TTM_PLAN_E       (1 << 30)
 
+/* ---- univariate form ("U-form") of a separable map whose terms are all univariate -------------------------
+ * (csrc/ttm_uform.h).  Static structure in two int32 tables compiled by the host, coefficients in a section
+ * appended to the folded-coefficient buffer by ttm_fold:
+ *   ucomp : TTM_UC_LEN int32 per component
+ *   ugrp  : TTM_UG_LEN int32 per group; a component's nonmonotone groups first, then (TTM_UCF_OWN) one group for
+ *           the polynomial / Hermite-function terms of its monotone list
+ *   U section (doubles, at fold + u_base): per component, at DBL_OFF: {c0, -t_lo/h, 1/h, 2/h} and 16 doubles per
+ *           group {B[0..7] monomial coefficients of the exp(-x^2/4) part, A[0..7] of the plain part}; at TAB_OFF the
+ *           spline of the summed special terms: NI columns of TTM_U_TSTRIDE doubles (12 coefficients in the local
+ *           coordinate s in [-1,1] of the interval + padding), column 0 / NI-1 = the linear tails; then 2 doubles per
+ *           component {fit error of the value, of the derivative} at u_err_off.                                   */
+#define TTM_U_PMAX        7   /* largest polynomial order a group may have                      */
+#define TTM_U_DEG        11   /* degree of the spline pieces                                    */
+#define TTM_U_TSTRIDE    14   /* doubles per spline column (16-byte reads of 16 consecutive columns hit disjoint banks) */
+#define TTM_U_NI_MAX    128   /* most columns a spline may have (LDS budget of the staged table) */
+#define TTM_UC_LEN        8
+#define TTM_UC_KC         0
+#define TTM_UC_KC_SLOT    1   /* planned column cache slot for x_kc (-1: none)                  */
+#define TTM_UC_N_GRP      2   /* nonmonotone groups                                             */
+#define TTM_UC_GRP_OFF    3   /* first group record                                             */
+#define TTM_UC_NI         4   /* spline columns (0: the component has no special terms)         */
+#define TTM_UC_TAB_OFF    5   /* doubles, relative to the U section                             */
+#define TTM_UC_DBL_OFF    6
+#define TTM_UC_FLAGS      7
+#define TTM_UCF_OWN       1   /* group record N_GRP holds the monotone polynomial / HF terms    */
+#define TTM_UCF_PUT_E     2   /* exp(-x_kc^2/4) is stored with x_kc (a later group reads it): the U-form kernels
+                                 compute it eagerly, so every Hermite-function reader of a swept column is a hit */
+/* ucomp is followed by TTM_PLAN_WAYS entry-state words per component (column | TTM_PLAN_E, -1 = empty): the cache
+ * contents when a sweep reaches that component, under the eager semantics above                                  */
+#define TTM_UC_STATE(D, k) ((D) * TTM_UC_LEN + (k) * TTM_PLAN_WAYS)
+#define TTM_UG_LEN        8
+#define TTM_UG_VAR        0
+#define TTM_UG_FLAGS      1   /* TTM_PLAN_* | degree of B << 16 | TTM_UGF_POLY | degree of A << 24 */
+#define TTM_UG_SRCA       2   /* offset in the component's folded block of the plain coefficients of P_1.. (-1: none) */
+#define TTM_UG_PA         3
+#define TTM_UG_SRCB       4   /* same for the Hermite-function coefficients                     */
+#define TTM_UG_PB         5
+#define TTM_UG_DEGB(f) (((f) >> 16) & 15)
+#define TTM_UG_DEGA(f) (((f) >> 24) & 15)
+#define TTM_UGF_POLY     (1 << 20)   /* group has plain polynomial terms                        */
+
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
@@ -193,12 +234,25 @@ typedef struct ttm_program {
     int32_t rectifier;          /* TTM_RECT_*                                      */
     int32_t Q;                  /* quadrature order                                */
     int32_t plan_ways;          /* ways of the planned column cache (1..TTM_PLAN_WAYS) the fints plan was made for */
-    int32_t reserved;
+    int32_t u_enabled;          /* 1: the map has a U-form (separable, all terms univariate, orders <= TTM_U_PMAX, splines
+                                   within TTM_U_NI_MAX columns): ttm_fold also writes the U section and ttm_forward /
+                                   ttm_inverse_table run the U-form kernels                                       */
     double  delta;              /* TM:34, added to the rectifier / to dS           */
+    /* U-form tables (valid when u_enabled) */
+    const int32_t* ucomp;       /* device, TTM_UC_LEN x D                            */
+    const int32_t* ugrp;        /* device, TTM_UG_LEN per group                      */
+    const double*  umono;       /* device, (TTM_U_PMAX+1)^2: row n = monomial coefficients of P_n */
+    const double*  ugeo;        /* device, 2 doubles per component {t_lo, h} of its spline        */
+    const int32_t* h_ucomp;     /* host copy of ucomp (launch planning)              */
+    const int32_t* h_ugrp;      /* host copy of ugrp                                 */
+    int64_t u_size;             /* doubles of the U section                          */
+    int64_t u_err_off;          /* offset (within the U section) of the 2 x D fit errors */
 } ttm_program;
 
 const char* ttm_last_error_string(void);
 int  ttm_version(void);
+/* sizeof(ttm_program) as the library was compiled: bindings check their mirror of the struct against it */
+int64_t ttm_program_sizeof(void);
 /* number of visible HIP devices; 0 with an error string when there is none */
 int  ttm_device_count(int* count);
 
@@ -234,6 +288,12 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
  * plus 8 doubles of read-ahead padding; the kernels load coefficients four at a time).  Call it whenever
  * the coefficients change, before ttm_forward / ttm_inverse_*.                                    */
 int64_t ttm_fold_size(const ttm_program* p);
+/* offset (doubles) of the U section inside the fold buffer; -1 when the program has no U-form.  The 2 x D fit errors
+ * {value, derivative} of the special-term splines are at fold + ttm_uform_offset(p) + p->u_err_off after ttm_fold: a
+ * host that wants the guarantee reads them back (once per special-term placement is enough in practice: the error is
+ * governed by the interval width, which the host chooses from the scales) and clears u_enabled if they exceed its
+ * tolerance - the direct kernels then run instead.                                                               */
+int64_t ttm_uform_offset(const ttm_program* p);
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream);
 
 /* ---- K2/K3: forward map ------------------------------------------------------

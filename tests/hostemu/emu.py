@@ -22,7 +22,7 @@ SRC = os.path.join(HERE, 'ttm_hostemu.cpp')
 LIB = os.path.join(HERE, 'libttm_hostemu.so')
 CSRC = os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc')
 DEPS = [SRC, os.path.join(CSRC, 'ttm_eval.h'), os.path.join(CSRC, 'ttm_math.h'), os.path.join(CSRC, 'ttm_vec.h'),
-        os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
+        os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(CSRC, 'ttm_uform.h'), os.path.join(CSRC, 'ttm_cheb_table.h'), os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
 
 _lib = None
 
@@ -85,9 +85,35 @@ class EmuMap:
     def pack(self, coeffs_nonmon, coeffs_mon):
         coef = np.ascontiguousarray(np.concatenate([np.concatenate((np.asarray(n, float), np.asarray(m, float)))
                                                     for n, m in zip(coeffs_nonmon, coeffs_mon)]))
-        self.fold = np.zeros(int(self.cm.fold_off[-1]) + 8)
-        lib().ttm_fold(self.pp, ptr(coef), ptr(self.fold), None)
+        self.attach_uform()
+        self.fold = np.zeros(int(lib().ttm_fold_size(self.pp)))
+        rc = lib().ttm_fold(self.pp, ptr(coef), ptr(self.fold), None)
+        assert rc == 0
         return coef
+
+    def attach_uform(self):
+        """U-form tables for the current special-term constants (what transport_map._refresh_uform does)."""
+        cm = self.cm
+        if not cm.u_static:
+            return
+        termtable.uform_geometry(cm)
+        if getattr(self, 'no_uform', False):
+            cm.u_enabled = False
+        self.ucomp = np.ascontiguousarray(cm.ucomp, dtype=np.int32)
+        self.ugrp = np.ascontiguousarray(cm.ugrp, dtype=np.int32)
+        self.umono = np.ascontiguousarray(cm.umono)
+        self.ugeo = np.ascontiguousarray(cm.ugeo)
+        _capi.set_uform(self.prog, cm, self.ucomp.ctypes.data, self.ugrp.ctypes.data, self.umono.ctypes.data,
+                        self.ugeo.ctypes.data)
+        self.prog.h_ucomp = self.ucomp.ctypes.data
+        self.prog.h_ugrp = self.ugrp.ctypes.data
+
+    def uform_errors(self):
+        off = int(lib().ttm_uform_offset(self.pp))
+        if off < 0:
+            return None
+        off += int(self.cm.u_err_off)
+        return self.fold[off:off + 2 * self.cm.D].reshape(-1, 2).copy()
 
     @staticmethod
     def soa(X):

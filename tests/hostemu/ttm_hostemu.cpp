@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_eval.h"
+#include "../../triangular_transport_toolbox_amd/csrc/ttm_uform.h"
 
 using namespace ttm;
 
@@ -97,12 +98,42 @@ void forward_plan(const ttm_program* p, const Prog& g, const double* fold, const
     }
 }
 
+int64_t fold_base_size_(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }
+
+// U-form forward of one "thread" (R = double or VecD<N>) through components [k0,k1)
+template <class R, class XA>
+void forward_u(const ttm_program* p, const double* fold, const XA& xa, int k0, int k1, bool want_ld, bool want_val,
+               R* S_out, R& ld, R& ss, const double* sigma) {
+    const double* U = fold + fold_base_size_(p);
+    double cbuf[8 * lanes_of<R>::value];
+    PlanCache<XA, R> x(xa, CacheStore<R>{cbuf, 1});
+    if (k0 > 0) x.warm(p->ucomp + TTM_UC_STATE(p->D, k0));
+    ld = R(0.0); ss = R(0.0);
+    const bool fixed = getenv("TTM_EMU_U_FIXED") != nullptr;      // test knob: the fixed-degree instantiation
+    for (int k = k0; k < k1; ++k) {
+        const int* uc = p->ucomp + k * TTM_UC_LEN;
+        const R xk = xa(uc[TTM_UC_KC]);
+        R S, dS;
+        if (fixed) {
+            if (want_ld) u_component<TTM_U_PMAX, TTM_U_PMAX, true>(uc, p->ugrp, U, U + uc[TTM_UC_TAB_OFF], xk, x, want_val, S, dS);
+            else u_component<TTM_U_PMAX, TTM_U_PMAX, false>(uc, p->ugrp, U, U + uc[TTM_UC_TAB_OFF], xk, x, true, S, dS);
+        } else {
+            if (want_ld) u_component<-1, -1, true>(uc, p->ugrp, U, U + uc[TTM_UC_TAB_OFF], xk, x, want_val, S, dS);
+            else u_component<-1, -1, false>(uc, p->ugrp, U, U + uc[TTM_UC_TAB_OFF], xk, x, true, S, dS);
+        }
+        if (want_ld) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
+        S_out[k - k0] = S;
+        ss = vfma(S, S, ss);
+    }
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* ttm_last_error_string(void) { return "hostemu"; }
 int ttm_version(void) { return TTM_VERSION; }
+int64_t ttm_program_sizeof(void) { return (int64_t)sizeof(ttm_program); }
 int ttm_device_count(int* count) { if (count) *count = 0; return TTM_E_HIP; }
 
 int64_t ttm_colstats_work_size(int64_t, int32_t d) { return d; }
@@ -151,19 +182,55 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     return 0;
 }
 
-int64_t ttm_fold_size(const ttm_program* p) { return p->h_fold_off[p->D] + 8; }
+static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }
+static bool u_on(const ttm_program* p) { return p->u_enabled && !getenv("TTM_NO_UFORM"); }
+
+int64_t ttm_fold_size(const ttm_program* p) { return fold_base_size(p) + (p->u_enabled ? p->u_size : 0); }
+int64_t ttm_uform_offset(const ttm_program* p) { return p->u_enabled ? fold_base_size(p) : -1; }
 
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
     for (int k = 0; k < p->D; ++k)
         fold_coeffs(p->itab + p->h_comp_off[k], p->ftab + p->h_ftab_off[k], p->dpar + p->h_dpar_off[k],
                     coef + p->h_coef_off[k], fold + p->h_fold_off[k], 0, 1);
     for (int k = 0; k < p->D; ++k) fold_st8(p->fdesc + k * TTM_FDESC_LEN, p->fints, fold + p->h_fold_off[k], 0, 1);
+    if (p->u_enabled) {                       // U-form section (csrc/ttm_uform.h), same builder as the k_uform kernel
+        double* U = fold + fold_base_size(p);
+        std::vector<double> ybuf(TTM_U_NI_MAX * TTM_CHEB_N);
+        for (int k = 0; k < p->D; ++k) {
+            const int* uc = p->ucomp + k * TTM_UC_LEN;
+            const int* fd = p->fdesc + k * TTM_FDESC_LEN;
+            const double* foldk = fold + p->h_fold_off[k];
+            const double* geo = p->ugeo + 2 * k;
+            if (uc[TTM_UC_NI] > TTM_U_NI_MAX) return TTM_E_LIMIT;
+            uform_build_groups(uc, p->ugrp, fd, p->umono, geo, foldk, U, 0, 1);
+            double ev = 0.0, ed = 0.0;
+            if (uc[TTM_UC_NI] > 0) {
+                uform_spline_nodes(uc, fd, geo, foldk, ybuf.data(), 0, 1);
+                uform_spline_fit(uc, fd, geo, foldk, ybuf.data(), U, 0, 1);
+                uform_spline_verify(uc, fd, geo, foldk, U, 0, 1, ev, ed);
+            }
+            U[p->u_err_off + 2 * k] = (ev != ev) ? INFINITY : ev;
+            U[p->u_err_off + 2 * k + 1] = (ed != ed) ? INFINITY : ed;
+        }
+    }
     return 0;
 }
 
 int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
                 int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void*) {
     const Prog g = make_prog(p);
+    if (p->monotonicity == TTM_MONO_SEPARABLE && u_on(p) && all_fast(p, k0, k1)) {     // same dispatch as the library
+        std::vector<double> S(k1 - k0);
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+            double ld, ss;
+            forward_u<double>(p, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma);
+            if (Z) for (int k = k0; k < k1; ++k) Z[(int64_t)(k - k0) * ldz + n] = S[k - k0];
+            if (logdet) logdet[n] = ld;
+            if (sumsq) sumsq[n] = ss;
+        }
+        return 0;
+    }
     if (all_fast(p, k0, k1)) {
         std::vector<double> S(k1 - k0);
         for (int64_t n = 0; n < N; ++n) {
@@ -227,6 +294,22 @@ struct XSoA2 {
 int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
                      int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet) {
     const Prog g = make_prog(p);
+    if (p->monotonicity == TTM_MONO_SEPARABLE && u_on(p) && all_fast(p, k0, k1)) {
+        std::vector<VecD<2>> S(k1 - k0);
+        for (int64_t n = 0; n < N; n += 2) {
+            const int64_t n1 = n + 1 < N ? n + 1 : n;
+            XSoA2 xa{X, ldx, n, n1};
+            VecD<2> ld, ss;
+            forward_u<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
+            for (int k = k0; k < k1; ++k) {
+                Z[(int64_t)(k - k0) * ldz + n] = S[k - k0].v[0];
+                Z[(int64_t)(k - k0) * ldz + n1] = S[k - k0].v[1];
+            }
+            logdet[n] = ld.v[0];
+            logdet[n1] = ld.v[1];
+        }
+        return 0;
+    }
     if (all_fast(p, k0, k1)) {
         std::vector<VecD<2>> S(k1 - k0);
         for (int64_t n = 0; n < N; n += 2) {

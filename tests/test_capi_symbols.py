@@ -26,8 +26,11 @@ def test_library_builds_and_exports_all_symbols():
 
 
 def test_struct_layout_matches_header():
-    # 16 pointers + 6 int32 + 1 double on LP64
-    assert ctypes.sizeof(_capi.ttm_program) == 17 * 8 + 8 * 4 + 8
+    # 17 + 6 pointers, 8 int32, 1 double, 2 int64 on LP64 - and what the library itself was compiled with
+    assert ctypes.sizeof(_capi.ttm_program) == 23 * 8 + 8 * 4 + 8 + 2 * 8
+    assert _capi.load().ttm_program_sizeof() == ctypes.sizeof(_capi.ttm_program)
+    from tests.hostemu import emu
+    assert emu.lib().ttm_program_sizeof() == ctypes.sizeof(_capi.ttm_program)
 
 
 def test_no_device_fails_loudly():

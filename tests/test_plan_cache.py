@@ -95,13 +95,23 @@ def test_planned_equals_tagged_and_partial_sweeps(name):
     coef = em.pack(non, mon)
     rng = np.random.default_rng(5)
     X = rng.standard_normal((64, cm.d_cols))
-    Zp, ldp = _run(em, coef, X)
-    os.environ['TTM_NO_PLAN'] = '1'
+    # direct kernels (U-form off): statically planned column cache == run-time tagged cache, bit for bit
+    os.environ['TTM_NO_UFORM'] = '1'
     try:
-        Zt, ldt = _run(em, coef, X)
+        Zd, ldd = _run(em, coef, X)
+        os.environ['TTM_NO_PLAN'] = '1'
+        try:
+            Zt, ldt = _run(em, coef, X)
+        finally:
+            del os.environ['TTM_NO_PLAN']
     finally:
-        del os.environ['TTM_NO_PLAN']
-    assert np.array_equal(Zp, Zt) and np.array_equal(ldp, ldt)
+        del os.environ['TTM_NO_UFORM']
+    assert np.array_equal(Zd, Zt) and np.array_equal(ldd, ldt)
+    # default dispatch (U-form when the map has one): same values to rounding, same planned cache
+    Zp, ldp = _run(em, coef, X)
+    assert np.max(np.abs(Zp - Zd) / (1 + np.abs(Zd))) < 1e-12
+    ok = np.isfinite(ldd)
+    assert np.array_equal(np.isfinite(ldp), ok) and np.max(np.abs(ldp[ok] - ldd[ok]) / (1 + np.abs(ldd[ok])), initial=0) < 1e-10
     # sweeps starting at every k0: same columns as the full sweep (the entry state is preloaded)
     for k0 in range(1, cm.D, max(1, cm.D // 7)):
         Zs, _ = _run(em, coef, X, k0, cm.D)

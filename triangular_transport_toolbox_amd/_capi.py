@@ -20,7 +20,9 @@ class ttm_program(ctypes.Structure):
     _fields_ = [('itab', c_vp), ('ftab', c_vp), ('fdesc', c_vp), ('fints', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
                 ('h_comp_off', c_vp), ('h_dpar_off', c_vp), ('h_coef_off', c_vp), ('h_nslots', c_vp), ('h_n_nm', c_vp), ('h_fold_off', c_vp), ('h_ftab_off', c_vp), ('h_nb1', c_vp), ('h_complex', c_vp), ('d_offsets', c_vp),
                 ('D', c_i32), ('d_cols', c_i32), ('family', c_i32), ('monotonicity', c_i32), ('rectifier', c_i32),
-                ('Q', c_i32), ('plan_ways', c_i32), ('reserved', c_i32), ('delta', c_dbl)]
+                ('Q', c_i32), ('plan_ways', c_i32), ('u_enabled', c_i32), ('delta', c_dbl),
+                ('ucomp', c_vp), ('ugrp', c_vp), ('umono', c_vp), ('ugeo', c_vp), ('h_ucomp', c_vp), ('h_ugrp', c_vp),
+                ('u_size', c_i64), ('u_err_off', c_i64)]
 
 
 MONO = {'integrated rectifier': 0, 'separable monotonicity': 1}
@@ -29,6 +31,7 @@ RECT = {'exponential': 0, 'softplus': 1, 'squared': 2, 'expneg': 3, 'explinearun
 _SIGNATURES = {
     'ttm_last_error_string': (ctypes.c_char_p, []),
     'ttm_version': (ctypes.c_int, []),
+    'ttm_program_sizeof': (c_i64, []),
     'ttm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'ttm_colstats_work_size': (c_i64, [c_i64, c_i32]),
     'ttm_colstats': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -37,6 +40,7 @@ _SIGNATURES = {
     'ttm_select_work_size': (c_i64, [c_i32]),
     'ttm_order_statistics': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'ttm_fold_size': (c_i64, [ctypes.POINTER(ttm_program)]),
+    'ttm_uform_offset': (c_i64, [ctypes.POINTER(ttm_program)]),
     'ttm_fold': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp]),
     'ttm_forward': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64,
                                    c_vp, c_vp, c_vp, c_vp]),
@@ -81,6 +85,9 @@ def load():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        if lib.ttm_program_sizeof() != ctypes.sizeof(ttm_program):
+            raise RuntimeError('libttm.so was built from a different include/ttm.h (struct ttm_program: %d bytes, '
+                               'binding: %d)' % (lib.ttm_program_sizeof(), ctypes.sizeof(ttm_program)))
         _lib = lib
     return _lib
 
@@ -129,4 +136,18 @@ def make_program(cm, itab_ptr, ftab_ptr, fdesc_ptr, fints_ptr, dpar_ptr, qx_ptr,
     p.Q = int(Q)
     p.plan_ways = int(cm.plan_ways)
     p.delta = float(delta)
+    p.u_enabled = 0
+    return p
+
+
+def set_uform(p, cm, ucomp_ptr, ugrp_ptr, umono_ptr, ugeo_ptr):
+    """Attach / refresh the U-form tables of a program (device pointers; the host copy of ucomp is kept alive
+    by the program object).  Called again whenever the spline geometry changes (termtable.uform_geometry)."""
+    p._keep_u = np.ascontiguousarray(cm.ucomp, dtype=np.int32)
+    p.ucomp, p.ugrp, p.umono, p.ugeo = ucomp_ptr, ugrp_ptr, umono_ptr, ugeo_ptr
+    p._keep_g = np.ascontiguousarray(cm.ugrp, dtype=np.int32)
+    p.h_ucomp = p._keep_u.ctypes.data
+    p.h_ugrp = p._keep_g.ctypes.data
+    p.u_size, p.u_err_off = int(cm.u_size), int(cm.u_err_off)
+    p.u_enabled = 1 if cm.u_enabled else 0
     return p

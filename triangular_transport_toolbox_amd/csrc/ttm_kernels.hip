@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include "ttm_eval.h"
+#include "ttm_uform.h"
 
 using namespace ttm;
 
@@ -484,6 +485,212 @@ __global__ __launch_bounds__(256) void k_forward_plan(DevProg P, int k0, int k1,
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// U-form (csrc/ttm_uform.h): builder and forward kernel
+// ---------------------------------------------------------------------------
+
+struct UTabs {               // by-value kernel argument
+    const int* ucomp;
+    const int* ugrp;
+    const double* umono;
+    const double* ugeo;
+};
+
+// one workgroup per component: monomial coefficients of the groups, spline of the summed special terms, fit check
+__global__ __launch_bounds__(256) void k_uform(DevProg P, UTabs T, const double* __restrict__ fold, double* __restrict__ U,
+                                               int64_t err_off) {
+    __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
+    __shared__ double red[2][4];
+    const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
+    const int D1 = P.D + 1;
+    const int* uc = T.ucomp + k * TTM_UC_LEN;
+    const int* fd = P.fdesc + k * TTM_FDESC_LEN;
+    const double* foldk = fold + P.off[3 * D1 + k];
+    const double* geo = T.ugeo + 2 * k;
+    uform_build_groups(uc, T.ugrp, fd, T.umono, geo, foldk, U, tid, bd);
+    double ev = 0.0, ed = 0.0;
+    if (uc[TTM_UC_NI] > 0) {
+        uform_spline_nodes(uc, fd, geo, foldk, ybuf, tid, bd);
+        __syncthreads();
+        uform_spline_fit(uc, fd, geo, foldk, ybuf, U, tid, bd);
+        __syncthreads();
+        uform_spline_verify(uc, fd, geo, foldk, U, tid, bd, ev, ed);
+    }
+    if (ev != ev) ev = INFINITY;
+    if (ed != ed) ed = INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ev = fmax(ev, __shfl_down(ev, off, 64));
+        ed = fmax(ed, __shfl_down(ed, off, 64));
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = ev; red[1][tid >> 6] = ed; }
+    __syncthreads();
+    if (tid == 0) {
+        const int nw = bd >> 6;
+        for (int w = 1; w < nw; ++w) { ev = fmax(ev, red[0][w]); ed = fmax(ed, red[1][w]); }
+        U[err_off + 2 * k] = ev;
+        U[err_off + 2 * k + 1] = ed;
+    }
+}
+
+// NS rows of one thread inside the current tile (32-bit row numbers: the column base stays a scalar pointer and
+// every access is `global_load_dwordx2 v, v_off, s[base]`)
+template <int NS>
+struct XRowsN {
+    typedef typename real_of<NS>::type R;
+    const double* X;
+    int64_t ld;
+    unsigned int n[NS];
+    __device__ __forceinline__ R operator()(int var) const {
+        const double* col = X + (int64_t)var * ld;
+        R r;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) set_elem(r, e, col[n[e]]);
+        return r;
+    }
+};
+
+typedef double D2 __attribute__((ext_vector_type(2)));      // 16-byte staging unit of the spline tables
+
+// rows of one thread as BYTE offsets into a column (32-bit): every access is `global_load_dwordx2 v, v_off, s[base]`
+template <int NS>
+struct XOffN {
+    typedef typename real_of<NS>::type R;
+    const char* X;
+    int64_t ldb;                 // column stride in bytes
+    unsigned int off[NS];
+    __device__ __forceinline__ R operator()(int var) const {
+        const char* col = X + (int64_t)var * ldb;
+        R r;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) set_elem(r, e, *(const double*)(col + off[e]));
+        return r;
+    }
+};
+
+// Forward map in U-form.  The workgroup walks a flat sequence of steps (tile, component).  While step s is
+// evaluated, the x_k column and the spline table of step s + 1 are in flight to registers; the table is written
+// to the other LDS buffer at the end of the step: one barrier per step, no pipeline drain at tile boundaries.
+// DB / DA: Horner degrees of the Hermite-function / plain part of every nonmonotone group (-1: per group).
+// LDS: [table buffer 0 | table buffer 1 | column cache (2 x ways x NS x blockDim)]
+template <bool WANT_LD, int NS, int DB, int DA>
+__global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
+                                                   const double* __restrict__ U_, int D, int k0, int k1,
+                                                   const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                   double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
+                                                   const double* __restrict__ sigma, double* __restrict__ sumsq, int tab_cap) {
+    typedef typename real_of<NS>::type R;
+    cint_p ucomp = (cint_p)ucomp_;
+    cint_p ugrp = (cint_p)ugrp_;
+    cdbl_p U = (cdbl_p)U_;
+    const int bd = blockDim.x, tid = threadIdx.x;
+    const int ncomp = k1 - k0;
+    const int64_t rpt = (int64_t)NS * bd;
+    const int64_t ntiles = (N + rpt - 1) / rpt;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    const int64_t S = ((ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) * ncomp;
+    double* tabbuf = g_smem;
+    CacheStore<R> cst;
+    cst.base = g_smem + 2 * (size_t)tab_cap + tid;
+    cst.stride = bd;
+    const bool want_val = (Z != nullptr) || (sumsq != nullptr);
+
+    XOffN<NS> cx;                // rows of the tile being evaluated
+    cx.X = (const char*)X; cx.ldb = ldx * 8;
+    bool act[NS];
+    int64_t ctile = blockIdx.x;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+        const int64_t n = ctile * rpt + (int64_t)e * bd + tid;
+        act[e] = n < N;
+        cx.off[e] = (unsigned int)(act[e] ? n : N - 1) * 8u;
+    }
+    // first column, first table
+    R xk_next = cx(ucomp[k0 * TTM_UC_LEN + TTM_UC_KC]);
+    {
+        const int n16 = (TTM_U_TSTRIDE / 2) * ucomp[k0 * TTM_UC_LEN + TTM_UC_NI];
+        const D2* src = (const D2*)(U_ + ucomp[k0 * TTM_UC_LEN + TTM_UC_TAB_OFF]);
+        D2* dst = (D2*)tabbuf;
+        for (int i = tid; i < n16; i += bd) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    int k = k0;
+    R ld(0.0), ss(0.0);
+    for (int64_t s = 0; s < S; ++s) {
+        cint_p uc = ucomp + k * TTM_UC_LEN;
+        const R xk = xk_next;
+        // next step: component, rows, its column and its spline table
+        const bool wrap = (k + 1 == k1);
+        const int knext = wrap ? k0 : k + 1;
+        const bool has_next = s + 1 < S;
+        XOffN<NS> nx = cx;
+        bool nact[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) nact[e] = act[e];
+        if (wrap) {
+            const int64_t t2 = ctile + gridDim.x;
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                const int64_t n = t2 * rpt + (int64_t)e * bd + tid;
+                nact[e] = n < N;
+                nx.off[e] = (unsigned int)(nact[e] ? n : N - 1) * 8u;
+            }
+        }
+        cint_p ucn = ucomp + knext * TTM_UC_LEN;
+        const int n16 = has_next ? (TTM_U_TSTRIDE / 2) * ucn[TTM_UC_NI] : 0;
+        // (every lane loads, with a clamped index, inside uniform branches: the values stay in registers and the
+        // loads stay asynchronous; a per-lane predicate here makes the compiler park them in scratch)
+        const D2* tsrc = (const D2*)(U_ + ucn[TTM_UC_TAB_OFF]);
+        D2 stg0 = {0.0, 0.0}, stg1 = {0.0, 0.0}, stg2 = {0.0, 0.0}, stg3 = {0.0, 0.0};
+        if (n16 > 0) stg0 = tsrc[min(tid, n16 - 1)];
+        if (n16 > bd) stg1 = tsrc[min(tid + bd, n16 - 1)];
+        if (n16 > 2 * bd) stg2 = tsrc[min(tid + 2 * bd, n16 - 1)];
+        if (n16 > 3 * bd) stg3 = tsrc[min(tid + 3 * bd, n16 - 1)];
+        if (has_next) xk_next = nx(ucn[TTM_UC_KC]);
+
+        PlanCache<XOffN<NS>, R> x(cx, cst);
+        if (k == k0) {
+            ld = R(0.0); ss = R(0.0);
+            if (k0 > 0) x.warm(ucomp + TTM_UC_STATE(D, k0));
+        }
+        const double* tab = tabbuf + (size_t)(s & 1) * tab_cap;
+        R Sv, dS;
+        u_component<DB, DA, WANT_LD>(uc, ugrp, U, tab, xk, x, WANT_LD ? want_val : true, Sv, dS);
+        if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+        // staged table -> the other buffer (its last readers passed the previous barrier); before the stores of
+        // this step so that waiting for the table loads does not wait for the stores
+        D2* tdst = (D2*)(tabbuf + (size_t)((s + 1) & 1) * tab_cap);
+        if (tid < n16) tdst[tid] = stg0;
+        if (tid + bd < n16) tdst[tid + bd] = stg1;
+        if (tid + 2 * bd < n16) tdst[tid + 2 * bd] = stg2;
+        if (tid + 3 * bd < n16) tdst[tid + 3 * bd] = stg3;
+        if (Z) {
+            char* zc = (char*)(Z + (int64_t)(k - k0) * ldz);
+#pragma unroll
+            for (int e = 0; e < NS; ++e)
+                if (act[e]) *(double*)(zc + cx.off[e]) = elem(Sv, e);
+        }
+        ss = vfma(Sv, Sv, ss);
+        if (wrap) {
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                if (act[e]) {
+                    if (WANT_LD) *(double*)((char*)logdet + cx.off[e]) = elem(ld, e);
+                    if (sumsq) *(double*)((char*)sumsq + cx.off[e]) = elem(ss, e);
+                }
+            }
+            ctile += gridDim.x;
+        }
+        __syncthreads();
+        k = knext;
+        cx = nx;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) act[e] = nact[e];
+    }
+}
+
 // basis matrices of one component
 __global__ __launch_bounds__(256) void k_basis(DevProg P, int k, int which, const double* __restrict__ X, int64_t ldx,
                                                int64_t N, double* __restrict__ out, int64_t ldo) {
@@ -879,6 +1086,8 @@ const char* ttm_last_error_string(void) { return g_err; }
 
 int ttm_version(void) { return TTM_VERSION; }
 
+int64_t ttm_program_sizeof(void) { return (int64_t)sizeof(ttm_program); }
+
 int ttm_device_count(int* count) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -941,13 +1150,32 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     return check_launch("k_select");
 }
 
-int64_t ttm_fold_size(const ttm_program* p) { return (p && p->h_fold_off) ? p->h_fold_off[p->D] + 8 : -1; }   // + read-ahead padding
+static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }   // + read-ahead padding, even
+
+static bool u_on(const ttm_program* p) {
+    return p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo && p->h_ucomp && p->h_ugrp && !getenv("TTM_NO_UFORM");
+}
+
+int64_t ttm_fold_size(const ttm_program* p) {
+    if (!p || !p->h_fold_off) return -1;
+    return fold_base_size(p) + (p->u_enabled ? p->u_size : 0);
+}
+
+int64_t ttm_uform_offset(const ttm_program* p) { return (p && p->h_fold_off && p->u_enabled) ? fold_base_size(p) : -1; }
 
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream) {
     int rc = validate(p, 0, p ? p->D : 0);
     if (rc) return rc;
     if (!coef || !fold) return set_err(TTM_E_ARG, "ttm_fold: bad arguments%s");
     hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
+    if (p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo) {
+        for (int k = 0; k < p->D; ++k)
+            if (p->h_ucomp && p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > TTM_U_NI_MAX)
+                return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
+        const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
+        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(256), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
+                           fold + fold_base_size(p), (int64_t)p->u_err_off);
+    }
     return check_launch("k_fold");
 }
 
@@ -967,6 +1195,50 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const int bd = pick_block(nsl, 0, NS);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_forward: %s%lld scratch slots per sample do not fit the LDS budget", "", nsl);
     const bool sep = p->monotonicity == TTM_MONO_SEPARABLE;
+    if (sep && u_on(p) && all_fast(p, k0, k1) && N < ((int64_t)1 << 29)) {
+        // U-form: monomial groups + special-term splines staged per component in LDS
+        int tab_cap = 0;
+        for (int k = k0; k < k1; ++k) {
+            const int c = TTM_U_TSTRIDE * p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI];
+            tab_cap = c > tab_cap ? c : tab_cap;
+        }
+        int ways = p->plan_ways;
+        if (ways < 1 || ways > TTM_PLAN_WAYS) ways = TTM_PLAN_WAYS;
+        int uNS = N >= 2 * 256 * 256 ? 2 : 1;
+        if (const char* e = getenv("TTM_U_NS")) uNS = atoi(e);
+        if (uNS != 1 && uNS != 2 && uNS != 4) uNS = 2;
+        const int ubd = 256;
+        const size_t lds = ((size_t)2 * tab_cap + (size_t)2 * ways * uNS * ubd) * 8;
+        if (lds <= (size_t)kLdsBudget) {
+            typedef void (*ukern_t)(const int*, const int*, const double*, int, int, int, const double*, int64_t, int64_t, double*,
+                                    int64_t, double*, const double*, double*, int);
+            // Horner degrees of the nonmonotone groups in this launch -> smallest fixed-degree instantiation
+            int mb = 0, ma = 0;
+            for (int k = k0; k < k1; ++k) {
+                const int* uc = p->h_ucomp + k * TTM_UC_LEN;
+                for (int g = 0; g < uc[TTM_UC_N_GRP]; ++g) {
+                    const int fl = p->h_ugrp[(uc[TTM_UC_GRP_OFF] + g) * TTM_UG_LEN + TTM_UG_FLAGS];
+                    if ((fl & TTM_PLAN_HF) && TTM_UG_DEGB(fl) > mb) mb = TTM_UG_DEGB(fl);
+                    if ((fl & TTM_UGF_POLY) && TTM_UG_DEGA(fl) > ma) ma = TTM_UG_DEGA(fl);
+                }
+            }
+            const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
+            if (getenv("TTM_U_GENERIC_DEG")) { /* tuning knob: per-group degrees */ }
+#define TTM_UK(L, NSV) (cls == 0 ? k_forward_u<L, NSV, 3, 1> : cls == 1 ? k_forward_u<L, NSV, 5, 5> : k_forward_u<L, NSV, 7, 7>)
+            ukern_t uk = logdet ? (uNS == 4 ? TTM_UK(true, 4) : uNS == 2 ? TTM_UK(true, 2) : TTM_UK(true, 1))
+                                : (uNS == 4 ? TTM_UK(false, 4) : uNS == 2 ? TTM_UK(false, 2) : TTM_UK(false, 1));
+#undef TTM_UK
+            int wgs_per_cu = (int)((size_t)(160 * 1024) / (lds ? lds : 1));
+            if (wgs_per_cu > 8) wgs_per_cu = 8;
+            if (wgs_per_cu < 1) wgs_per_cu = 1;
+            if (const char* e = getenv("TTM_U_WGS")) wgs_per_cu = atoi(e) > 0 ? atoi(e) : wgs_per_cu;
+            int64_t tiles = (N + (int64_t)uNS * ubd - 1) / ((int64_t)uNS * ubd);
+            int64_t grid = tiles < (int64_t)256 * wgs_per_cu ? tiles : (int64_t)256 * wgs_per_cu;
+            hipLaunchKernelGGL(uk, dim3((unsigned)grid), dim3(ubd), lds, (hipStream_t)stream, p->ucomp, p->ugrp,
+                               fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, tab_cap);
+            return check_launch("k_forward_u");
+        }
+    }
     if (all_fast(p, k0, k1)) {
         typedef void (*pkern_t)(DevProg, int, int, const double*, const double*, int64_t, int64_t, double*, int64_t, double*,
                                 const double*, double*);

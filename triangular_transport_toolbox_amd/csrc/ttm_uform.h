@@ -1,0 +1,363 @@
+// ttm_uform.h - the "univariate form" (U-form) of a separable transport map and its evaluators.
+//
+// For a separable map whose terms are all univariate (no cross terms; TM:2554-2558 with the basis of
+// TM:905-1026, 1096-1150) every component is a sum of functions of ONE variable each:
+//
+//     S_k(x) = c0_k + sum_{groups (k,j)} f_kj(x_j) + own_k(x_k) + G_k(x_k)
+//
+//   f_kj(x) = A(x) + exp(-x^2/4) B(x)   the nonmonotone terms on column j: A collects the plain polynomial terms,
+//                                       B the Hermite-function terms (a_n folded in), both as MONOMIAL coefficients
+//                                       (degree <= TTM_U_PMAX), so a group costs one Horner pass instead of a
+//                                       three-term recurrence plus per-order weights;
+//   own_k    the same form for polynomial / Hermite-function terms of the monotone list (on x_k);
+//   G_k(t)   the weighted sum of the component's special terms (LET / RET / RBF / iRBF).  Each of them needs an erf
+//            and a Gaussian; their SUM is one smooth univariate function, linear outside the support of its terms.
+//            It is compiled, whenever the coefficients change, into a piecewise polynomial: uniform intervals of
+//            width h <= kappa * (smallest scale), degree 11 interpolation at Chebyshev nodes, exact linear tails.
+//            Evaluating it costs one index computation, 12 table reads and 11 FMAs whatever the number of special
+//            terms - the forward map of BASELINE config C5 goes from ~300 to ~60 fp64 instructions per
+//            component evaluation.  The fit is verified when it is built (max error against the direct
+//            evaluation at the extrema of T_12, value and derivative) and the host falls back to the direct
+//            kernels when the error exceeds its tolerance.
+//
+// The builder (`uform_*`, run by ttm_fold after the folded coefficients) and the per-sample evaluators live here
+// as host/device inline functions: the HIP kernels wrap them with LDS staging, tests/hostemu runs the same bodies
+// on the host.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/ttm.h"
+#include "ttm_cheb_table.h"
+#include "ttm_eval.h"
+
+namespace ttm {
+
+#if defined(__HIPCC__)
+__device__ const double g_cheb_nodes[TTM_CHEB_N] = { TTM_CHEB_NODES };
+__device__ const double g_cheb_vinv_hi[TTM_CHEB_N * TTM_CHEB_N] = { TTM_CHEB_VINV_HI };
+__device__ const double g_cheb_vinv_lo[TTM_CHEB_N * TTM_CHEB_N] = { TTM_CHEB_VINV_LO };
+#endif
+static const double h_cheb_nodes[TTM_CHEB_N] = { TTM_CHEB_NODES };
+static const double h_cheb_vinv_hi[TTM_CHEB_N * TTM_CHEB_N] = { TTM_CHEB_VINV_HI };
+static const double h_cheb_vinv_lo[TTM_CHEB_N * TTM_CHEB_N] = { TTM_CHEB_VINV_LO };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TTM_CHEB_NODE(m) g_cheb_nodes[m]
+#define TTM_CHEB_VH(i) g_cheb_vinv_hi[i]
+#define TTM_CHEB_VL(i) g_cheb_vinv_lo[i]
+#else
+#define TTM_CHEB_NODE(m) h_cheb_nodes[m]
+#define TTM_CHEB_VH(i) h_cheb_vinv_hi[i]
+#define TTM_CHEB_VL(i) h_cheb_vinv_lo[i]
+#endif
+
+static_assert(TTM_CHEB_DEG == TTM_U_DEG, "spline degree");
+
+// ---------------------------------------------------------------------------
+// builder
+// ---------------------------------------------------------------------------
+
+// value and d/dt of G(t) = sum of the unified special-term records {centre, 1/(sqrt2 scale), A1, B0, B1, G, DG, DT}
+// (include/ttm.h, TTM_FD_ST8), with the library erf / exp: this is the function the spline interpolates
+TTM_HD void u_st_direct(const double* rec, int n_st, double t, double& v, double& dv) {
+    double a = 0.0, da = 0.0;
+    for (int s = 0; s < n_st; ++s) {
+        const double* r = rec + 8 * s;
+        const double d = t - r[0];
+        const double tt = d * r[1];
+        const double e = erf(tt);
+        const double gs = exp(-(tt * tt));
+        const double hh = fma(r[4], e, r[3]);
+        a += r[2] * e + d * hh + r[5] * gs;
+        da += hh + fma(tt, r[7], r[6]) * gs;
+    }
+    v = a; dv = da;
+}
+
+// asymptotes: G(t) -> icpt + slope * t for t below (side = -1) / above (side = +1) the support of every term
+TTM_HD void u_st_tail(const double* rec, int n_st, int side, double& icpt, double& slope) {
+    double ic = 0.0, sl = 0.0;
+    for (int s = 0; s < n_st; ++s) {
+        const double* r = rec + 8 * s;
+        const double hh = r[3] + side * r[4];
+        ic += side * r[2] - r[0] * hh;
+        sl += hh;
+    }
+    icpt = ic; slope = sl;
+}
+
+// header doubles and monomial coefficients of the groups of one component.
+//   uc: the component's TTM_UC record, ug: all group records, umono: TTM_U_PMAX+1 rows of monomial coefficients
+//   (row n = P_n), foldk: the component's folded coefficients, fd: its fast-path descriptor, geo: {t_lo, h}
+TTM_HD void uform_build_groups(const int* uc, const int* ug, const int* fd, const double* umono, const double* geo,
+                               const double* foldk, double* U, int first, int stride) {
+    const int ng = uc[TTM_UC_N_GRP] + (uc[TTM_UC_FLAGS] & TTM_UCF_OWN ? 1 : 0);
+    double* cd = U + uc[TTM_UC_DBL_OFF];
+    const int* g0 = ug + TTM_UG_LEN * uc[TTM_UC_GRP_OFF];
+    for (int idx = first; idx < ng * 16; idx += stride) {
+        const int g = idx >> 4, j = idx & 15, deg = j & 7;
+        const int* G = g0 + TTM_UG_LEN * g;
+        const int src = (j < 8) ? G[TTM_UG_SRCB] : G[TTM_UG_SRCA];
+        const int P = (j < 8) ? G[TTM_UG_PB] : G[TTM_UG_PA];
+        double acc = 0.0;
+        if (src >= 0)
+            for (int n = 1; n <= P; ++n) acc = fma(foldk[src + n - 1], umono[n * (TTM_U_PMAX + 1) + deg], acc);
+        cd[4 + idx] = acc;
+    }
+    if (first == 0) {
+        cd[0] = foldk[0] + foldk[fd[TTM_FD_ST8]];
+        const double h = geo[1];
+        cd[1] = uc[TTM_UC_NI] ? -geo[0] / h : 0.0;
+        cd[2] = uc[TTM_UC_NI] ? 1.0 / h : 0.0;
+        cd[3] = uc[TTM_UC_NI] ? 2.0 / h : 0.0;
+    }
+}
+
+// phase 1 of the spline: G at the Chebyshev nodes of every interior interval -> ybuf[interval * 12 + node]
+TTM_HD void uform_spline_nodes(const int* uc, const int* fd, const double* geo, const double* foldk, double* ybuf,
+                               int first, int stride) {
+    const int n_int = uc[TTM_UC_NI] - 2;
+    const double* rec = foldk + fd[TTM_FD_ST8] + 8;
+    const int n_st = fd[TTM_FD_N_ST];
+    const double t_lo = geo[0], h = geo[1];
+    for (int idx = first; idx < n_int * TTM_CHEB_N; idx += stride) {
+        const int i = idx / TTM_CHEB_N, m = idx % TTM_CHEB_N;
+        const double t = t_lo + ((double)i + 0.5 + 0.5 * TTM_CHEB_NODE(m)) * h;
+        double v, dv;
+        u_st_direct(rec, n_st, t, v, dv);
+        ybuf[idx] = v;
+    }
+}
+
+// phase 2: monomial coefficients in the local coordinate s in [-1,1] of every interval (double-double
+// accumulation of VINV . y), plus the two tail columns (exactly linear in s)
+TTM_HD void uform_spline_fit(const int* uc, const int* fd, const double* geo, const double* foldk, const double* ybuf,
+                             double* U, int first, int stride) {
+    const int nI = uc[TTM_UC_NI], n_int = nI - 2;
+    double* tab = U + uc[TTM_UC_TAB_OFF];
+    for (int idx = first; idx < n_int * TTM_CHEB_N; idx += stride) {
+        const int i = idx / TTM_CHEB_N, j = idx % TTM_CHEB_N;
+        const double* y = ybuf + i * TTM_CHEB_N;
+        double sh = 0.0, sl = 0.0;
+        for (int m = 0; m < TTM_CHEB_N; ++m) {
+            const double vh = TTM_CHEB_VH(j * TTM_CHEB_N + m), vl = TTM_CHEB_VL(j * TTM_CHEB_N + m);
+            const double p = vh * y[m];
+            const double pe = fma(vh, y[m], -p) + vl * y[m];
+            const double s = sh + p;
+            const double bb = s - sh;
+            const double se = (sh - (s - bb)) + (p - bb);
+            sh = s;
+            sl += se + pe;
+        }
+        tab[(i + 1) * TTM_U_TSTRIDE + j] = sh + sl;
+    }
+    // tails: column 0 is centred at t_lo - h/2, column nI-1 at t_hi + h/2; t - centre = s h / 2
+    const double* rec = foldk + fd[TTM_FD_ST8] + 8;
+    const int n_st = fd[TTM_FD_N_ST];
+    for (int idx = first; idx < 2 * TTM_U_TSTRIDE; idx += stride) {
+        const int side = idx / TTM_U_TSTRIDE, j = idx % TTM_U_TSTRIDE;
+        double ic, sl;
+        u_st_tail(rec, n_st, side ? 1 : -1, ic, sl);
+        const double h = geo[1];
+        const double centre = side ? geo[0] + ((double)n_int + 0.5) * h : geo[0] - 0.5 * h;
+        const double v = j == 0 ? fma(sl, centre, ic) : (j == 1 ? sl * (0.5 * h) : 0.0);
+        tab[(side ? nI - 1 : 0) * TTM_U_TSTRIDE + j] = v;
+    }
+    for (int idx = first; idx < n_int * (TTM_U_TSTRIDE - TTM_CHEB_N); idx += stride)      // padding of the interior columns
+        tab[(idx / (TTM_U_TSTRIDE - TTM_CHEB_N) + 1) * TTM_U_TSTRIDE + TTM_CHEB_N + idx % (TTM_U_TSTRIDE - TTM_CHEB_N)] = 0.0;
+}
+
+// one column of the spline at local coordinate s: value and d/ds
+TTM_HD void u_spline_column(const double* col, double s, double& p, double& dp) {
+    double a = col[TTM_U_DEG], da = 0.0;
+    for (int j = TTM_U_DEG - 1; j >= 0; --j) {
+        da = fma(da, s, a);
+        a = fma(a, s, col[j]);
+    }
+    p = a; dp = da;
+}
+
+// phase 3: largest error of the fit against the direct evaluation, value and derivative, relative to 1 + |exact|,
+// probed at the extrema of T_12 of every interior interval and one interval into each tail.
+TTM_HD void uform_spline_verify(const int* uc, const int* fd, const double* geo, const double* foldk, const double* U,
+                                int first, int stride, double& err_v, double& err_d) {
+    const int nI = uc[TTM_UC_NI], n_int = nI - 2;
+    const double* tab = U + uc[TTM_UC_TAB_OFF];
+    const double* rec = foldk + fd[TTM_FD_ST8] + 8;
+    const int n_st = fd[TTM_FD_N_ST];
+    const double t_lo = geo[0], h = geo[1];
+    double ev = 0.0, ed = 0.0;
+    const int NP = TTM_CHEB_N + 1;
+    for (int idx = first; idx < nI * NP; idx += stride) {
+        const int col = idx / NP, q = idx % NP;
+        const double s = cos(3.14159265358979323846 * (double)q / (double)TTM_CHEB_N);
+        const double t = t_lo + ((double)(col - 1) + 0.5 + 0.5 * s) * h;
+        double v, dv, p, dp;
+        u_st_direct(rec, n_st, t, v, dv);
+        u_spline_column(tab + col * TTM_U_TSTRIDE, s, p, dp);
+        dp *= 2.0 / h;
+        const double a = fabs(p - v) / (1.0 + fabs(v)), b = fabs(dp - dv) / (1.0 + fabs(dv));
+        ev = (a > ev || a != a) ? a : ev;
+        ed = (b > ed || b != b) ? b : ed;
+    }
+    err_v = ev; err_d = ed;
+}
+
+// ---------------------------------------------------------------------------
+// evaluators (R = double or VecD<N>)
+// ---------------------------------------------------------------------------
+
+TTM_HD double vfloor(double a) { return floor(a); }
+template <int N> TTM_HD VecD<N> vfloor(const VecD<N>& a) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = floor(a.v[i]);
+    return r;
+}
+
+// Horner pass over P+1 uniform coefficients: value and (DER) derivative
+template <int P, bool DER, class R>
+TTM_HD void u_horner_fixed(cdbl_p c, const R& x, R& v, R& dv) {
+    double k[P + 1];
+#pragma unroll
+    for (int j = 0; j <= P; ++j) k[j] = c[j];
+    R a(k[P]), da(0.0);
+#pragma unroll
+    for (int j = P - 1; j >= 0; --j) {
+        if (DER) da = vfma(da, x, a);
+        a = vfma(a, x, k[j]);
+    }
+    v = a; dv = da;
+}
+
+template <bool DER, class R>
+TTM_HD void u_horner(int P, cdbl_p c, const R& x, R& v, R& dv) {
+    switch (P) {
+        case 1: u_horner_fixed<1, DER>(c, x, v, dv); break;
+        case 2: u_horner_fixed<2, DER>(c, x, v, dv); break;
+        case 3: u_horner_fixed<3, DER>(c, x, v, dv); break;
+        case 4: u_horner_fixed<4, DER>(c, x, v, dv); break;
+        case 5: u_horner_fixed<5, DER>(c, x, v, dv); break;
+        case 6: u_horner_fixed<6, DER>(c, x, v, dv); break;
+        default: u_horner_fixed<7, DER>(c, x, v, dv); break;
+    }
+}
+
+// Horner pass of compile-time degree DEG (>= 0) or of the run-time degree P (DEG < 0)
+template <int DEG, bool DER, class R>
+TTM_HD void u_poly(int P, cdbl_p c, const R& x, R& v, R& dv) {
+    if (DEG >= 0) u_horner_fixed<(DEG >= 0 ? DEG : 0), DER>(c, x, v, dv);
+    else u_horner<DER>(P, c, x, v, dv);
+}
+
+// sum of the nonmonotone groups of a component (constant c0 included).
+// DB / DA >= 0: every group is evaluated with these degrees (coefficients beyond a group's own degree are zero in
+// the U section), no run-time dispatch; < 0: per-group degrees from the flag word.
+// A group whose column and (for Hermite-function terms) exp(-x^2/4) are in the planned cache - every group of a
+// full sweep over columns produced by the sweep itself - takes the two-read fast path.
+template <int DB, int DA, class R, class Fetch>
+TTM_HD R u_nonmon(cint_p uc, cint_p ug_all, cdbl_p U, Fetch& x) {
+    cdbl_p cd = U + uc[TTM_UC_DBL_OFF];
+    const int n_grp = uc[TTM_UC_N_GRP];
+    cint_p ug = ug_all + TTM_UG_LEN * uc[TTM_UC_GRP_OFF];
+    R s(cd[0]);
+    for (int g = 0; g < n_grp; ++g) {
+        const int var = ug[TTM_UG_LEN * g + TTM_UG_VAR], fl = ug[TTM_UG_LEN * g + TTM_UG_FLAGS];
+        cdbl_p rec = cd + 4 + 16 * g;
+        R xv, e(0.0), v, dv;
+        if ((fl & (TTM_PLAN_HF | TTM_PLAN_XHIT | TTM_PLAN_EHIT)) == (TTM_PLAN_HF | TTM_PLAN_XHIT | TTM_PLAN_EHIT)) {
+            const int slot = TTM_PLAN_SLOT(fl);
+            xv = x.st.get(2 * slot);
+            e = x.st.get(2 * slot + 1);
+        } else {
+            x.fetch(var, fl, xv, e);
+        }
+        if (fl & TTM_PLAN_HF) {
+            u_poly<DB, false>(TTM_UG_DEGB(fl), rec, xv, v, dv);
+            s = vfma(e, v, s);
+        }
+        if (fl & TTM_UGF_POLY) {
+            u_poly<DA, false>(TTM_UG_DEGA(fl), rec + 8, xv, v, dv);
+            s = s + v;
+        }
+    }
+    return s;
+}
+
+// polynomial / Hermite-function terms of the monotone list (functions of x_k): value and derivative;
+// ek = exp(-x_k^2/4) (only read when the group has Hermite-function terms)
+template <bool DER, class R>
+TTM_HD void u_own(cint_p uc, cint_p ug_all, cdbl_p U, const R& xk, const R& ek, R& m, R& dm) {
+    const int g = uc[TTM_UC_N_GRP];
+    cint_p G = ug_all + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + g);
+    cdbl_p rec = U + uc[TTM_UC_DBL_OFF] + 4 + 16 * g;
+    const int fl = G[TTM_UG_FLAGS];
+    R v, dv;
+    if (fl & TTM_PLAN_HF) {
+        u_horner<DER>(TTM_UG_DEGB(fl), rec, xk, v, dv);
+        m = vfma(ek, v, m);
+        if (DER) dm = vfma(ek, vfma(-0.5 * xk, v, dv), dm);      // d/dx [e^{-x^2/4} B] = e^{-x^2/4} (B' - x B / 2)
+    }
+    if (fl & TTM_UGF_POLY) {
+        u_horner<DER>(TTM_UG_DEGA(fl), rec + 8, xk, v, dv);
+        m = m + v;
+        if (DER) dm = dm + dv;
+    }
+}
+
+// the special-term spline at t: value and d/dt.  tab: the component's table ([column][TTM_U_TSTRIDE]), nI columns
+template <bool DER, class R>
+TTM_HD void u_spline(const double* tab, int nI, double sp_a, double sp_b, double sp_ds, const R& t, R& g, R& dg) {
+    const R u = vfma(t, sp_b, sp_a);                         // (t - t_lo) / h
+    const R fl = vfloor(vmin(vmax(u, -1.0), (double)(nI - 2)));
+    const R s = vfma(2.0, u - fl, -1.0);                     // local coordinate; unbounded in the (linear) tails
+    const typename int_of<R>::type col = vtoint(fl);
+    R p, dp(0.0);
+#pragma unroll
+    for (int e = 0; e < lanes_of<R>::value; ++e) {
+        const double* c = tab + (ielem(col, e) + 1) * TTM_U_TSTRIDE;
+        const double se = elem(s, e);
+        double a = c[TTM_U_DEG], da = 0.0;
+#pragma unroll
+        for (int j = TTM_U_DEG - 1; j >= 0; --j) {
+            if (DER) da = fma(da, se, a);
+            a = fma(a, se, c[j]);
+        }
+        set_elem(p, e, a);
+        set_elem(dp, e, da);
+    }
+    g = p;
+    dg = DER ? dp * sp_ds : dp;
+}
+
+// S_k and dS_k/dx_k of one component in U-form; afterwards x_k (and exp(-x_k^2/4) when a later group reads it)
+// goes into its planned cache slot.  x: a PlanCache.
+template <int DB, int DA, bool DER, class R, class Fetch>
+TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, const R& xk, Fetch& x, bool want_value,
+                        R& S, R& dS) {
+    const int flags = uc[TTM_UC_FLAGS], nI = uc[TTM_UC_NI], slot = uc[TTM_UC_KC_SLOT];
+    const bool own = flags & TTM_UCF_OWN;
+    const bool own_hf = own && ((ug_all + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + uc[TTM_UC_N_GRP]))[TTM_UG_FLAGS] & TTM_PLAN_HF);
+    const bool put_e = (flags & TTM_UCF_PUT_E) && slot >= 0;
+    R ek(0.0);
+    if (put_e || own_hf) ek = fast_exp(-0.25 * (xk * xk));
+    R m(0.0), dm(0.0);
+    if (own) u_own<DER>(uc, ug_all, U, xk, ek, m, dm);
+    if (nI > 0) {
+        cdbl_p cd = U + uc[TTM_UC_DBL_OFF];
+        R g, dg;
+        u_spline<DER>(tab, nI, cd[1], cd[2], cd[3], xk, g, dg);
+        m = m + g;
+        if (DER) dm = dm + dg;
+    }
+    S = want_value ? u_nonmon<DB, DA, R>(uc, ug_all, U, x) + m : m;
+    dS = dm;
+    if (slot >= 0) {
+        x.st.set(2 * slot, xk);
+        if (put_e) x.st.set(2 * slot + 1, ek);
+    }
+}
+
+}  // namespace ttm

@@ -343,7 +343,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     itab, dpar = [], []
     comp_off, dpar_off, coef_off, fold_off, ftab_off = [0], [0], [0], [0], [0]
     ftab, fdesc, fints = [], [], []
-    plan_seq, complex_all = [], []
+    plan_seq, complex_all, u_info = [], [], []
     nslots, nb1, n_nm_all, n_mon_all = [], [], [], []
 
     for k in range(D):
@@ -537,6 +537,12 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         fdesc.extend([kc, len(groups), len(b_st), maxP_hf, maxP_poly, complex_comp, fint_off, fold_off[-1], stream_rel,
                       len(bfuns), off_wb, st8_rel, n_stA, -1, plan_off, 0])
         plan_seq.append(([(g_[0], bool(g_[3])) for g_ in groups] if not complex_comp else None, kc, fint_off))
+        u_info.append(dict(kc=kc, complex=complex_comp, fint_off=fint_off, stream_rel=stream_rel, maxP_hf=maxP_hf,
+                           maxP_poly=maxP_poly,
+                           groups=[(g_[0], g_[1], g_[2],
+                                    max([f[2] for _, f in by_var[g_[0]] if f[3]], default=0),
+                                    max([f[2] for _, f in by_var[g_[0]] if not f[3]], default=0)) for g_ in groups],
+                           st_p0=[bf[2] for bf in bfuns[len(b_hf) + len(b_poly):]]))
         # ---- assemble the block ---------------------------------------------
         hdr = [0] * HDR_LEN
         off_nm = HDR_LEN
@@ -607,4 +613,161 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
     cm.offsets = np.concatenate((cm.comp_off, cm.dpar_off, cm.coef_off, cm.fold_off, cm.ftab_off)).astype(np.int32)
     cm.n_nm = np.asarray(n_nm_all, dtype=np.int32)
     cm.n_mon = np.asarray(n_mon_all, dtype=np.int32)
+    _compile_uform(cm, u_info, polyclass, separable)
     return cm
+
+
+# ---- univariate form (include/ttm.h "U-form", csrc/ttm_uform.h) -----------------------------------------
+U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
+UCF_OWN, UGF_POLY = 1, 1 << 20
+U_KAPPA = 0.5                 # spline interval width / smallest special-term scale (degree 11: fit error ~1e-15)
+U_SUPPORT = 6.0 * np.sqrt(2.0)   # |x - centre| / scale beyond which erf / the Gaussian are at their limits to 1e-16
+U_TOL_VALUE, U_TOL_DERIV = 2e-13, 2e-11     # accepted fit errors (relative to 1 + |exact|) before falling back
+
+
+def _compile_uform(cm, u_info, polyclass, separable):
+    """Static part of the U-form: group records with the planned-cache flags, monomial conversion matrix.
+    The spline geometry depends on the special-term constants and is (re)computed by uform_geometry()."""
+    cm.u_static = False
+    cm.u_enabled = False
+    cm.u_info = u_info
+    cm.ucomp = np.zeros(max(1, cm.D) * UC_LEN, dtype=np.int32)
+    cm.ugrp = np.zeros(UG_LEN, dtype=np.int32)
+    cm.umono = np.zeros((U_PMAX + 1) ** 2)
+    cm.ugeo = np.zeros(2 * max(1, cm.D))
+    cm.u_size, cm.u_err_off = 0, 0
+    if not separable or any(u['complex'] for u in u_info):
+        return
+    if any(g[1] > U_PMAX for u in u_info for g in u['groups']) or \
+            any(max(u['maxP_hf'], u['maxP_poly']) > U_PMAX for u in u_info):
+        return
+    for n in range(U_PMAX + 1):
+        c = polyclass.basis(n).convert(kind=np.polynomial.Polynomial).coef
+        cm.umono[n * (U_PMAX + 1):n * (U_PMAX + 1) + len(c)] = c
+    ucomp, ugrp = [], []
+    for k, u in enumerate(u_info):
+        grp_off = len(ugrp) // UG_LEN
+        for gi, (var, P, off, p_hf, p_plain) in enumerate(u['groups']):
+            fl = int(cm.fints[u['fint_off'] + 4 * gi + 3]) | (p_hf << 16) | (p_plain << 24) | (UGF_POLY if p_plain else 0)
+            ugrp += [var, fl, off if p_plain else -1, p_plain, off + P if p_hf else -1, p_hf, 0, 0]
+        flags = 0
+        if u['maxP_hf'] or u['maxP_poly']:
+            flags |= UCF_OWN
+            fl = (PLAN_HF if u['maxP_hf'] else 0) | (UGF_POLY if u['maxP_poly'] else 0) | \
+                (u['maxP_hf'] << 16) | (u['maxP_poly'] << 24)
+            ugrp += [u['kc'], fl, u['stream_rel'] + u['maxP_hf'] if u['maxP_poly'] else -1, u['maxP_poly'],
+                     u['stream_rel'] if u['maxP_hf'] else -1, u['maxP_hf'], 0, 0]
+        ucomp += [u['kc'], int(cm.fdesc[k * FD_LEN + FD_KC_SLOT]), len(u['groups']), grp_off, 0, 0, 0, flags]
+    ucomp = np.asarray(ucomp, dtype=np.int32).reshape(-1, UC_LEN)
+    ugrp = np.asarray(ugrp if len(ugrp) else [0] * UG_LEN, dtype=np.int32).reshape(-1, UG_LEN)
+    state = _plan_eager_e(ucomp, ugrp, cm.fints, [int(cm.fdesc[k * FD_LEN + 14]) for k in range(cm.D)])
+    cm.ucomp = np.concatenate((ucomp.ravel(), state.ravel())).astype(np.int32)
+    cm.ugrp = ugrp.ravel().copy()
+    cm.u_static = True
+    uform_geometry(cm)
+
+
+UCF_PUT_E = 2
+
+
+def _plan_eager_e(ucomp, ugrp, fints, plan_offs):
+    """The planned column cache of the direct kernels computes exp(-x^2/4) of a cached column lazily, at its
+    first Hermite-function reader (that reader's flag word lacks TTM_PLAN_EHIT).  The U-form kernels compute
+    it when the column is PUT (the component's own x_k, already in registers) if any reader needs it before the
+    slot is reused: every such reader then carries EHIT and takes the two-LDS-read fast path.  Returns the
+    entry-state words (TTM_PLAN_WAYS per component, column | TTM_PLAN_E) under these semantics, for sweeps
+    that start at k0 > 0."""
+    D = ucomp.shape[0]
+    # events in sweep order: ('r', group index, slot, hf, hit) reads and ('p', k, slot) puts
+    events = []
+    for k in range(D):
+        for g in range(int(ucomp[k, 2])):
+            gi = int(ucomp[k, 3]) + g
+            fl = int(ugrp[gi, 1])
+            events.append(('r', gi, (fl >> 8) & 255, bool(fl & PLAN_HF), bool(fl & PLAN_XHIT), k))
+        events.append(('p', k, int(ucomp[k, 1]), False, False, k))
+    for i, ev in enumerate(events):
+        if ev[0] != 'p' or ev[2] < 0:
+            continue
+        readers = []
+        for ev2 in events[i + 1:]:
+            if ev2[2] != ev[2]:
+                continue
+            if ev2[0] == 'p' or not ev2[4]:
+                break                                   # slot rewritten (put, or filled by a miss)
+            if ev2[3]:
+                readers.append(ev2[1])
+        if readers:
+            ucomp[ev[1], 7] |= UCF_PUT_E
+            for gi in readers:
+                ugrp[gi, 1] |= PLAN_EHIT
+    # entry states: replay
+    state = np.full((D, PLAN_WAYS), -1, dtype=np.int64)
+    slots = {}
+    ei = 0
+    for k in range(D):
+        if k == 0:
+            base = fints[plan_offs[0]:plan_offs[0] + PLAN_WAYS]
+            for w in range(PLAN_WAYS):
+                if base[w] >= 0:
+                    slots[w] = [int(base[w]) & ~PLAN_E, bool(int(base[w]) & PLAN_E)]
+        for w, (col, e) in slots.items():
+            state[k, w] = col | (PLAN_E if e else 0)
+        while ei < len(events) and events[ei][5] == k:
+            ev = events[ei]
+            ei += 1
+            if ev[2] in (255, -1):
+                continue
+            if ev[0] == 'p':
+                slots[ev[2]] = [int(ucomp[k, 0]), bool(ucomp[k, 7] & UCF_PUT_E)]
+            else:
+                gi = ev[1]
+                if not ev[4]:
+                    slots[ev[2]] = [int(ugrp[gi, 0]), ev[3]]
+                elif ev[3]:
+                    slots[ev[2]][1] = True
+    return state.astype(np.int32)
+
+
+def uform_geometry(cm, kappa=None):
+    """Spline geometry of every component from the current special-term constants (cm.dpar): support
+    [t_lo, t_hi] = union of centre -+ U_SUPPORT scale, n intervals of width h <= kappa min(scale); fills the
+    NI / TAB_OFF / DBL_OFF words of ucomp, ugeo, the U-section size, and decides u_enabled."""
+    if not cm.u_static:
+        cm.u_enabled = False
+        return False
+    kappa = U_KAPPA if kappa is None else kappa
+    uc = cm.ucomp[:cm.D * UC_LEN].reshape(-1, UC_LEN)       # (view: the entry-state words follow)
+    off, ok = 0, True
+    geo = np.zeros((cm.D, 2))
+    for k, u in enumerate(cm.u_info):
+        ng = int(uc[k, 2]) + (1 if uc[k, 7] & UCF_OWN else 0)
+        uc[k, 6] = off
+        off += 4 + 16 * ng
+    for k, u in enumerate(cm.u_info):
+        nI = 0
+        if len(u['st_p0']):
+            base = int(cm.dpar_off[k])
+            mu = np.asarray([cm.dpar[base + p0] for p0 in u['st_p0']])
+            sc = np.asarray([cm.dpar[base + p0 + 1] for p0 in u['st_p0']])
+            if not (np.all(np.isfinite(mu)) and np.all(np.isfinite(sc)) and np.all(sc > 0)):
+                ok = False          # constants not placed yet (or degenerate): no U-form until they are
+                mu, sc = np.zeros(1), np.ones(1)
+            t_lo, t_hi = float(np.min(mu - U_SUPPORT * sc)), float(np.max(mu + U_SUPPORT * sc))
+            n_int = int(np.ceil((t_hi - t_lo) / (kappa * float(np.min(sc)))))
+            n_int = max(n_int, 2)
+            n_int += n_int % 2      # even number of columns: 16-byte copies
+            nI = n_int + 2
+            if nI > U_NI_MAX:
+                ok = False
+                nI = 2 + 2
+                n_int = 2
+            geo[k] = (t_lo, (t_hi - t_lo) / n_int)
+        uc[k, 4] = nI
+        uc[k, 5] = off
+        off += U_TSTRIDE * nI
+    cm.u_err_off = off
+    cm.u_size = off + 2 * cm.D + (off % 2)
+    cm.ugeo = geo.ravel().copy()
+    cm.u_enabled = bool(ok)
+    return cm.u_enabled

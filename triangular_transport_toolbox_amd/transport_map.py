@@ -173,6 +173,9 @@ class transport_map():
                                         self._qx_d.numel(),
                                         self.monotonicity, self.rectifier_type, self.delta)
         self._pp = ctypes.byref(self._prog)
+        self._u_checked = None
+        self._u_rejected = False
+        self._refresh_uform()
         self._work = None
         self._obj_cache = None
 
@@ -229,6 +232,44 @@ class transport_map():
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
         return t
+
+    def _refresh_uform(self):
+        """(Re)attach the U-form tables (include/ttm.h "U-form"): called at construction and after every
+        special-term placement, which changes the spline geometry."""
+        torch = _torch()
+        cm = self._cm
+        if not cm.u_static:
+            return
+        termtable.uform_geometry(cm)
+        if self._u_rejected:
+            cm.u_enabled = False
+        self._ucomp_d = self._to_dev(cm.ucomp, dtype=torch.int32)
+        self._ugeo_d = self._to_dev(cm.ugeo)
+        if getattr(self, '_ugrp_d', None) is None:
+            self._ugrp_d = self._to_dev(cm.ugrp, dtype=torch.int32)
+            self._umono_d = self._to_dev(cm.umono)
+        _capi.set_uform(self._prog, cm, self._ucomp_d.data_ptr(), self._ugrp_d.data_ptr(), self._umono_d.data_ptr(),
+                        self._ugeo_d.data_ptr())
+        self._u_checked = None
+
+    def _check_uform(self, fold):
+        """The special-term splines are verified when they are built (fit error against the direct evaluation,
+        csrc/ttm_uform.h).  The errors are read back with every packed coefficient vector (2 D doubles); a spline
+        outside the tolerance disables the U-form for this map until the next special-term placement (the direct
+        kernels run instead) and the fold is redone without it."""
+        cm = self._cm
+        if not cm.u_enabled:
+            return True
+        off = int(self._lib.ttm_uform_offset(self._pp)) + int(cm.u_err_off)
+        err = fold[off:off + 2 * cm.D].cpu().numpy().reshape(cm.D, 2)
+        self.uform_fit_error = err
+        ok = bool(np.all(err[:, 0] <= termtable.U_TOL_VALUE) and np.all(err[:, 1] <= termtable.U_TOL_DERIV))
+        self._u_checked = ok
+        if not ok:
+            self._u_rejected = True
+            cm.u_enabled = False
+            self._prog.u_enabled = 0
+        return ok
 
     # ------------------------------------------------------------------------
     # samples
@@ -372,6 +413,8 @@ class transport_map():
         termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
         self._cm.fill_special_terms(self.special_terms)
         self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
+        self._u_rejected = False
+        self._refresh_uform()
 
     def reset(self, X):
         """TM:710-748: new samples, coefficients back to coeffs_init."""
@@ -404,6 +447,9 @@ class transport_map():
         # folded coefficients (device pre-pass, include/ttm.h "Folded coefficients"); kept with the vector
         fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
         _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
+        if not self._check_uform(fold):
+            fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
+            _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
         coef._ttm_fold = fold
         return coef
 
