@@ -202,6 +202,20 @@ extern "C" {
 #define TTM_UG_DEGA(f) (((f) >> 24) & 15)
 #define TTM_UGF_POLY     (1 << 20)   /* group has plain polynomial terms                        */
 
+/* "hot" records of a U-form map (H section, appended to the U section by ttm_fold when u_h_cls > 0): one
+ * fixed-stride record per component holding everything a sweep step needs, so that the kernel issues all scalar
+ * loads of a step at once instead of chasing ucomp -> ugrp -> U offsets:
+ *   header, TTM_H_HDR doubles: int32 {put slot (2 x way, -1: none), flags (bit 0: store exp(-x_kc^2/4) too)},
+ *           int32 {NI, kc}, c0, -t_lo/h, 1/h, 2/h, int32 {TAB_OFF, number of groups}, 0
+ *   u_h_ng group records of GS doubles: int32 {slot of the column (2 x way), 1} ({0, 0} for the padding records
+ *           beyond the component's own groups), B[0..DB], A[0..DA], zero padding;
+ *           (DB, DA, GS) = (3,1,8) / (5,5,16) / (7,7,24) for u_h_cls = 1 / 2 / 3.
+ * Available (u_h_cls > 0) when every group of a full sweep reads a column the sweep itself produced (all cache
+ * hits), no component has polynomial / Hermite-function terms in its monotone list and none has more than
+ * TTM_H_NG_MAX nonmonotone groups.                                                                              */
+#define TTM_H_HDR         8
+#define TTM_H_NG_MAX      4
+
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
@@ -245,8 +259,11 @@ typedef struct ttm_program {
     const double*  ugeo;        /* device, 2 doubles per component {t_lo, h} of its spline        */
     const int32_t* h_ucomp;     /* host copy of ucomp (launch planning)              */
     const int32_t* h_ugrp;      /* host copy of ugrp                                 */
-    int64_t u_size;             /* doubles of the U section                          */
+    int64_t u_size;             /* doubles of the U section (H section included)     */
     int64_t u_err_off;          /* offset (within the U section) of the 2 x D fit errors */
+    int64_t u_h_off;            /* offset (within the U section) of the hot records  */
+    int32_t u_h_cls;            /* 0: no hot records; 1..3: degree class             */
+    int32_t u_h_ng;             /* group records per component                       */
 } ttm_program;
 
 const char* ttm_last_error_string(void);

@@ -127,6 +127,49 @@ void forward_u(const ttm_program* p, const double* fold, const XA& xa, int k0, i
     }
 }
 
+// hot-record forward (what k_forward_hl evaluates) of one "thread"
+template <int NG, int CLS, class R, class XA>
+void forward_h(const ttm_program* p, const double* fold, const XA& xa, int k0, int k1, bool want_ld, bool want_val,
+               R* S_out, R& ld, R& ss, const double* sigma) {
+    constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
+    const double* U = fold + fold_base_size_(p);
+    const int ways = (p->plan_ways < 1 || p->plan_ways > TTM_PLAN_WAYS) ? TTM_PLAN_WAYS : p->plan_ways;
+    double cbuf[2 * TTM_PLAN_WAYS * lanes_of<R>::value];
+    for (auto& c : cbuf) c = 0.0;
+    (void)ways;
+    CacheStore<R> st{cbuf, 1};
+    PlanCache<XA, R> x(xa, st);
+    if (k0 > 0) x.warm(p->ucomp + TTM_UC_STATE(p->D, k0));
+    ld = R(0.0); ss = R(0.0);
+    const int hs = TTM_H_HDR + p->u_h_ng * GS;
+    for (int k = k0; k < k1; ++k) {
+        const double* rec = U + p->u_h_off + (int64_t)k * hs;
+        const int kc = ((const int*)rec)[3];
+        const int tab_off = ((const int*)rec)[12];
+        const R xk = xa(kc);
+        R S, dS;
+        if (want_ld) h_component<NG, DB, DA, GS, true>(rec, U + tab_off, xk, st, want_val, S, dS);
+        else h_component<NG, DB, DA, GS, false>(rec, U + tab_off, xk, st, true, S, dS);
+        if (want_ld) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
+        S_out[k - k0] = S;
+        ss = vfma(S, S, ss);
+    }
+}
+
+template <class R, class XA>
+bool forward_h_dispatch(const ttm_program* p, const double* fold, const XA& xa, int k0, int k1, bool want_ld, bool want_val,
+                        R* S_out, R& ld, R& ss, const double* sigma) {
+#define TTM_FH(NGV, C) forward_h<NGV, C, R>(p, fold, xa, k0, k1, want_ld, want_val, S_out, ld, ss, sigma); return true
+    switch (p->u_h_ng * 10 + p->u_h_cls) {
+        case 11: TTM_FH(1, 1); case 12: TTM_FH(1, 2); case 13: TTM_FH(1, 3);
+        case 21: TTM_FH(2, 1); case 22: TTM_FH(2, 2); case 23: TTM_FH(2, 3);
+        case 31: TTM_FH(3, 1); case 32: TTM_FH(3, 2); case 33: TTM_FH(3, 3);
+        case 41: TTM_FH(4, 1); case 42: TTM_FH(4, 2); case 43: TTM_FH(4, 3);
+        default: return false;
+    }
+#undef TTM_FH
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,6 +227,7 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
 
 static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }
 static bool u_on(const ttm_program* p) { return p->u_enabled && !getenv("TTM_NO_UFORM"); }
+static int plan_ways_of(const ttm_program* p) { return (p->plan_ways < 1 || p->plan_ways > TTM_PLAN_WAYS) ? TTM_PLAN_WAYS : p->plan_ways; }
 
 int64_t ttm_fold_size(const ttm_program* p) { return fold_base_size(p) + (p->u_enabled ? p->u_size : 0); }
 int64_t ttm_uform_offset(const ttm_program* p) { return p->u_enabled ? fold_base_size(p) : -1; }
@@ -203,6 +247,7 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
             const double* geo = p->ugeo + 2 * k;
             if (uc[TTM_UC_NI] > TTM_U_NI_MAX) return TTM_E_LIMIT;
             uform_build_groups(uc, p->ugrp, fd, p->umono, geo, foldk, U, 0, 1);
+            if (p->u_h_cls > 0) uform_build_hot(uc, p->ugrp, U, p->u_h_off, p->u_h_cls, p->u_h_ng, k, 0, 1);
             double ev = 0.0, ed = 0.0;
             if (uc[TTM_UC_NI] > 0) {
                 uform_spline_nodes(uc, fd, geo, foldk, ybuf.data(), 0, 1);
@@ -221,10 +266,12 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const Prog g = make_prog(p);
     if (p->monotonicity == TTM_MONO_SEPARABLE && u_on(p) && all_fast(p, k0, k1)) {     // same dispatch as the library
         std::vector<double> S(k1 - k0);
+        const bool hot = p->u_h_cls > 0 && !getenv("TTM_EMU_NO_HOT");     // hot records (what k_forward_hl evaluates)
         for (int64_t n = 0; n < N; ++n) {
             XSoA xa{X, ldx, n};
             double ld, ss;
-            forward_u<double>(p, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma);
+            if (!(hot && forward_h_dispatch<double>(p, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma)))
+                forward_u<double>(p, fold, xa, k0, k1, logdet != nullptr, Z || sumsq, S.data(), ld, ss, sigma);
             if (Z) for (int k = k0; k < k1; ++k) Z[(int64_t)(k - k0) * ldz + n] = S[k - k0];
             if (logdet) logdet[n] = ld;
             if (sumsq) sumsq[n] = ss;

@@ -57,7 +57,8 @@ def test_import_export_and_moments(backend):
         assert relerr(tm.X_mean, X.mean(axis=0)) < 1e-13 and relerr(tm.X_std, X.std(axis=0)) < 1e-13
         Xs = tm._import(X, True)
         ref = (X - tm.X_mean) / tm.X_std
-        assert np.array_equal(Xs.cpu().numpy(), ref.T)              # same two IEEE operations per element
+        assert Xs.shape[1] % 2 == 0 and Xs.shape[1] >= N            # padded leading dimension (16-byte aligned columns)
+        assert np.array_equal(Xs[:, :N].cpu().numpy(), ref.T)       # same two IEEE operations per element
         back = tm._export(Xs, N, 0, d, True)
         assert np.array_equal(back, ref * tm.X_std + tm.X_mean)
         assert np.array_equal(tm._export(Xs, N, 1 if d > 1 else 0, d - (1 if d > 1 else 0), False), ref[:, (1 if d > 1 else 0):])
@@ -74,6 +75,8 @@ def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
     tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
     monkeypatch.setenv('TTM_FORWARD_NS', '1')
     monkeypatch.setenv('TTM_INVERSE_NS', '1')
+    monkeypatch.setenv('TTM_U_NS', '1')
+    monkeypatch.setenv('TTM_U_LOADER', '0')
     Z1 = tm.map(X)
     sep = desc['kwargs']['monotonicity'] == 'separable monotonicity'
     if sep:
@@ -81,10 +84,17 @@ def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
         I1 = tm.inverse_map(npz['inv_Z'])
     monkeypatch.setenv('TTM_FORWARD_NS', ns)
     monkeypatch.setenv('TTM_INVERSE_NS', '2')
+    monkeypatch.setenv('TTM_U_NS', ns)
     assert np.array_equal(tm.map(X), Z1)
     if sep:
         assert np.array_equal(tm.evaluate_pullback_density(X), p1)
         assert np.array_equal(tm.inverse_map(npz['inv_Z']), I1)
+        # the loader-wave kernels (U-form maps; chosen automatically for large ensembles) - odd N, ragged last tile
+        monkeypatch.setenv('TTM_U_LOADER', '1')
+        assert np.array_equal(tm.map(X), Z1)
+        assert np.array_equal(tm.evaluate_pullback_density(X), p1)
+        assert np.array_equal(tm.map(X[:1]), Z1[:1])
+        assert np.array_equal(tm.map(X[:513]), Z1[:513])
 
 
 def test_large_ensemble_properties(backend):

@@ -499,7 +499,7 @@ struct UTabs {               // by-value kernel argument
 
 // one workgroup per component: monomial coefficients of the groups, spline of the summed special terms, fit check
 __global__ __launch_bounds__(256) void k_uform(DevProg P, UTabs T, const double* __restrict__ fold, double* __restrict__ U,
-                                               int64_t err_off) {
+                                               int64_t err_off, int64_t h_off, int h_cls, int h_ng) {
     __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
     __shared__ double red[2][4];
     const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
@@ -509,6 +509,10 @@ __global__ __launch_bounds__(256) void k_uform(DevProg P, UTabs T, const double*
     const double* foldk = fold + P.off[3 * D1 + k];
     const double* geo = T.ugeo + 2 * k;
     uform_build_groups(uc, T.ugrp, fd, T.umono, geo, foldk, U, tid, bd);
+    if (h_cls > 0) {
+        __syncthreads();
+        uform_build_hot(uc, T.ugrp, U, h_off, h_cls, h_ng, k, tid, bd);
+    }
     double ev = 0.0, ed = 0.0;
     if (uc[TTM_UC_NI] > 0) {
         uform_spline_nodes(uc, fd, geo, foldk, ybuf, tid, bd);
@@ -688,6 +692,371 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
         cx = nx;
 #pragma unroll
         for (int e = 0; e < NS; ++e) act[e] = nact[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Forward map in U-form with dedicated loader waves (the kernel the large-ensemble path runs).
+//
+// Workgroup = 4 evaluating waves (256 threads, two adjacent samples each: a 512-row tile) + wave 4, which streams
+// the x_k columns, + wave 5, which streams the spline tables - both by LDS-DMA (global_load_lds_dwordx4: no
+// registers, no LDS instructions), each into its own ring of LDS slots, xlead / tlead steps ahead of the
+// evaluation.  The evaluating waves issue NO vector loads: they read their column pair from the ring with one
+// ds_read_b128, so nothing they do waits on HBM latency, and the compiler's conservative vmcnt placement has
+// nothing to serialise.  One s_barrier per step hands a slot over: a loader arrives at barrier A(s) only after
+// its counted `s_waitcnt vmcnt(n)` says the data of step s has landed, and, having passed A(s), may overwrite the
+// slot of step s-1 (every evaluating wave finished it before arriving).  Loaders keep issuing (harmless
+// duplicate) DMAs past the last step so that the counts behind the immediates stay valid.
+// Requires 16-byte aligned X / Z columns (even leading dimensions) and ldx >= N rounded up to even.
+// LDS (doubles): [x ring: (LEAD+1) x 512 | table ring: 3 x tab_slot | column cache: 2 x ways x 2 x 256]
+// ---------------------------------------------------------------------------
+#define TTM_UL_ROWS 512       // rows per tile (4 evaluating waves x 64 lanes x 2 samples)
+// xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
+// xlead + 1 and tlead + 1 slots.  xlead <= 4 and tlead <= 2 (the vmcnt immediates).
+
+#define TTM_RAW_BARRIER()                       \
+    do {                                        \
+        asm volatile("" ::: "memory");          \
+        __builtin_amdgcn_s_barrier();           \
+        asm volatile("" ::: "memory");          \
+    } while (0)
+
+__device__ __forceinline__ void ul_wait_vmcnt(int n) {      // all but the n youngest vector-memory operations are done
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ void ul_dma16(const void* g, double* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// x loader: column of step `step` (clamped to the last step: duplicates) -> ring slot step % XSLOTS
+struct UlCursor {
+    int64_t tile;        // tile index of the cursor
+    int k;
+    int64_t step;
+};
+
+template <bool WANT_LD, int DB, int DA>
+__global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
+                                                    const double* __restrict__ U_, int D, int k0, int k1,
+                                                    const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                    double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
+                                                    const double* __restrict__ sigma, double* __restrict__ sumsq,
+                                                    int tab_slot, int xlead, int tlead) {
+    typedef VecD<2> R;
+    const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
+    cint_p ucomp = (cint_p)ucomp_;
+    cint_p ugrp = (cint_p)ugrp_;
+    cdbl_p U = (cdbl_p)U_;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int ncomp = k1 - k0;
+    const int64_t ntiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t S = my_tiles * ncomp;
+    double* ring = g_smem;
+    double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
+    double* cache = tabs + (size_t)TSLOTS * tab_slot;
+
+    if (wv == 4) {
+        // ---- x loader -------------------------------------------------------------------------------------------
+        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;           // first row of the last readable pair
+        int64_t ptile = blockIdx.x;
+        int pk = k0;
+        int64_t pstep = 0;                                               // step the cursor (ptile, pk) stands for
+        int xs = 0;                                                      // ring slot of the next issue (steps in order)
+        auto issue = [&](int64_t step) {
+            // advance the cursor to min(step, S - 1)
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
+            }
+            const double* col = X + (int64_t)ucomp[pk * TTM_UC_LEN + TTM_UC_KC] * ldx;
+            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
+            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+#pragma unroll
+            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
+                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
+                pair = pair < last_pair ? pair : last_pair;
+                ul_dma16(col + pair, slot + c * 128);
+            }
+        };
+        for (int j = 0; j < xlead; ++j) issue(j);
+        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+        TTM_RAW_BARRIER();                                               // A(0)
+        for (int64_t s = 0; s < S; ++s) {
+            issue(s + xlead);
+            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));            // x(s + 1) has landed
+            TTM_RAW_BARRIER();                                           // A(s + 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain before the LDS is released
+        return;
+    }
+    if (wv == 5) {
+        // ---- table loader ---------------------------------------------------------------------------------------
+        int pk = k0;
+        int64_t pstep = 0;
+        int ts = 0;                                                      // table slot of the next issue
+        auto issue = [&](int64_t step) -> int {
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) pk = k0;
+            }
+            const int nI = ucomp[pk * TTM_UC_LEN + TTM_UC_NI];
+            const int bytes = nI * (TTM_U_TSTRIDE * 8);
+            const char* src = (const char*)(U_ + ucomp[pk * TTM_UC_LEN + TTM_UC_TAB_OFF]);
+            double* slot = tabs + (size_t)ts * tab_slot;
+            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+            const int nch = (bytes + 1023) >> 10;
+            for (int c = 0; c < nch; ++c) {
+                const int off = c * 1024 + lane * 16;
+                if (off < bytes) ul_dma16(src + off, slot + c * 128);
+            }
+            return nch;
+        };
+        issue(0);
+        const int n1 = tlead > 1 ? issue(1) : 0;
+        ul_wait_vmcnt(n1);
+        TTM_RAW_BARRIER();                                               // A(0)
+        for (int64_t s = 0; s < S; ++s) {
+            const int n = issue(s + tlead);
+            ul_wait_vmcnt(tlead > 1 ? n : 0);                            // table(s + 1) has landed
+            TTM_RAW_BARRIER();                                           // A(s + 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- evaluating waves -------------------------------------------------------------------------------------------
+    CacheStore<R> cst;
+    cst.base = cache + tid;
+    cst.stride = 256;
+    const bool want_val = (Z != nullptr) || (sumsq != nullptr);
+    XOffN<2> cx;
+    cx.X = (const char*)X; cx.ldb = ldx * 8;
+    bool act0 = false, act1 = false;
+    int64_t ctile = blockIdx.x;
+    int k = k0;
+    R ld(0.0), ss(0.0);
+    int xs = 0, ts = 0;
+    TTM_RAW_BARRIER();                                                   // A(0)
+    for (int64_t s = 0; s < S; ++s) {
+        cint_p uc = ucomp + k * TTM_UC_LEN;
+        if (k == k0) {
+            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
+            act0 = n < N; act1 = n + 1 < N;
+            cx.off[0] = (unsigned int)(act0 ? n : N - 1) * 8u;
+            cx.off[1] = (unsigned int)(act1 ? n + 1 : N - 1) * 8u;
+            ld = R(0.0); ss = R(0.0);
+        }
+        PlanCache<XOffN<2>, R> x(cx, cst);
+        if (k == k0 && k0 > 0) x.warm(ucomp + TTM_UC_STATE(D, k0));
+        const D2 xp = *(const D2*)(ring + (size_t)xs * TTM_UL_ROWS + 2 * tid);
+        R xk;
+        xk.v[0] = xp.x; xk.v[1] = xp.y;
+        const double* tab = tabs + (size_t)ts * tab_slot;
+        xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+        ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+        R Sv, dS;
+        u_component<DB, DA, WANT_LD>(uc, ugrp, U, tab, xk, x, WANT_LD ? want_val : true, Sv, dS);
+        if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+        if (Z) {
+            double* zc = Z + (int64_t)(k - k0) * ldz + ctile * TTM_UL_ROWS + 2 * tid;
+            if (act1) { D2 o = {Sv.v[0], Sv.v[1]}; *(D2*)zc = o; }
+            else if (act0) *zc = Sv.v[0];
+        }
+        ss = vfma(Sv, Sv, ss);
+        const bool wrap = (k + 1 == k1);
+        if (wrap) {
+            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
+            if (WANT_LD) {
+                if (act1) { D2 o = {ld.v[0], ld.v[1]}; *(D2*)(logdet + n) = o; }
+                else if (act0) logdet[n] = ld.v[0];
+            }
+            if (sumsq) {
+                if (act1) { D2 o = {ss.v[0], ss.v[1]}; *(D2*)(sumsq + n) = o; }
+                else if (act0) sumsq[n] = ss.v[0];
+            }
+            ctile += gridDim.x;
+            k = k0;
+        } else {
+            ++k;
+        }
+        TTM_RAW_BARRIER();                                               // A(s + 1)
+    }
+}
+
+// Hot-record variant of k_forward_ul (include/ttm.h "H section"): the evaluating waves read ONE fixed-stride record
+// per step (all scalar loads at known offsets, issued together) and run straight-line code: NG group records of
+// degree class CLS, every column from the planned cache.  Same loader waves, rings and barrier protocol.
+template <bool WANT_LD, int NG, int CLS>
+__global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+                                                    int D, int k0, int k1,
+                                                    const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                    double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
+                                                    const double* __restrict__ sigma, double* __restrict__ sumsq,
+                                                    int tab_slot, int xlead, int tlead) {
+    typedef VecD<2> R;
+    const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
+    constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
+    constexpr int HS = TTM_H_HDR + NG * GS;
+    cdbl_p H = (cdbl_p)(U_ + h_off);
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int ncomp = k1 - k0;
+    const int64_t ntiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t S = my_tiles * ncomp;
+    double* ring = g_smem;
+    double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
+    double* cache = tabs + (size_t)TSLOTS * tab_slot;
+
+    if (wv == 4) {
+        // ---- x loader -------------------------------------------------------------------------------------------
+        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
+        int64_t ptile = blockIdx.x;
+        int pk = k0;
+        int64_t pstep = 0;
+        int xs = 0;
+        auto issue = [&](int64_t step) {
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
+            }
+            const int kc = ((cint_p)(H + (int64_t)pk * HS))[3];
+            const double* col = X + (int64_t)kc * ldx;
+            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
+            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+#pragma unroll
+            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
+                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
+                pair = pair < last_pair ? pair : last_pair;
+                ul_dma16(col + pair, slot + c * 128);
+            }
+        };
+        for (int j = 0; j < xlead; ++j) issue(j);
+        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+        TTM_RAW_BARRIER();
+        for (int64_t s = 0; s < S; ++s) {
+            issue(s + xlead);
+            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+            TTM_RAW_BARRIER();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    if (wv == 5) {
+        // ---- table loader ---------------------------------------------------------------------------------------
+        int pk = k0;
+        int64_t pstep = 0;
+        int ts = 0;
+        auto issue = [&](int64_t step) -> int {
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) pk = k0;
+            }
+            cint_p ri = (cint_p)(H + (int64_t)pk * HS);
+            const int nI = ri[2];
+            const int bytes = nI * (TTM_U_TSTRIDE * 8);
+            const char* src = (const char*)(U_ + ri[12]);
+            double* slot = tabs + (size_t)ts * tab_slot;
+            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+            const int nch = (bytes + 1023) >> 10;
+            for (int c = 0; c < nch; ++c) {
+                const int off = c * 1024 + lane * 16;
+                if (off < bytes) ul_dma16(src + off, slot + c * 128);
+            }
+            return nch;
+        };
+        issue(0);
+        const int n1 = tlead > 1 ? issue(1) : 0;
+        ul_wait_vmcnt(n1);
+        TTM_RAW_BARRIER();
+        for (int64_t s = 0; s < S; ++s) {
+            const int n = issue(s + tlead);
+            ul_wait_vmcnt(tlead > 1 ? n : 0);
+            TTM_RAW_BARRIER();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- evaluating waves -------------------------------------------------------------------------------------------
+    CacheStore<R> cst;
+    cst.base = cache + tid;
+    cst.stride = 256;
+    const bool want_val = (Z != nullptr) || (sumsq != nullptr);
+    bool act0 = false, act1 = false;
+    int64_t ctile = blockIdx.x;
+    int k = k0;
+    R ld(0.0), ss(0.0);
+    int xs = 0, ts = 0;
+    TTM_RAW_BARRIER();                                                   // A(0)
+    for (int64_t s = 0; s < S; ++s) {
+        cdbl_p rec = H + (int64_t)k * HS;
+        if (k == k0) {
+            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
+            act0 = n < N; act1 = n + 1 < N;
+            ld = R(0.0); ss = R(0.0);
+            if (k0 > 0) {                                                // (rare: sweeps that start inside the map)
+                XOffN<2> cx;
+                cx.X = (const char*)X; cx.ldb = ldx * 8;
+                cx.off[0] = (unsigned int)(act0 ? n : N - 1) * 8u;
+                cx.off[1] = (unsigned int)(act1 ? n + 1 : N - 1) * 8u;
+                PlanCache<XOffN<2>, R> x(cx, cst);
+                x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
+            }
+        }
+        const D2 xp = *(const D2*)(ring + (size_t)xs * TTM_UL_ROWS + 2 * tid);
+        R xk;
+        xk.v[0] = xp.x; xk.v[1] = xp.y;
+        const double* tab = tabs + (size_t)ts * tab_slot;
+        xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+        ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+        R Sv, dS;
+        h_component<NG, DB, DA, GS, WANT_LD>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
+        if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
+        if (Z) {
+            double* zc = Z + (int64_t)(k - k0) * ldz + ctile * TTM_UL_ROWS + 2 * tid;
+            if (act1) { D2 o = {Sv.v[0], Sv.v[1]}; *(D2*)zc = o; }
+            else if (act0) *zc = Sv.v[0];
+        }
+        ss = vfma(Sv, Sv, ss);
+        if (k + 1 == k1) {
+            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
+            if (WANT_LD) {
+                if (act1) { D2 o = {ld.v[0], ld.v[1]}; *(D2*)(logdet + n) = o; }
+                else if (act0) logdet[n] = ld.v[0];
+            }
+            if (sumsq) {
+                if (act1) { D2 o = {ss.v[0], ss.v[1]}; *(D2*)(sumsq + n) = o; }
+                else if (act0) sumsq[n] = ss.v[0];
+            }
+            ctile += gridDim.x;
+            k = k0;
+        } else {
+            ++k;
+        }
+        TTM_RAW_BARRIER();                                               // A(s + 1)
     }
 }
 
@@ -1152,6 +1521,10 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
 
 static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }   // + read-ahead padding, even
 
+static int plan_ways_of(const ttm_program* p) {
+    return (p->plan_ways < 1 || p->plan_ways > TTM_PLAN_WAYS) ? TTM_PLAN_WAYS : p->plan_ways;
+}
+
 static bool u_on(const ttm_program* p) {
     return p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo && p->h_ucomp && p->h_ugrp && !getenv("TTM_NO_UFORM");
 }
@@ -1174,7 +1547,7 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* strea
                 return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
         const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
         hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(256), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
-                           fold + fold_base_size(p), (int64_t)p->u_err_off);
+                           fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng);
     }
     return check_launch("k_fold");
 }
@@ -1204,6 +1577,77 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         }
         int ways = p->plan_ways;
         if (ways < 1 || ways > TTM_PLAN_WAYS) ways = TTM_PLAN_WAYS;
+        // large ensembles with aligned columns: loader-wave kernel
+        {
+            int nimax = 0, nchmax = 0;
+            for (int k = k0; k < k1; ++k) {
+                const int ni = p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI];
+                nimax = ni > nimax ? ni : nimax;
+            }
+            nchmax = (nimax * TTM_U_TSTRIDE * 8 + 1023) >> 10;
+            const int tab_slot = TTM_U_TSTRIDE * nimax;                   // doubles (nI is even: 16-byte multiple)
+            int xlead = 3, tlead = 1;
+            if (const char* e = getenv("TTM_U_XLEAD")) xlead = atoi(e);
+            if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
+            xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
+            tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
+            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256) * 8;
+            const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
+                                 (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
+                                 (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
+                                 ((uintptr_t)(fold + fold_base_size(p)) % 16 == 0);
+            bool use_ul = aligned && N >= 64 * 1024 && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 / 2;
+            if (const char* e = getenv("TTM_U_LOADER")) use_ul = aligned && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 && atoi(e) != 0;
+            if (use_ul && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT")) {
+                typedef void (*hkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*,
+                                        int64_t, double*, const double*, double*, int, int, int);
+                hkern_t hk;
+#define TTM_HK(L, NGV) (p->u_h_cls == 1 ? k_forward_hl<L, NGV, 1> : p->u_h_cls == 2 ? k_forward_hl<L, NGV, 2> : k_forward_hl<L, NGV, 3>)
+                if (p->u_h_ng == 2) hk = logdet ? TTM_HK(true, 2) : TTM_HK(false, 2);
+                else hk = logdet ? TTM_HK(true, 4) : TTM_HK(false, 4);
+#undef TTM_HK
+                int wgs = (int)((size_t)(160 * 1024) / lds_ul);
+                if (wgs > 5) wgs = 5;
+                if (wgs < 1) wgs = 1;
+                if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+                const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+                const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
+                hipError_t he = hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ul);
+                (void)he;
+                hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp,
+                                   fold + fold_base_size(p), (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz,
+                                   logdet, sigma, sumsq, tab_slot, xlead, tlead);
+                return check_launch("k_forward_hl");
+            }
+            if (use_ul) {
+                typedef void (*lkern_t)(const int*, const int*, const double*, int, int, int, const double*, int64_t, int64_t,
+                                        double*, int64_t, double*, const double*, double*, int, int, int);
+                int mb = 0, ma = 0;
+                for (int k = k0; k < k1; ++k) {
+                    const int* uc = p->h_ucomp + k * TTM_UC_LEN;
+                    for (int g = 0; g < uc[TTM_UC_N_GRP]; ++g) {
+                        const int fl = p->h_ugrp[(uc[TTM_UC_GRP_OFF] + g) * TTM_UG_LEN + TTM_UG_FLAGS];
+                        if ((fl & TTM_PLAN_HF) && TTM_UG_DEGB(fl) > mb) mb = TTM_UG_DEGB(fl);
+                        if ((fl & TTM_UGF_POLY) && TTM_UG_DEGA(fl) > ma) ma = TTM_UG_DEGA(fl);
+                    }
+                }
+                const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
+                lkern_t lk = logdet ? (cls == 0 ? k_forward_ul<true, 3, 1> : cls == 1 ? k_forward_ul<true, 5, 5> : k_forward_ul<true, 7, 7>)
+                                    : (cls == 0 ? k_forward_ul<false, 3, 1> : cls == 1 ? k_forward_ul<false, 5, 5> : k_forward_ul<false, 7, 7>);
+                int wgs = (int)((size_t)(160 * 1024) / lds_ul);
+                if (wgs > 5) wgs = 5;                                    // 6 waves per workgroup, 32 per CU
+                if (wgs < 1) wgs = 1;
+                if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+                const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+                const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
+                hipError_t he = hipFuncSetAttribute((const void*)lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ul);
+                (void)he;
+                hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp, p->ugrp,
+                                   fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq,
+                                   tab_slot, xlead, tlead);
+                return check_launch("k_forward_ul");
+            }
+        }
         int uNS = N >= 2 * 256 * 256 ? 2 : 1;
         if (const char* e = getenv("TTM_U_NS")) uNS = atoi(e);
         if (uNS != 1 && uNS != 2 && uNS != 4) uNS = 2;

@@ -27,6 +27,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/ttm.h"
 #include "ttm_cheb_table.h"
@@ -167,6 +168,49 @@ TTM_HD void uform_spline_fit(const int* uc, const int* fd, const double* geo, co
     }
     for (int idx = first; idx < n_int * (TTM_U_TSTRIDE - TTM_CHEB_N); idx += stride)      // padding of the interior columns
         tab[(idx / (TTM_U_TSTRIDE - TTM_CHEB_N) + 1) * TTM_U_TSTRIDE + TTM_CHEB_N + idx % (TTM_U_TSTRIDE - TTM_CHEB_N)] = 0.0;
+}
+
+// two int32 in the bits of one double (little endian: lo first) - the int fields of the hot records
+TTM_HD double u_pack2(int lo, int hi) {
+    const unsigned long long u = (unsigned long long)(unsigned int)lo | ((unsigned long long)(unsigned int)hi << 32);
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
+TTM_HD int u_h_gs(int cls) { return cls == 1 ? 8 : (cls == 2 ? 16 : 24); }
+TTM_HD int u_h_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : 7); }
+TTM_HD int u_h_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : 7); }
+
+// hot record of one component (include/ttm.h "H section"), from its U-form block; run after uform_build_groups.
+TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_off, int cls, int ng, int k,
+                            int first, int stride) {
+    const int GS = u_h_gs(cls), DB = u_h_db(cls), DA = u_h_da(cls);
+    const int hs = TTM_H_HDR + ng * GS;
+    double* rec = U + h_off + (int64_t)k * hs;
+    const double* cd = U + uc[TTM_UC_DBL_OFF];
+    const int n_grp = uc[TTM_UC_N_GRP];
+    for (int idx = first; idx < hs; idx += stride) {
+        double v = 0.0;
+        if (idx < TTM_H_HDR) {
+            if (idx == 0) v = u_pack2(uc[TTM_UC_KC_SLOT] >= 0 ? 2 * uc[TTM_UC_KC_SLOT] : -1, (uc[TTM_UC_FLAGS] & TTM_UCF_PUT_E) ? 1 : 0);
+            else if (idx == 1) v = u_pack2(uc[TTM_UC_NI], uc[TTM_UC_KC]);
+            else if (idx <= 5) v = cd[idx - 2];
+            else if (idx == 6) v = u_pack2(uc[TTM_UC_TAB_OFF], n_grp);
+        } else {
+            const int g = (idx - TTM_H_HDR) / GS, j = (idx - TTM_H_HDR) % GS;
+            if (g < n_grp) {
+                const int* G = ug + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + g);
+                const int fl = G[TTM_UG_FLAGS];
+                if (j == 0) v = u_pack2(2 * TTM_PLAN_SLOT(fl), 1);
+                else if (j <= 1 + DB) v = (fl & TTM_PLAN_HF) ? cd[4 + 16 * g + (j - 1)] : 0.0;
+                else if (j <= 2 + DB + DA) v = (fl & TTM_UGF_POLY) ? cd[4 + 16 * g + 8 + (j - 2 - DB)] : 0.0;
+            } else if (j == 0) {
+                v = u_pack2(0, 0);
+            }
+        }
+        rec[idx] = v;
+    }
 }
 
 // one column of the spline at local coordinate s: value and d/ds
@@ -357,6 +401,68 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
     if (slot >= 0) {
         x.st.set(2 * slot, xk);
         if (put_e) x.st.set(2 * slot + 1, ek);
+    }
+}
+
+// S_k and dS_k/dx_k from a hot record (include/ttm.h "H section"): NG group records of degree (DB, DA) and stride
+// GS, every column from the planned cache (st; slot s of a sample set = st.get(s)), then the put of x_k.  All scalar
+// loads of the step are at fixed offsets from `rec`.  A component that uses all NG records, has a spline and
+// stores exp(-x_k^2/4) - every component of a banded map but the first and last few - runs as ONE basic block, so
+// the scheduler can overlap the cache / table reads with the exp and Horner chains; the others take the guarded path.
+template <int NG, int DB, int DA, int GS, bool DER, class R>
+TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheStore<R>& st, bool want_value, R& S, R& dS) {
+    cint_p ri = (cint_p)rec;
+    const int put2 = ri[0], flg = ri[1], nI = ri[2], n_grp = ri[13];
+    if (n_grp == NG && nI > 0 && (flg & 1) && put2 >= 0 && want_value) {
+        R xv[NG], ev[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot2 = ((cint_p)(rec + TTM_H_HDR + g * GS))[0];
+            xv[g] = st.get(slot2);
+            ev[g] = st.get(slot2 + 1);
+        }
+        R m, dm;
+        u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
+        const R ek = fast_exp(-0.25 * (xk * xk));
+        R s(rec[2]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            cdbl_p gr = rec + TTM_H_HDR + g * GS;
+            R b, a, dv;
+            u_horner_fixed<DB, false>(gr + 1, xv[g], b, dv);
+            u_horner_fixed<DA, false>(gr + 2 + DB, xv[g], a, dv);
+            s = vfma(ev[g], b, s) + a;
+        }
+        S = s + m;
+        dS = dm;
+        st.set(put2, xk);
+        st.set(put2 + 1, ek);
+        return;
+    }
+    R s(rec[2]);
+    if (want_value) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g < n_grp) {
+                cdbl_p gr = rec + TTM_H_HDR + g * GS;
+                const int slot2 = ((cint_p)gr)[0];
+                const R xv = st.get(slot2), ev = st.get(slot2 + 1);
+                R b, a, dv;
+                u_horner_fixed<DB, false>(gr + 1, xv, b, dv);
+                u_horner_fixed<DA, false>(gr + 2 + DB, xv, a, dv);
+                s = vfma(ev, b, s) + a;
+            }
+        }
+    }
+    R ek(0.0);
+    if (flg & 1) ek = fast_exp(-0.25 * (xk * xk));
+    R m(0.0), dm(0.0);
+    if (nI > 0) u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
+    S = s + m;
+    dS = dm;
+    if (put2 >= 0) {
+        st.set(put2, xk);
+        if (flg & 1) st.set(put2 + 1, ek);
     }
 }
 

@@ -619,6 +619,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 
 # ---- univariate form (include/ttm.h "U-form", csrc/ttm_uform.h) -----------------------------------------
 U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
+H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24)
 UCF_OWN, UGF_POLY = 1, 1 << 20
 U_KAPPA = 0.5                 # spline interval width / smallest special-term scale (degree 11: fit error ~1e-15)
 U_SUPPORT = 6.0 * np.sqrt(2.0)   # |x - centre| / scale beyond which erf / the Gaussian are at their limits to 1e-16
@@ -636,6 +637,7 @@ def _compile_uform(cm, u_info, polyclass, separable):
     cm.umono = np.zeros((U_PMAX + 1) ** 2)
     cm.ugeo = np.zeros(2 * max(1, cm.D))
     cm.u_size, cm.u_err_off = 0, 0
+    cm.u_h_off, cm.u_h_cls, cm.u_h_ng = 0, 0, 0
     if not separable or any(u['complex'] for u in u_info):
         return
     if any(g[1] > U_PMAX for u in u_info for g in u['groups']) or \
@@ -664,6 +666,23 @@ def _compile_uform(cm, u_info, polyclass, separable):
     cm.ucomp = np.concatenate((ucomp.ravel(), state.ravel())).astype(np.int32)
     cm.ugrp = ugrp.ravel().copy()
     cm.u_static = True
+    # hot records (include/ttm.h "H section"): all-hit sweeps of maps with few groups per component
+    need = PLAN_HF | PLAN_XHIT | PLAN_EHIT
+    all_hit = True
+    mb = ma = 0
+    for k in range(cm.D):
+        for g in range(int(ucomp[k, 2])):
+            fl = int(ugrp[int(ucomp[k, 3]) + g, 1])
+            hit = (fl & PLAN_XHIT) and ((fl & need) == need or not (fl & PLAN_HF))
+            all_hit = all_hit and bool(hit)
+            if fl & PLAN_HF:
+                mb = max(mb, (fl >> 16) & 15)
+            if fl & UGF_POLY:
+                ma = max(ma, (fl >> 24) & 15)
+    ng = int(max(ucomp[:, 2], default=0))
+    if all_hit and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
+        cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
+        cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
     uform_geometry(cm)
 
 
@@ -767,7 +786,12 @@ def uform_geometry(cm, kappa=None):
         uc[k, 5] = off
         off += U_TSTRIDE * nI
     cm.u_err_off = off
-    cm.u_size = off + 2 * cm.D + (off % 2)
+    off += 2 * cm.D
+    off += (-off) % 8
+    cm.u_h_off = off
+    if cm.u_h_cls:
+        off += cm.D * (H_HDR + cm.u_h_ng * H_GS[cm.u_h_cls])
+    cm.u_size = off + (off % 2)
     cm.ugeo = geo.ravel().copy()
     cm.u_enabled = bool(ok)
     return cm.u_enabled

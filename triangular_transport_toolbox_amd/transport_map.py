@@ -204,6 +204,16 @@ class transport_map():
         torch = _torch()
         return torch.zeros(shape, dtype=dtype or torch.float64, device=self._dev)
 
+    @staticmethod
+    def _ld(N):
+        """Leading dimension of column-major sample matrices: N rounded up to even, so that every column starts
+        16-byte aligned and can be read in pairs (what the loader-wave kernels need, include/ttm.h)."""
+        return int(N) + (int(N) & 1)
+
+    def _cols(self, ncols, N, zero=False):
+        """Column-major ncols x N device matrix with padded leading dimension (a (ncols, ld) tensor)."""
+        return (self._zeros if zero else self._empty)(int(ncols), self._ld(N))
+
     def _stream(self):
         if self._dev.type != 'cuda':
             return None
@@ -280,10 +290,10 @@ class transport_map():
         X = np.ascontiguousarray(X, dtype=np.float64)
         N, d = X.shape
         Xrow = self._to_dev(X)
-        Xs = self._empty(d, N)
+        Xs = self._cols(d, N, zero=True)
         mean = self._mean_d if standardize else None
         sd = self._std_d if standardize else None
-        _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(Xs), N,
+        _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(Xs), Xs.shape[1],
                                          self._stream()))
         return Xs
 
@@ -346,13 +356,13 @@ class transport_map():
         elif self.standardization.lower() in ('quantile', 'quantiles'):
             # median / quantile spread per column (TM:775-778) from device order statistics; the
             # quantiles of X - median are the quantiles of X minus the median (monotone shift)
-            Xraw = self._empty(d, N)
+            Xraw = self._cols(d, N, zero=True)
             Xrow = self._to_dev(X)
-            _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, None, None, self._ptr(Xraw), N, self._stream()))
+            _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, None, None, self._ptr(Xraw), Xraw.shape[1], self._stream()))
             med, spread = np.empty(d), np.empty(d)
             for j in range(d):
-                med[j] = self._device_quantile(Xraw[j], [0.5])[0]
-                qs = self._device_quantile(Xraw[j], [0.8413447460685429, 0.15865525393145707], shift=med[j])
+                med[j] = self._device_quantile(Xraw[j, :N], [0.5])[0]
+                qs = self._device_quantile(Xraw[j, :N], [0.8413447460685429, 0.15865525393145707], shift=med[j])
                 spread[j] = (qs[0] - qs[1]) / 2
             self.X_mean, self.X_std = med, spread
         else:
@@ -408,7 +418,7 @@ class transport_map():
         def column_quantiles(var, q):
             key = (var, tuple(np.asarray(q, dtype=float).tolist()))
             if key not in memo:
-                memo[key] = self._device_quantile(self._Xs[var], q)
+                memo[key] = self._device_quantile(self._Xs[var, :self._N], q)
             return memo[key]
         termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
         self._cm.fill_special_terms(self.special_terms)
@@ -470,16 +480,16 @@ class transport_map():
         """TM:2391-2437: Z[:, k] = S_k(x) for all map components."""
         Xs, N = self._samples_for(X)
         coef = self._pack_coeffs()
-        Z = self._empty(self.D, N)
+        Z = self._cols(self.D, N)
         _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
-                                          self._ptr(Z), N, None, None, None, self._stream()))
+                                          self._ptr(Z), Z.shape[1], None, None, None, self._stream()))
         return self._export(Z, N, 0, self.D, False)
 
     # device-resident entry points (column-major tensors in, column-major tensors out; no PCIe traffic)
     def forward_device(self, Xs, N, coef=None, Z=None, logdet=None, sigma=None, sumsq=None):
         """S(x) for a standardised column-major device matrix Xs (d x N) -> Z (D x N)."""
         coef = self._pack_coeffs() if coef is None else coef
-        Z = self._empty(self.D, N) if Z is None else Z
+        Z = self._cols(self.D, N) if Z is None else Z
         _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
                                           self._ptr(Z), Z.shape[1], self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq),
                                           self._stream()))
@@ -489,7 +499,7 @@ class transport_map():
         """S^{-1}(z) for a column-major device matrix Zs (D x N) -> standardised X (d x N);
         conditioning columns (if any) must already be in X."""
         coef = self._pack_coeffs() if coef is None else coef
-        X = self._zeros(self._cm.d_cols, N) if X is None else X
+        X = self._cols(self._cm.d_cols, N, zero=True) if X is None else X
         if table is None:
             table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
         if table:
@@ -507,10 +517,10 @@ class transport_map():
             x = np.asarray(x)
             Xs, N = self._import(x, False), x.shape[0]
         coef = self._pack_coeffs(k, coeffs_nonmon, coeffs_mon)
-        Z = self._empty(1, N)
+        Z = self._cols(1, N)
         _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, int(k), int(k) + 1,
-                                          self._ptr(Z), N, None, None, None, self._stream()))
-        return Z[0].cpu().numpy()
+                                          self._ptr(Z), Z.shape[1], None, None, None, self._stream()))
+        return Z[0, :N].cpu().numpy()
 
     def basis(self, k, which, x=None):
         """Basis matrices of component k on standardised samples (None = training):
@@ -542,7 +552,7 @@ class transport_map():
         sigma = self._to_dev(np.asarray(self.X_std[off:off + self.D], dtype=float))
         coef = self._pack_coeffs()
         ld = self._empty(N)
-        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xraw), N, N, 0, self.D, None, N,
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xraw), Xraw.shape[1], N, 0, self.D, None, N,
                                           self._ptr(ld), self._ptr(sigma), None, self._stream()))
         return ld
 
@@ -602,13 +612,13 @@ class transport_map():
         ncomp = k1 - k0
         if Z.shape[-1] < ncomp:
             raise IndexError('Z has %d columns, %d are needed' % (Z.shape[-1], ncomp))
-        Xs = self._zeros(d, N)
+        Xs = self._cols(d, N, zero=True)
         if Xstar_cols is not None and E > 0:
             cols = np.array(Xstar_cols, dtype=float, copy=True)
             if self.standardize_samples:
                 cols -= self.X_mean[:E]
                 cols /= self.X_std[:E]
-            Xs[:E].copy_(torch.from_numpy(np.ascontiguousarray(cols.T)))
+            Xs[:E, :N].copy_(torch.from_numpy(np.ascontiguousarray(cols.T)))
         Zs = self._to_dev(np.ascontiguousarray(Z[:, :ncomp].T))
         coef = self._pack_coeffs()
         table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
@@ -650,7 +660,7 @@ class transport_map():
                                                       ctypes.c_void_p(uns_d.data_ptr()), st))
         trunc = 1 if self.root_search_truncation else 0
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(out_d),
+                                                self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(out_d),
                                                 self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
                                                 self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
         if int(uns_d.max().item()) == 0:
@@ -668,7 +678,7 @@ class transport_map():
         bkt_d = self._to_dev(bkt, dtype=torch.int32)
         tmin_d, tmax_d = self._to_dev(tmin), self._to_dev(tmax)
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                self._ptr(Zs), N, self._ptr(Xs), N, N, self._ptr(tab_x_d),
+                                                self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(tab_x_d),
                                                 self._ptr(tab_y_d), resolution, resolution, None, self._ptr(tmin_d),
                                                 self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
 
@@ -684,13 +694,13 @@ class transport_map():
         owns_first = dist is None or dist.get_rank() == 0
         first = 1 if owns_first else 0
         if N - first > 0:
-            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs, first), N,
-                                                     self._ptr(Xs, first), N, N - first,
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs, first), Zs.shape[1],
+                                                     self._ptr(Xs, first), Xs.shape[1], N - first,
                                                      ctypes.c_void_p(iters.data_ptr()), None, self._stream()))
         self._allreduce(iters, op='max')
         if owns_first:
             dummy = self._zeros(ncomp, dtype=torch.int32)
-            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs), N, self._ptr(Xs), N, 1,
+            _capi.check(self._lib.ttm_inverse_bisect(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1, self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], 1,
                                                      ctypes.c_void_p(dummy.data_ptr()), ctypes.c_void_p(iters.data_ptr()),
                                                      self._stream()))
         if self.verbose and int(iters.max().item()) >= 100:
