@@ -206,7 +206,8 @@ extern "C" {
  * fixed-stride record per component holding everything a sweep step needs, so that the kernel issues all scalar
  * loads of a step at once instead of chasing ucomp -> ugrp -> U offsets:
  *   header, TTM_H_HDR doubles: int32 {put slot (2 x way, -1: none), flags (bit 0: store exp(-x_kc^2/4) too)},
- *           int32 {NI, kc}, c0, -t_lo/h, 1/h, 2/h, int32 {TAB_OFF, number of groups}, 0
+ *           int32 {NI, kc}, c0, -t_lo/h, 1/h, 2/h, int32 {TAB_OFF, number of groups}, constant of the
+ *           nonmonotone part alone (c0 also carries the monotone constants)
  *   u_h_ng group records of GS doubles: int32 {slot of the column (2 x way), 1} ({0, 0} for the padding records
  *           beyond the component's own groups), B[0..DB], A[0..DA], zero padding;
  *           (DB, DA, GS) = (3,1,8) / (5,5,16) / (7,7,24) for u_h_cls = 1 / 2 / 3.

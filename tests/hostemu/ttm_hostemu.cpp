@@ -43,6 +43,7 @@ struct XFake {
 };
 
 const double kErfTab[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
+const double kExpQTab[TTM_EXPQ_TABLE_LEN] = { TTM_EXPQ_TABLE_VALUES };
 
 Prog make_prog(const ttm_program* p) {
     Prog g;
@@ -137,7 +138,7 @@ void forward_h(const ttm_program* p, const double* fold, const XA& xa, int k0, i
     double cbuf[2 * TTM_PLAN_WAYS * lanes_of<R>::value];
     for (auto& c : cbuf) c = 0.0;
     (void)ways;
-    CacheStore<R> st{cbuf, 1};
+    CacheStore<R> st{cbuf, 1};               // (no exp table: as k_forward_hl)
     PlanCache<XA, R> x(xa, st);
     if (k0 > 0) x.warm(p->ucomp + TTM_UC_STATE(p->D, k0));
     ld = R(0.0); ss = R(0.0);
@@ -247,7 +248,7 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
             const double* geo = p->ugeo + 2 * k;
             if (uc[TTM_UC_NI] > TTM_U_NI_MAX) return TTM_E_LIMIT;
             uform_build_groups(uc, p->ugrp, fd, p->umono, geo, foldk, U, 0, 1);
-            if (p->u_h_cls > 0) uform_build_hot(uc, p->ugrp, U, p->u_h_off, p->u_h_cls, p->u_h_ng, k, 0, 1);
+            if (p->u_h_cls > 0) uform_build_hot(uc, p->ugrp, U, p->u_h_off, p->u_h_cls, p->u_h_ng, k, foldk[0], 0, 1);
             double ev = 0.0, ed = 0.0;
             if (uc[TTM_UC_NI] > 0) {
                 uform_spline_nodes(uc, fd, geo, foldk, ybuf.data(), 0, 1);
@@ -347,7 +348,9 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
             const int64_t n1 = n + 1 < N ? n + 1 : n;
             XSoA2 xa{X, ldx, n, n1};
             VecD<2> ld, ss;
-            forward_u<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
+            const bool hot = p->u_h_cls > 0 && !getenv("TTM_EMU_NO_HOT");
+            if (!(hot && forward_h_dispatch<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr)))
+                forward_u<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
             for (int k = k0; k < k1; ++k) {
                 Z[(int64_t)(k - k0) * ldz + n] = S[k - k0].v[0];
                 Z[(int64_t)(k - k0) * ldz + n1] = S[k - k0].v[1];
@@ -417,6 +420,7 @@ int emu_math(int which, const double* a, const double* b, int64_t n, double* out
             case 2: erf_gauss_tab<true>(kErfTab, a[i], e, g); out[i] = g; break;
             case 3: out[i] = fast_log(a[i]); break;
             case 4: out[i] = fast_rcp(a[i]); break;
+            case 6: out[i] = exp_q_tab(kExpQTab, a[i]); break;
             default: out[i] = fast_div(a[i], b[i]); break;
         }
     }
@@ -521,8 +525,49 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                       int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
                       int32_t truncate, void*) {
-    (void)bkt; (void)nb; (void)h_y_affine;   // the host double does the full search; the accelerated search must give the same index
     const Prog g = make_prog(p);
+    if (u_on(p) && p->u_h_cls >= 1 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
+        (nb + 1) % 4 == 0 && !getenv("TTM_EMU_NO_HOT")) {
+        // hot records + bucket scan + computed linspace abscissae: what k_inverse_hl evaluates
+        const double* U = fold + fold_base_size(p);
+        const int cls = p->u_h_cls, ng = p->u_h_ng;
+        const int GS = u_h_gs(cls), hs = TTM_H_HDR + ng * GS;
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+            double cbuf[2 * TTM_PLAN_WAYS];
+            for (auto& c : cbuf) c = 0.0;
+            CacheStore<double> st{cbuf, 1, kExpQTab};
+            PlanCache<XSoA, double> x(xa, st);
+            if (k0 > 0) x.warm(p->ucomp + TTM_UC_STATE(p->D, k0));
+            for (int k = k0; k < k1; ++k) {
+                const double* rec = U + p->u_h_off + (int64_t)k * hs;
+                double off;
+#define TTM_HO(NGV, C, DBV, DAV, GSV) if (ng == NGV && cls == C) off = h_offset<NGV, DBV, DAV, GSV, double>(rec, st)
+                TTM_HO(2, 1, 3, 1, 8); TTM_HO(2, 2, 5, 5, 16); TTM_HO(2, 3, 7, 7, 24);
+                TTM_HO(4, 1, 3, 1, 8); TTM_HO(4, 2, 5, 5, 16); TTM_HO(4, 3, 7, 7, 24);
+#undef TTM_HO
+                const double lo = tmin[k - k0], hi = tmax[k - k0];
+                const double scale = (double)nb / (hi - lo);
+                const bool use_bkt = scale > 0.0 && scale < 1.0e300;
+                double target = -off + Z[(int64_t)(k - k0) * ldz + n];
+                if (truncate) {
+                    if (target < lo) target = lo;
+                    if (target > hi) target = hi;
+                }
+                const double* xs = tab_x + (int64_t)(k - k0) * T;
+                const int a = h_search(xs, bkt + (int64_t)(k - k0) * (nb + 1), nb, T, lo, scale, use_bkt, target);
+                const int i = a < 1 ? 1 : (a > T - 1 ? T - 1 : a);
+                const double y_lo = (double)(i - 1) * h_y_affine[1] + h_y_affine[0];
+                const double y_hi = (i == T - 1) ? h_y_affine[2] : (double)i * h_y_affine[1] + h_y_affine[0];
+                const double slope = fast_div(y_hi - y_lo, xs[i] - xs[i - 1]);
+                const double r = slope * (target - xs[i - 1]) + y_lo;
+                h_put(rec, st, r);
+                X[(int64_t)((const int*)rec)[3] * ldx + n] = r;
+            }
+        }
+        return 0;
+    }
+    (void)bkt; (void)nb; (void)h_y_affine;   // below: the full search; the accelerated search must give the same index
     if (all_fast(p, k0, k1)) {               // planned column cache, one sample at a time through all components
         for (int64_t n = 0; n < N; ++n) {
             XSoA xa{X, ldx, n};

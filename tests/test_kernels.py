@@ -90,11 +90,16 @@ def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
         assert np.array_equal(tm.evaluate_pullback_density(X), p1)
         assert np.array_equal(tm.inverse_map(npz['inv_Z']), I1)
         # the loader-wave kernels (U-form maps; chosen automatically for large ensembles) - odd N, ragged last tile
+        # (hot-record kernels take exp(-x^2/4) from the 2^(j/32) table: same values to rounding, not bit for bit)
         monkeypatch.setenv('TTM_U_LOADER', '1')
-        assert np.array_equal(tm.map(X), Z1)
-        assert np.array_equal(tm.evaluate_pullback_density(X), p1)
-        assert np.array_equal(tm.map(X[:1]), Z1[:1])
-        assert np.array_equal(tm.map(X[:513]), Z1[:513])
+        ZL = tm.map(X)
+        assert relerr(ZL, Z1) < 1e-12
+        assert relerr(tm.evaluate_pullback_density(X), p1) < 1e-10
+        assert np.array_equal(tm.map(X[:1]), ZL[:1])
+        assert np.array_equal(tm.map(X[:513]), ZL[:513])
+        # (the loader-wave inverse evaluates the offsets in U-form: same values to rounding, not bit for bit)
+        assert relerr(tm.inverse_map(npz['inv_Z']), I1) < 1e-12
+        assert relerr(tm.inverse_map(npz['inv_Z'][:1]), I1[:1]) < 1e-12
 
 
 def test_large_ensemble_properties(backend):

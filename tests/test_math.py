@@ -69,3 +69,20 @@ def test_log_rcp_div():
     b = rng.standard_normal(100000) * np.exp(rng.uniform(-50, 50, 100000))
     assert ulps(run(4, b), 1.0 / b).max() <= 1.0
     assert ulps(run(5, a, b), a / b).max() <= 1.0
+
+
+def test_exp_q_table():
+    """exp(-x^2/4) from the 32-entry 2^(j/32) table (hot kernels): <= 2 ulp, NaN in -> NaN out, +-inf -> 0."""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-12, 12, 100000), rng.standard_normal(100000), np.linspace(-60, 60, 4001),
+                        [0.0, -0.0, 1e-200, 54.0, -54.0]])
+    got = run(6, x)
+    mp.mp.dps = 30
+    sub = np.r_[0:3000, 100000:103000, 200000:204006]
+    # (relative to exp of the ROUNDED argument -x*x/4, as NumPy's np.exp(-x**2/4) in the reference is)
+    ref = np.array([float(mp.exp(mp.mpf(float(-0.25 * (v * v))))) for v in x[sub]])
+    ok = ref > 1e-300
+    assert ulps(got[sub][ok], ref[ok]).max() <= 2.0
+    assert np.abs(got[sub][~ok]).max(initial=0.0) < 1e-299
+    assert np.isnan(run(6, [np.nan]))[0]
+    assert run(6, [np.inf])[0] == 0.0 and run(6, [-np.inf])[0] == 0.0 and run(6, [1e200])[0] == 0.0

@@ -278,6 +278,7 @@ template <class R>
 struct CacheStore {          // 8 values per sample: x of four columns, then their exp(-x^2/4)
     double* base;            // this thread's column
     int stride;              // doubles between consecutive slots of one element
+    const double* etab = nullptr;    // 2^(j/32) table for exp_q_tab (hot kernels only)
     TTM_HD R get(int i) const {
         R r;
 #pragma unroll
@@ -695,7 +696,7 @@ struct PlanCache {
             if (v >= 0) {
                 const R x = xa(v & ~TTM_PLAN_E);
                 st.set(2 * w, x);
-                if (v & TTM_PLAN_E) st.set(2 * w + 1, fast_exp(-0.25 * (x * x)));
+                if (v & TTM_PLAN_E) st.set(2 * w + 1, st.etab ? exp_q_tab(st.etab, x) : fast_exp(-0.25 * (x * x)));
             }
         }
     }

@@ -128,6 +128,7 @@ struct XFake {               // TM:4050-4051: zeros except column kc
 };
 
 __device__ const double g_erf_table[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
+__device__ const double g_expq_table[TTM_EXPQ_TABLE_LEN] = { TTM_EXPQ_TABLE_VALUES };
 
 extern __shared__ __align__(16) double g_smem[];
 
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void k_uform(DevProg P, UTabs T, const double*
     uform_build_groups(uc, T.ugrp, fd, T.umono, geo, foldk, U, tid, bd);
     if (h_cls > 0) {
         __syncthreads();
-        uform_build_hot(uc, T.ugrp, U, h_off, h_cls, h_ng, k, tid, bd);
+        uform_build_hot(uc, T.ugrp, U, h_off, h_cls, h_ng, k, foldk[0], tid, bd);
     }
     double ev = 0.0, ed = 0.0;
     if (uc[TTM_UC_NI] > 0) {
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
                                                     const double* __restrict__ X, int64_t ldx, int64_t N,
                                                     double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
                                                     const double* __restrict__ sigma, double* __restrict__ sumsq,
-                                                    int tab_slot, int xlead, int tlead) {
+                                                    int tab_slot, int xlead, int tlead, int ways) {
     typedef VecD<2> R;
     const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
@@ -1004,6 +1005,7 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
     CacheStore<R> cst;
     cst.base = cache + tid;
     cst.stride = 256;
+    (void)ways;
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
     bool act0 = false, act1 = false;
     int64_t ctile = blockIdx.x;
@@ -1056,6 +1058,207 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
         } else {
             ++k;
         }
+        TTM_RAW_BARRIER();                                               // A(s + 1)
+    }
+}
+
+__device__ __forceinline__ void ul_dma4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// Table inverse from hot records with loader waves (same workgroup anatomy and barrier protocol as k_forward_hl):
+// wave 4 streams the z_k columns, wave 5 the 1001-point table and its bucket index of the component, both by
+// LDS-DMA; the evaluating waves (two adjacent samples per thread) compute the nonmonotone offset from the planned
+// column cache, search the staged table (np.searchsorted left: bucket start + forward scan, four entries at a
+// time), interpolate with interp1d's slope form, put x_k into the cache and store it.  The abscissae are the
+// computed np.linspace (yreg semantics of k_inverse_table).  Requires (nb + 1) % 4 == 0.
+// LDS (doubles): [z ring: (xlead+1) x 512 | table ring: (tlead+1) x tab_slot | column cache: 2 x ways x 2 x 256]
+// table slot: [xs: T rounded up to even | bucket index: nb + 1 int32]
+template <int NG, int CLS>
+__global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+                                                    int D, int k0, int k1,
+                                                    const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
+                                                    const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
+                                                    const double* __restrict__ tmin, const double* __restrict__ tmax,
+                                                    const int* __restrict__ bkt, int nb, int truncate,
+                                                    int tab_slot, int xlead, int tlead, int ways) {
+    typedef VecD<2> R;
+    const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
+    constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
+    constexpr int HS = TTM_H_HDR + NG * GS;
+    cdbl_p H = (cdbl_p)(U_ + h_off);
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int ncomp = k1 - k0;
+    const int64_t ntiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+    if ((int64_t)blockIdx.x >= ntiles) return;
+    const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t S = my_tiles * ncomp;
+    double* ring = g_smem;
+    double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
+    double* cache = tabs + (size_t)TSLOTS * tab_slot;
+    const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
+
+    if (wv == 4) {
+        // ---- z loader -------------------------------------------------------------------------------------------
+        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
+        int64_t ptile = blockIdx.x;
+        int pk = k0;
+        int64_t pstep = 0;
+        int xs = 0;
+        auto issue = [&](int64_t step) {
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
+            }
+            const double* col = Z + (int64_t)(pk - k0) * ldz;
+            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
+            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+#pragma unroll
+            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
+                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
+                pair = pair < last_pair ? pair : last_pair;
+                ul_dma16(col + pair, slot + c * 128);
+            }
+        };
+        for (int j = 0; j < xlead; ++j) issue(j);
+        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+        TTM_RAW_BARRIER();
+        for (int64_t s = 0; s < S; ++s) {
+            issue(s + xlead);
+            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+            TTM_RAW_BARRIER();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    if (wv == 5) {
+        // ---- table loader: xs row (T doubles) + bucket row (nb + 1 int32) -----------------------------------------
+        int pk = k0;
+        int64_t pstep = 0;
+        int ts = 0;
+        const int bytes1 = (T * 8) & ~15, tail4 = (T * 8 - bytes1) / 4;       // 16-byte units, then 0 or 2 dwords
+        const int bytes2 = (nb + 1) * 4;
+        const int nch1 = (bytes1 + 1023) >> 10, nch2 = (bytes2 + 1023) >> 10;
+        auto issue = [&](int64_t step) -> int {
+            while (pstep < step && pstep < S - 1) {
+                ++pstep;
+                if (++pk == k1) pk = k0;
+            }
+            const char* src1 = (const char*)(tab_x + (int64_t)(pk - k0) * T);
+            const char* src2 = (const char*)(bkt + (int64_t)(pk - k0) * (nb + 1));
+            double* slot = tabs + (size_t)ts * tab_slot;
+            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+            for (int c = 0; c < nch1; ++c) {
+                const int off = c * 1024 + lane * 16;
+                if (off < bytes1) ul_dma16(src1 + off, slot + c * 128);
+            }
+            if (lane < tail4) ul_dma4(src1 + bytes1 + lane * 4, (char*)slot + bytes1);
+            for (int c = 0; c < nch2; ++c) {
+                const int off = c * 1024 + lane * 16;
+                if (off < bytes2) ul_dma16(src2 + off, slot + Teven + c * 128);
+            }
+            return nch1 + (tail4 ? 1 : 0) + nch2;
+        };
+        issue(0);
+        const int n1 = tlead > 1 ? issue(1) : 0;
+        ul_wait_vmcnt(n1);
+        TTM_RAW_BARRIER();
+        for (int64_t s = 0; s < S; ++s) {
+            const int n = issue(s + tlead);
+            ul_wait_vmcnt(tlead > 1 ? n : 0);
+            TTM_RAW_BARRIER();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- evaluating waves -------------------------------------------------------------------------------------------
+    CacheStore<R> cst;
+    cst.base = cache + tid;
+    cst.stride = 256;
+    double* etab = cache + (size_t)2 * ways * 2 * 256;                   // 2^(j/32), behind the column cache
+    if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
+    cst.etab = etab;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bool act0 = false, act1 = false;
+    int64_t ctile = blockIdx.x;
+    int k = k0;
+    int xs = 0, ts = 0;
+    // sentinels behind the table entries of every slot (the DMAs only ever write the first T doubles)
+    if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TTM_RAW_BARRIER();                                                   // A(0)
+    for (int64_t s = 0; s < S; ++s) {
+        cdbl_p rec = H + (int64_t)k * HS;
+        if (k == k0) {
+            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
+            act0 = n < N; act1 = n + 1 < N;
+            if (k0 > 0) {                                                // (conditional inverse: columns given in X)
+                XOffN<2> cx;
+                cx.X = (const char*)X; cx.ldb = ldx * 8;
+                cx.off[0] = (unsigned int)(act0 ? n : N - 1) * 8u;
+                cx.off[1] = (unsigned int)(act1 ? n + 1 : N - 1) * 8u;
+                PlanCache<XOffN<2>, R> x(cx, cst);
+                x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
+            }
+        }
+        const D2 zp = *(const D2*)(ring + (size_t)xs * TTM_UL_ROWS + 2 * tid);
+        const double* xsl = tabs + (size_t)ts * tab_slot;
+        const int* bkl = (const int*)(xsl + Teven);
+        xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+        ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+        const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
+        // bucket number of a target: (target - lo) nb / (hi - lo); the search starts one bucket lower, so the
+        // last-bit difference between this reciprocal and the division of the index kernel does not matter
+        const double scale = (double)nb * fast_rcp(hi - lo);
+        const bool use_bkt = scale > 0.0 && scale < 1.0e300;
+        const R off = h_offset<NG, DB, DA, GS, R>(rec, cst);
+        double tg[2];
+        int a[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            double target = -off.v[e] + (e ? zp.y : zp.x);
+            if (truncate) {                          // TM:4074-4076 (comparisons keep NaN untouched)
+                if (target < lo) target = lo;
+                if (target > hi) target = hi;
+            }
+            tg[e] = target;
+            int q = (int)((target - lo) * scale) - 1;
+            q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
+            a[e] = use_bkt ? bkl[q] : 0;
+        }
+        // np.searchsorted(xs, target) (left) = a + #{entries from a on that are < target}: both samples scan four
+        // entries per round together (a finished sample re-counts 0); the table is followed by +inf sentinels
+        for (int round = 0; round < 4096; ++round) {
+            int c[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double* q4 = xsl + a[e];
+                c[e] = (q4[0] < tg[e] ? 1 : 0) + (q4[1] < tg[e] ? 1 : 0) + (q4[2] < tg[e] ? 1 : 0) + (q4[3] < tg[e] ? 1 : 0);
+                a[e] += c[e];
+            }
+            if (c[0] < 4 && c[1] < 4) break;
+        }
+        R r;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = a[e] < 1 ? 1 : (a[e] > T - 1 ? T - 1 : a[e]);
+            const double x_lo = xsl[i - 1], x_hi = xsl[i];
+            const double y_lo = (double)(i - 1) * ystep + y0;
+            const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
+            const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
+            r.v[e] = slope * (tg[e] - x_lo) + y_lo;
+        }
+        h_put(rec, cst, r);
+        {
+            const int kc = ((cint_p)rec)[3];
+            double* xc = X + (int64_t)kc * ldx + ctile * TTM_UL_ROWS + 2 * tid;
+            if (act1) { D2 o = {r.v[0], r.v[1]}; *(D2*)xc = o; }
+            else if (act0) *xc = r.v[0];
+        }
+        if (k + 1 == k1) { ctile += gridDim.x; k = k0; }
+        else ++k;
         TTM_RAW_BARRIER();                                               // A(s + 1)
     }
 }
@@ -1521,6 +1724,22 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
 
 static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }   // + read-ahead padding, even
 
+// dynamic LDS above 64 KB has to be allowed per kernel; remember what was granted (the call is not free)
+static void allow_big_lds(const void* kern, size_t bytes) {
+    static thread_local const void* seen[64];
+    static thread_local size_t granted[64];
+    static thread_local int n = 0;
+    for (int i = 0; i < n; ++i)
+        if (seen[i] == kern) {
+            if (granted[i] >= bytes) return;
+            granted[i] = bytes;
+            (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            return;
+        }
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (n < 64) { seen[n] = kern; granted[n] = bytes; ++n; }
+}
+
 static int plan_ways_of(const ttm_program* p) {
     return (p->plan_ways < 1 || p->plan_ways > TTM_PLAN_WAYS) ? TTM_PLAN_WAYS : p->plan_ways;
 }
@@ -1586,12 +1805,12 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             }
             nchmax = (nimax * TTM_U_TSTRIDE * 8 + 1023) >> 10;
             const int tab_slot = TTM_U_TSTRIDE * nimax;                   // doubles (nI is even: 16-byte multiple)
-            int xlead = 3, tlead = 1;
+            int xlead = 3, tlead = 2;
             if (const char* e = getenv("TTM_U_XLEAD")) xlead = atoi(e);
             if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
             xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
             tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
-            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256) * 8;
+            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256 + TTM_EXPQ_TABLE_LEN) * 8;
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
@@ -1600,7 +1819,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             if (const char* e = getenv("TTM_U_LOADER")) use_ul = aligned && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 && atoi(e) != 0;
             if (use_ul && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT")) {
                 typedef void (*hkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*,
-                                        int64_t, double*, const double*, double*, int, int, int);
+                                        int64_t, double*, const double*, double*, int, int, int, int);
                 hkern_t hk;
 #define TTM_HK(L, NGV) (p->u_h_cls == 1 ? k_forward_hl<L, NGV, 1> : p->u_h_cls == 2 ? k_forward_hl<L, NGV, 2> : k_forward_hl<L, NGV, 3>)
                 if (p->u_h_ng == 2) hk = logdet ? TTM_HK(true, 2) : TTM_HK(false, 2);
@@ -1612,11 +1831,10 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
                 const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
-                hipError_t he = hipFuncSetAttribute((const void*)hk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ul);
-                (void)he;
+                allow_big_lds((const void*)hk, lds_ul);
                 hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp,
                                    fold + fold_base_size(p), (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz,
-                                   logdet, sigma, sumsq, tab_slot, xlead, tlead);
+                                   logdet, sigma, sumsq, tab_slot, xlead, tlead, ways);
                 return check_launch("k_forward_hl");
             }
             if (use_ul) {
@@ -1640,8 +1858,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
                 const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
-                hipError_t he = hipFuncSetAttribute((const void*)lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ul);
-                (void)he;
+                allow_big_lds((const void*)lk, lds_ul);
                 hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp, p->ugrp,
                                    fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq,
                                    tab_slot, xlead, tlead);
@@ -1757,6 +1974,44 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         T < 8 || T > 65536 || nb < 4 || nb > 65536 || (ldy != 0 && ldy < T) || (h_y_affine && ldy != 0))
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
+    // large ensembles of maps with hot records: loader-wave kernel
+    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
+        h_y_affine && ldy == 0 && (nb + 1) % 4 == 0 && T <= 4096 && !getenv("TTM_U_NO_HOT")) {
+        const int ways = plan_ways_of(p);
+        int xlead = 2, tlead = 1;          // (three workgroups per CU with the 12 KB table slots)
+        if (const char* e = getenv("TTM_U_XLEAD")) xlead = atoi(e);
+        if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
+        xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
+        tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
+        const int Teven = (T + 4 + 1) & ~1;                              // entries + 4 sentinels, even
+        const int tab_slot = Teven + (nb + 1 + 1) / 2;                   // doubles
+        const int nops = ((((T * 8) & ~15) + 1023) >> 10) + ((T & 1) ? 1 : 0) + (((nb + 1) * 4 + 1023) >> 10);
+        const size_t lds = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256 + TTM_EXPQ_TABLE_LEN) * 8;
+        const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
+                             ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ((uintptr_t)bkt % 16 == 0) && ((uintptr_t)tab_x % 8 == 0);
+        bool use = aligned && N >= 64 * 1024 && nops <= 15 && lds <= (size_t)160 * 1024 / 2;
+        if (const char* e = getenv("TTM_U_LOADER")) use = aligned && nops <= 15 && lds <= (size_t)160 * 1024 && atoi(e) != 0;
+        if (use) {
+            typedef void (*ikern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t,
+                                    const double*, int, double, double, double, const double*, const double*, const int*, int, int,
+                                    int, int, int, int);
+            ikern_t ik;
+#define TTM_IK(NGV) (p->u_h_cls == 1 ? k_inverse_hl<NGV, 1> : p->u_h_cls == 2 ? k_inverse_hl<NGV, 2> : k_inverse_hl<NGV, 3>)
+            if (p->u_h_ng == 2) ik = TTM_IK(2); else ik = TTM_IK(4);
+#undef TTM_IK
+            int wgs = (int)((size_t)(160 * 1024) / lds);
+            if (wgs > 5) wgs = 5;
+            if (wgs < 1) wgs = 1;
+            if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+            const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+            const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
+            allow_big_lds((const void*)ik, lds);
+            hipLaunchKernelGGL(ik, dim3((unsigned)grid), dim3(384), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
+                               (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine[0],
+                               h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, xlead, tlead, ways);
+            return check_launch("k_inverse_hl");
+        }
+    }
     const int bd = 256;
     int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)
     if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob

@@ -101,6 +101,45 @@ TTM_HD double erf_tab(const double* tab, double t) {
     return e;
 }
 
+// exp(-x^2/4) from a 32-entry table of 2^(j/32) (staged in LDS by the hot kernels: per-lane gathers, 32 entries =
+// one 8-byte bank each, conflict-free): y = -x^2/4 = (32 e + j) ln2/32 + r, |r| <= ln2/64, exp(y) = 2^e T[j] p(r) with
+// the degree-6 Taylor polynomial (truncation 3.5e-18): 22 instructions instead of the 30 of fast_exp, <= 2 ulp.
+// NaN / inf: x = NaN gives NaN (through r); x = +-inf gives 0 (y is clamped at -800).  Meant for the cached
+// E(x_j) of the map kernels, which only ever multiplies a polynomial of the same x_j.
+#define TTM_EXPQ_TABLE_LEN 32
+#define TTM_EXPQ_TABLE_VALUES \
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0, \
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0, \
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0, \
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0, \
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0, \
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0, \
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0, \
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0
+
+TTM_HD double exp_q_tab(const double* tab, double x) {
+    double y = -0.25 * (x * x);
+    y = (y < -800.0) ? -800.0 : y;                                   // (a compare keeps NaN; fmax would drop it)
+    const double k = rint(y * 0x1.71547652b82fep+5);                 // 32 / ln 2
+    double r = fma(k, -0x1.62e42fee00000p-6, y);                     // ln2/32 = hi + lo, hi has 32 significant bits
+    r = fma(k, -0x1.a39ef35793c76p-38, r);
+    const int ki = (int)k;
+    const double t = tab[ki & 31];
+    double p = fma(0.001388888888888889, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(t * p, ki >> 5);
+}
+template <int N> TTM_HD VecD<N> exp_q_tab(const double* tab, const VecD<N>& x) {
+    VecD<N> r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.v[i] = exp_q_tab(tab, x.v[i]);
+    return r;
+}
+
 TTM_HD double fast_log(double x) {
     int e;
     double m = frexp(x, &e);                          // [0.5, 1)

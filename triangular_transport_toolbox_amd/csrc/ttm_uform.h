@@ -183,7 +183,8 @@ TTM_HD int u_h_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : 7); }
 TTM_HD int u_h_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : 7); }
 
 // hot record of one component (include/ttm.h "H section"), from its U-form block; run after uform_build_groups.
-TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_off, int cls, int ng, int k,
+// nm0: the constant of the nonmonotone part alone (folded[0]; c0 also carries the monotone constants)
+TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_off, int cls, int ng, int k, double nm0,
                             int first, int stride) {
     const int GS = u_h_gs(cls), DB = u_h_db(cls), DA = u_h_da(cls);
     const int hs = TTM_H_HDR + ng * GS;
@@ -197,6 +198,7 @@ TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_o
             else if (idx == 1) v = u_pack2(uc[TTM_UC_NI], uc[TTM_UC_KC]);
             else if (idx <= 5) v = cd[idx - 2];
             else if (idx == 6) v = u_pack2(uc[TTM_UC_TAB_OFF], n_grp);
+            else if (idx == 7) v = nm0;
         } else {
             const int g = (idx - TTM_H_HDR) / GS, j = (idx - TTM_H_HDR) % GS;
             if (g < n_grp) {
@@ -404,6 +406,11 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
     }
 }
 
+// exp(-x^2/4) of the hot paths: from the 2^(j/32) table when the kernel staged one (CacheStore::etab - the inverse
+// kernel: -6 % instructions), else the generic exp (the forward kernel: with the table lookup in its long basic
+// block the compiler keeps 30 more VGPRs live and a workgroup per CU is lost - measured slower)
+#define TTM_HL_EXP(st, x) ((st).etab ? exp_q_tab((st).etab, (x)) : fast_exp(-0.25 * ((x) * (x))))
+
 // S_k and dS_k/dx_k from a hot record (include/ttm.h "H section"): NG group records of degree (DB, DA) and stride
 // GS, every column from the planned cache (st; slot s of a sample set = st.get(s)), then the put of x_k.  All scalar
 // loads of the step are at fixed offsets from `rec`.  A component that uses all NG records, has a spline and
@@ -464,6 +471,77 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
         st.set(put2, xk);
         if (flg & 1) st.set(put2 + 1, ek);
     }
+}
+
+// nonmonotone part of a component from its hot record (what the inverse subtracts from z_k): same two paths as
+// h_component
+template <int NG, int DB, int DA, int GS, class R>
+TTM_HD R h_offset(cdbl_p rec, const CacheStore<R>& st) {
+    const int n_grp = ((cint_p)rec)[13];
+    R s(rec[7]);
+    if (n_grp == NG) {
+        R xv[NG], ev[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int slot2 = ((cint_p)(rec + TTM_H_HDR + g * GS))[0];
+            xv[g] = st.get(slot2);
+            ev[g] = st.get(slot2 + 1);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            cdbl_p gr = rec + TTM_H_HDR + g * GS;
+            R b, a, dv;
+            u_horner_fixed<DB, false>(gr + 1, xv[g], b, dv);
+            u_horner_fixed<DA, false>(gr + 2 + DB, xv[g], a, dv);
+            s = vfma(ev[g], b, s) + a;
+        }
+        return s;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g < n_grp) {
+            cdbl_p gr = rec + TTM_H_HDR + g * GS;
+            const int slot2 = ((cint_p)gr)[0];
+            const R xv = st.get(slot2), ev = st.get(slot2 + 1);
+            R b, a, dv;
+            u_horner_fixed<DB, false>(gr + 1, xv, b, dv);
+            u_horner_fixed<DA, false>(gr + 2 + DB, xv, a, dv);
+            s = vfma(ev, b, s) + a;
+        }
+    }
+    return s;
+}
+
+// put of a solved x_k (and exp(-x_k^2/4) when a later group reads it) into its planned cache slot
+template <class R>
+TTM_HD void h_put(cdbl_p rec, const CacheStore<R>& st, const R& xk) {
+    const int put2 = ((cint_p)rec)[0], flg = ((cint_p)rec)[1];
+    if (put2 >= 0) {
+        st.set(put2, xk);
+        if (flg & 1) st.set(put2 + 1, TTM_HL_EXP(st, xk));
+    }
+}
+
+// np.searchsorted(xs, target) (left) with a bucket index: bk[q] = first index whose entry is >= tmin + q step
+// (q = 0..nb; bk[0] = 0, bk[nb] = T).  Starts one bucket below the target's own (rounding of the bucket number)
+// and scans forward four entries at a time - with nb ~ T the first group almost always decides.
+TTM_HD int h_search(const double* xs, const int* bk, int nb, int T, double lo, double scale, bool use_bkt, double target) {
+    int a = 0;
+    if (use_bkt) {
+        int q = (int)((target - lo) * scale) - 1;
+        q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
+        a = bk[q];
+    }
+    // count entries < target from a on (xs is non-decreasing; NaN target: every compare is false -> a)
+    while (a < T) {
+        const int r = T - a;
+        const double v0 = xs[a], v1 = xs[r > 1 ? a + 1 : a], v2 = xs[r > 2 ? a + 2 : a], v3 = xs[r > 3 ? a + 3 : a];
+        const int c = (v0 < target ? 1 : 0) + ((r > 1 && v1 < target) ? 1 : 0) + ((r > 2 && v2 < target) ? 1 : 0) +
+                      ((r > 3 && v3 < target) ? 1 : 0);
+        a += c;
+        if (c < 4) break;
+    }
+    return a;
 }
 
 }  // namespace ttm

@@ -635,7 +635,7 @@ class transport_map():
         only an unsorted table (flat, noisy tails) takes the host detour that applies the sort."""
         torch = _torch()
         ncomp = k1 - k0
-        nb = 512
+        nb = 1023                  # buckets ~ table points; nb + 1 int32 per row = whole 16-byte units
         key = (resolution, start_distance)
         if getattr(self, '_pts_key', None) != key:
             self._pts = np.linspace(-start_distance, start_distance, resolution)
@@ -648,22 +648,31 @@ class transport_map():
             regen[-1] = float(start_distance)
             self._pts_affine = ((ctypes.c_double * 3)(-float(start_distance), step, float(start_distance))
                                 if np.array_equal(regen, self._pts) else None)
-        out_d = self._empty(ncomp, resolution)
-        tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
-        bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
-        uns_d = self._empty(ncomp, dtype=torch.int32)
         st = self._stream()
-        _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                      self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
-        _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
-                                                      self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
-                                                      ctypes.c_void_p(uns_d.data_ptr()), st))
         trunc = 1 if self.root_search_truncation else 0
-        _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(out_d),
-                                                self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
-                                                self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
-        if int(uns_d.max().item()) == 0:
+        # the tables depend on the coefficients only: they are built once per packed coefficient vector and kept
+        # with it (like its folded coefficients), so repeated inversions with the same map are lookups only
+        cache = getattr(coef, '_ttm_tables', None)
+        if cache is None:
+            cache = coef._ttm_tables = {}
+        tkey = (k0, k1, resolution, start_distance, nb)
+        if tkey not in cache:
+            out_d = self._empty(ncomp, resolution)
+            tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
+            bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
+            uns_d = self._empty(ncomp, dtype=torch.int32)
+            _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                          self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
+            _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
+                                                          self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
+                                                          ctypes.c_void_p(uns_d.data_ptr()), st))
+            cache[tkey] = (out_d, tmin_d, tmax_d, bkt_d, int(uns_d.max().item()) == 0)
+        out_d, tmin_d, tmax_d, bkt_d, is_sorted = cache[tkey]
+        if is_sorted:
+            _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                    self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(out_d),
+                                                    self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
+                                                    self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
             return
         # rare: some table is not non-decreasing -> reproduce interp1d's stable sort on the host and redo
         out = out_d.cpu().numpy()
