@@ -109,7 +109,7 @@ def test_falls_back_when_spline_would_be_too_fine(backend):
     from oracle.ttm_oracle import OracleMap
     rng = np.random.default_rng(5)
     X = rng.standard_normal((600, 3)) @ np.array([[1.0, 0.4, 0.0], [0.0, 1.0, 0.5], [0.0, 0.0, 1.0]])
-    mon, non, kw = _narrow_map(0.05)
+    mon, non, kw = _narrow_map(0.02)
     tm = transport_map(X=X, monotone=mon, nonmonotone=non, **kw)
     assert tm._cm.u_static and not tm._cm.u_enabled
     om = OracleMap(X=X, monotone=mon, nonmonotone=non, **{k: v for k, v in kw.items() if k != 'verbose'})

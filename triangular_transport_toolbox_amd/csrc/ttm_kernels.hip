@@ -711,7 +711,12 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 // Requires 16-byte aligned X / Z columns (even leading dimensions) and ldx >= N rounded up to even.
 // LDS (doubles): [x ring: (LEAD+1) x 512 | table ring: 3 x tab_slot | column cache: 2 x ways x 2 x 256]
 // ---------------------------------------------------------------------------
-#define TTM_UL_ROWS 512       // rows per tile (4 evaluating waves x 64 lanes x 2 samples)
+#ifndef TTM_UL_CW
+#define TTM_UL_CW 4           // evaluating waves per workgroup
+#endif
+#define TTM_UL_THREADS ((TTM_UL_CW + 2) * 64)
+#define TTM_UL_CT (TTM_UL_CW * 64)             // evaluating threads
+#define TTM_UL_ROWS (TTM_UL_CW * 128)          // rows per tile (evaluating waves x 64 lanes x 2 samples)
 // xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
 // xlead + 1 and tlead + 1 slots.  xlead <= 4 and tlead <= 2 (the vmcnt immediates).
 
@@ -740,8 +745,54 @@ __device__ __forceinline__ void ul_wait_vmcnt(int n) {      // all but the n you
         case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
         case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
         case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+        case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+        case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+        case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+        case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // (more than 30 younger operations: drain)
     }
+}
+
+// ---- flag hand-over between loader and evaluating waves (TTM_HL_FLAGS) -------------------------------------------
+// Progress words at the start of the workgroup's LDS: ready[0] / ready[1] = number of steps whose column / table has
+// landed (written by the loader after its counted vmcnt wait), done[w] = number of steps evaluating wave w has
+// finished (written after the step's last LDS read).  A loader issues step j into ring slot j % SLOTS once
+// min(done) >= j - SLOTS + 1; an evaluating wave starts step s once ready[0] > s and ready[1] > s.  No barrier in the
+// loop: the evaluating waves drift apart by up to the ring depth instead of meeting every step.  Every spin is
+// bounded (a protocol error ends in wrong numbers, which the parity tests catch, never in a hung GPU).
+struct HlCtl {
+    int ready[2];
+    int done[4];
+    int pad[2];
+};
+#define TTM_HL_SPIN_MAX (1 << 22)
+#ifndef TTM_HL_SLEEP
+#define TTM_HL_SLEEP 8       // s_sleep argument (x 64 cycles) of an idle loader's poll loop
+#endif
+
+__device__ __forceinline__ int hl_min_done(volatile HlCtl* c) {
+    const int a = c->done[0], b = c->done[1], d = c->done[2], e = c->done[3];
+    const int m = min(min(a, b), min(d, e));
+    return __builtin_amdgcn_readfirstlane(m);
+}
+__device__ __forceinline__ void hl_wait_ready(volatile HlCtl* c, int s) {
+    for (int i = 0; i < TTM_HL_SPIN_MAX; ++i) {
+        const int a = __builtin_amdgcn_readfirstlane(c->ready[0]), b = __builtin_amdgcn_readfirstlane(c->ready[1]);
+        if (a > s && b > s) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
 }
 
 __device__ __forceinline__ void ul_dma16(const void* g, double* lds_wave_base) {
@@ -757,7 +808,7 @@ struct UlCursor {
 };
 
 template <bool WANT_LD, int DB, int DA>
-__global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
+__global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_ul(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
                                                     const double* __restrict__ U_, int D, int k0, int k1,
                                                     const double* __restrict__ X, int64_t ldx, int64_t N,
                                                     double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
@@ -778,7 +829,7 @@ __global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucom
     double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
-    if (wv == 4) {
+    if (wv == TTM_UL_CW) {
         // ---- x loader -------------------------------------------------------------------------------------------
         const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;           // first row of the last readable pair
         int64_t ptile = blockIdx.x;
@@ -812,7 +863,7 @@ __global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucom
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain before the LDS is released
         return;
     }
-    if (wv == 5) {
+    if (wv == TTM_UL_CW + 1) {
         // ---- table loader ---------------------------------------------------------------------------------------
         int pk = k0;
         int64_t pstep = 0;
@@ -850,7 +901,7 @@ __global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucom
     // ---- evaluating waves -------------------------------------------------------------------------------------------
     CacheStore<R> cst;
     cst.base = cache + tid;
-    cst.stride = 256;
+    cst.stride = TTM_UL_CT;
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
     XOffN<2> cx;
     cx.X = (const char*)X; cx.ldb = ldx * 8;
@@ -910,7 +961,7 @@ __global__ __launch_bounds__(384) void k_forward_ul(const int* __restrict__ ucom
 // per step (all scalar loads at known offsets, issued together) and run straight-line code: NG group records of
 // degree class CLS, every column from the planned cache.  Same loader waves, rings and barrier protocol.
 template <bool WANT_LD, int NG, int CLS>
-__global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+__global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
                                                     int D, int k0, int k1,
                                                     const double* __restrict__ X, int64_t ldx, int64_t N,
                                                     double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
@@ -927,11 +978,19 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
+#ifdef TTM_HL_FLAGS
+    volatile HlCtl* ctl = (volatile HlCtl*)g_smem;                       // progress words (32 bytes)
+    double* ring = g_smem + 4;
+    if (tid < 8) ((int*)g_smem)[tid] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TTM_RAW_BARRIER();                                                   // the only barrier: progress words are zero
+#else
     double* ring = g_smem;
-    double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
+#endif
+    double* tabs = ring + (size_t)XSLOTS * TTM_UL_ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
-    if (wv == 4) {
+    if (wv == TTM_UL_CW) {
         // ---- x loader -------------------------------------------------------------------------------------------
         const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
         int64_t ptile = blockIdx.x;
@@ -954,6 +1013,26 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
                 ul_dma16(col + pair, slot + c * 128);
             }
         };
+#ifdef TTM_HL_FLAGS
+        // issue while slots are free, then wait for the oldest unpublished step to land and publish it
+        int ji = 0, jp = 0;
+        const int Si = (int)S;
+        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
+            const int md = hl_min_done(ctl);
+            while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
+            if (jp < ji) {
+                ul_wait_vmcnt((ji - jp - 1) * (TTM_UL_ROWS / 128));
+                ++jp;
+                if (lane == 0) ctl->ready[0] = jp;
+                spin = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
+                ++spin;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+#else
         for (int j = 0; j < xlead; ++j) issue(j);
         ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
         TTM_RAW_BARRIER();
@@ -964,8 +1043,9 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
+#endif
     }
-    if (wv == 5) {
+    if (wv == TTM_UL_CW + 1) {
         // ---- table loader ---------------------------------------------------------------------------------------
         int pk = k0;
         int64_t pstep = 0;
@@ -988,6 +1068,32 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
             }
             return nch;
         };
+#ifdef TTM_HL_FLAGS
+        int ji = 0, jp = 0;
+        const int Si = (int)S;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;                              // operations of the steps in flight, by step & 3
+        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
+            const int md = hl_min_done(ctl);
+            while (ji < Si && ji - md < TSLOTS && ji - jp < 3) {
+                const int n = issue(ji);
+                if ((ji & 3) == 0) c0 = n; else if ((ji & 3) == 1) c1 = n; else if ((ji & 3) == 2) c2 = n; else c3 = n;
+                ++ji;
+            }
+            if (jp < ji) {
+                int younger = 0;                                         // operations issued after step jp's
+                for (int q = jp + 1; q < ji; ++q) younger += (q & 3) == 0 ? c0 : ((q & 3) == 1 ? c1 : ((q & 3) == 2 ? c2 : c3));
+                ul_wait_vmcnt(younger);
+                ++jp;
+                if (lane == 0) ctl->ready[1] = jp;
+                spin = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
+                ++spin;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+#else
         issue(0);
         const int n1 = tlead > 1 ? issue(1) : 0;
         ul_wait_vmcnt(n1);
@@ -999,12 +1105,13 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
+#endif
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
     CacheStore<R> cst;
     cst.base = cache + tid;
-    cst.stride = 256;
+    cst.stride = TTM_UL_CT;
     (void)ways;
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
     bool act0 = false, act1 = false;
@@ -1012,8 +1119,13 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
     int k = k0;
     R ld(0.0), ss(0.0);
     int xs = 0, ts = 0;
+#ifndef TTM_HL_FLAGS
     TTM_RAW_BARRIER();                                                   // A(0)
+#endif
     for (int64_t s = 0; s < S; ++s) {
+#ifdef TTM_HL_FLAGS
+        hl_wait_ready(ctl, (int)s);
+#endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
             const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
@@ -1058,7 +1170,12 @@ __global__ __launch_bounds__(384) void k_forward_hl(const int* __restrict__ ucom
         } else {
             ++k;
         }
+#ifdef TTM_HL_FLAGS
+        asm volatile("" ::: "memory");
+        if (lane == 0) ctl->done[wv] = (int)s + 1;                       // (DS operations of a wave execute in order)
+#else
         TTM_RAW_BARRIER();                                               // A(s + 1)
+#endif
     }
 }
 
@@ -1076,7 +1193,7 @@ __device__ __forceinline__ void ul_dma4(const void* g, void* lds_wave_base) {
 // LDS (doubles): [z ring: (xlead+1) x 512 | table ring: (tlead+1) x tab_slot | column cache: 2 x ways x 2 x 256]
 // table slot: [xs: T rounded up to even | bucket index: nb + 1 int32]
 template <int NG, int CLS>
-__global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+__global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
                                                     int D, int k0, int k1,
                                                     const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
                                                     const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
@@ -1094,12 +1211,26 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
+#ifdef TTM_HL_FLAGS
+    volatile HlCtl* ctl = (volatile HlCtl*)g_smem;                       // progress words (32 bytes)
+    double* ring = g_smem + 4;
+#else
     double* ring = g_smem;
-    double* tabs = g_smem + (size_t)XSLOTS * TTM_UL_ROWS;
+#endif
+    double* tabs = ring + (size_t)XSLOTS * TTM_UL_ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
     const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
+    double* etab = cache + (size_t)2 * ways * 2 * TTM_UL_CT;                   // 2^(j/32), behind the column cache
+#ifdef TTM_HL_FLAGS
+    // one-time LDS set-up by the first waves, then the only barrier of the kernel
+    if (tid < 8) ((int*)g_smem)[tid] = 0;
+    if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
+    if (tid >= 64 && tid < 64 + TTM_EXPQ_TABLE_LEN) etab[tid - 64] = g_expq_table[tid - 64];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TTM_RAW_BARRIER();
+#endif
 
-    if (wv == 4) {
+    if (wv == TTM_UL_CW) {
         // ---- z loader -------------------------------------------------------------------------------------------
         const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
         int64_t ptile = blockIdx.x;
@@ -1121,6 +1252,26 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
                 ul_dma16(col + pair, slot + c * 128);
             }
         };
+#ifdef TTM_HL_FLAGS
+        // issue while slots are free, then wait for the oldest unpublished step to land and publish it
+        int ji = 0, jp = 0;
+        const int Si = (int)S;
+        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
+            const int md = hl_min_done(ctl);
+            while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
+            if (jp < ji) {
+                ul_wait_vmcnt((ji - jp - 1) * (TTM_UL_ROWS / 128));
+                ++jp;
+                if (lane == 0) ctl->ready[0] = jp;
+                spin = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
+                ++spin;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+#else
         for (int j = 0; j < xlead; ++j) issue(j);
         ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
         TTM_RAW_BARRIER();
@@ -1131,8 +1282,9 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
+#endif
     }
-    if (wv == 5) {
+    if (wv == TTM_UL_CW + 1) {
         // ---- table loader: xs row (T doubles) + bucket row (nb + 1 int32) -----------------------------------------
         int pk = k0;
         int64_t pstep = 0;
@@ -1160,6 +1312,32 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
             }
             return nch1 + (tail4 ? 1 : 0) + nch2;
         };
+#ifdef TTM_HL_FLAGS
+        int ji = 0, jp = 0;
+        const int Si = (int)S;
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;                              // operations of the steps in flight, by step & 3
+        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
+            const int md = hl_min_done(ctl);
+            while (ji < Si && ji - md < TSLOTS && ji - jp < 3) {
+                const int n = issue(ji);
+                if ((ji & 3) == 0) c0 = n; else if ((ji & 3) == 1) c1 = n; else if ((ji & 3) == 2) c2 = n; else c3 = n;
+                ++ji;
+            }
+            if (jp < ji) {
+                int younger = 0;                                         // operations issued after step jp's
+                for (int q = jp + 1; q < ji; ++q) younger += (q & 3) == 0 ? c0 : ((q & 3) == 1 ? c1 : ((q & 3) == 2 ? c2 : c3));
+                ul_wait_vmcnt(younger);
+                ++jp;
+                if (lane == 0) ctl->ready[1] = jp;
+                spin = 0;
+            } else {
+                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
+                ++spin;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+#else
         issue(0);
         const int n1 = tlead > 1 ? issue(1) : 0;
         ul_wait_vmcnt(n1);
@@ -1171,25 +1349,32 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
+#endif
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
     CacheStore<R> cst;
     cst.base = cache + tid;
-    cst.stride = 256;
-    double* etab = cache + (size_t)2 * ways * 2 * 256;                   // 2^(j/32), behind the column cache
+    cst.stride = TTM_UL_CT;
+#ifndef TTM_HL_FLAGS
     if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
-    cst.etab = etab;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    cst.etab = etab;
     bool act0 = false, act1 = false;
     int64_t ctile = blockIdx.x;
     int k = k0;
     int xs = 0, ts = 0;
+#ifndef TTM_HL_FLAGS
     // sentinels behind the table entries of every slot (the DMAs only ever write the first T doubles)
     if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TTM_RAW_BARRIER();                                                   // A(0)
+#endif
     for (int64_t s = 0; s < S; ++s) {
+#ifdef TTM_HL_FLAGS
+        hl_wait_ready(ctl, (int)s);
+#endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
             const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
@@ -1259,7 +1444,12 @@ __global__ __launch_bounds__(384) void k_inverse_hl(const int* __restrict__ ucom
         }
         if (k + 1 == k1) { ctile += gridDim.x; k = k0; }
         else ++k;
+#ifdef TTM_HL_FLAGS
+        asm volatile("" ::: "memory");
+        if (lane == 0) ctl->done[wv] = (int)s + 1;
+#else
         TTM_RAW_BARRIER();                                               // A(s + 1)
+#endif
     }
 }
 
@@ -1810,7 +2000,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
             xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
             tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
-            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256 + TTM_EXPQ_TABLE_LEN) * 8;
+            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
@@ -1826,13 +2016,13 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 else hk = logdet ? TTM_HK(true, 4) : TTM_HK(false, 4);
 #undef TTM_HK
                 int wgs = (int)((size_t)(160 * 1024) / lds_ul);
-                if (wgs > 5) wgs = 5;
+                if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
                 if (wgs < 1) wgs = 1;
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
                 const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
                 allow_big_lds((const void*)hk, lds_ul);
-                hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp,
+                hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds_ul, (hipStream_t)stream, p->ucomp,
                                    fold + fold_base_size(p), (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz,
                                    logdet, sigma, sumsq, tab_slot, xlead, tlead, ways);
                 return check_launch("k_forward_hl");
@@ -1853,13 +2043,13 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 lkern_t lk = logdet ? (cls == 0 ? k_forward_ul<true, 3, 1> : cls == 1 ? k_forward_ul<true, 5, 5> : k_forward_ul<true, 7, 7>)
                                     : (cls == 0 ? k_forward_ul<false, 3, 1> : cls == 1 ? k_forward_ul<false, 5, 5> : k_forward_ul<false, 7, 7>);
                 int wgs = (int)((size_t)(160 * 1024) / lds_ul);
-                if (wgs > 5) wgs = 5;                                    // 6 waves per workgroup, 32 per CU
+                if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);                                    // 6 waves per workgroup, 32 per CU
                 if (wgs < 1) wgs = 1;
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
                 const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
                 allow_big_lds((const void*)lk, lds_ul);
-                hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(384), lds_ul, (hipStream_t)stream, p->ucomp, p->ugrp,
+                hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds_ul, (hipStream_t)stream, p->ucomp, p->ugrp,
                                    fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq,
                                    tab_slot, xlead, tlead);
                 return check_launch("k_forward_ul");
@@ -1986,7 +2176,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         const int Teven = (T + 4 + 1) & ~1;                              // entries + 4 sentinels, even
         const int tab_slot = Teven + (nb + 1 + 1) / 2;                   // doubles
         const int nops = ((((T * 8) & ~15) + 1023) >> 10) + ((T & 1) ? 1 : 0) + (((nb + 1) * 4 + 1023) >> 10);
-        const size_t lds = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * 256 + TTM_EXPQ_TABLE_LEN) * 8;
+        const size_t lds = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
         const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
                              ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ((uintptr_t)bkt % 16 == 0) && ((uintptr_t)tab_x % 8 == 0);
         bool use = aligned && N >= 64 * 1024 && nops <= 15 && lds <= (size_t)160 * 1024 / 2;
@@ -2000,13 +2190,13 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
             if (p->u_h_ng == 2) ik = TTM_IK(2); else ik = TTM_IK(4);
 #undef TTM_IK
             int wgs = (int)((size_t)(160 * 1024) / lds);
-            if (wgs > 5) wgs = 5;
+            if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
             if (wgs < 1) wgs = 1;
             if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
             const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
             const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
             allow_big_lds((const void*)ik, lds);
-            hipLaunchKernelGGL(ik, dim3((unsigned)grid), dim3(384), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
+            hipLaunchKernelGGL(ik, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
                                (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine[0],
                                h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, xlead, tlead, ways);
             return check_launch("k_inverse_hl");

@@ -621,7 +621,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
 H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24)
 UCF_OWN, UGF_POLY = 1, 1 << 20
-U_KAPPA = 0.5                 # spline interval width / smallest special-term scale (degree 11: fit error ~1e-15)
+U_KAPPA = 0.75                # spline interval width / smallest special-term scale (degree 11: fit error < 1e-14;
+                              # 0.5: 3e-15, 0.9: 5e-14 - wider intervals = smaller tables to stream per sweep step)
 U_SUPPORT = 6.0 * np.sqrt(2.0)   # |x - centre| / scale beyond which erf / the Gaussian are at their limits to 1e-16
 U_TOL_VALUE, U_TOL_DERIV = 2e-13, 2e-11     # accepted fit errors (relative to 1 + |exact|) before falling back
 
@@ -755,7 +756,9 @@ def uform_geometry(cm, kappa=None):
     if not cm.u_static:
         cm.u_enabled = False
         return False
-    kappa = U_KAPPA if kappa is None else kappa
+    if kappa is None:
+        import os
+        kappa = float(os.environ.get('TTM_U_KAPPA', U_KAPPA))      # (tuning knob)
     uc = cm.ucomp[:cm.D * UC_LEN].reshape(-1, UC_LEN)       # (view: the entry-state words follow)
     off, ok = 0, True
     geo = np.zeros((cm.D, 2))

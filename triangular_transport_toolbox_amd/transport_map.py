@@ -635,7 +635,8 @@ class transport_map():
         only an unsorted table (flat, noisy tails) takes the host detour that applies the sort."""
         torch = _torch()
         ncomp = k1 - k0
-        nb = 1023                  # buckets ~ table points; nb + 1 int32 per row = whole 16-byte units
+        import os
+        nb = int(os.environ.get('TTM_INV_NB', 1023))   # buckets ~ table points; nb + 1 int32 per row = whole 16-byte units
         key = (resolution, start_distance)
         if getattr(self, '_pts_key', None) != key:
             self._pts = np.linspace(-start_distance, start_distance, resolution)
