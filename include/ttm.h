@@ -382,6 +382,14 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
 int64_t ttm_reduce_work_size(int32_t nout);
 int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* Xsoa,
                   int64_t ldx, int64_t N, double* work, double* out, void* stream);
+/* The same reduction for an optimiser that lives on the host (TM:3108-3114, 3252-3257 drive SciPy with one
+ * objective / gradient evaluation per call, so the per-call latency is what optimize() costs):
+ * h_coef_k is a HOST vector (<= 64 coefficients) that travels as kernel arguments - no host-to-device copy; the
+ * finishing sum runs in the workgroup that draws the last ticket of `counter` (device uint32, zero before the first
+ * call; left zero) in the order of the three-launch path, so both give the same bits; `out` may be pinned host
+ * memory (device-accessible), which also saves the device-to-host copy.  Two launches instead of three + two copies. */
+int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa,
+                       int64_t ldx, int64_t N, double* work, uint32_t* counter, double* out, void* stream);
 
 /* ---- K8: Gram matrix of [Psi_nonmon | Psi_mon] -------------------------------------
  * replaces the N x m passes of TM:2966-2975 (QR projection) and TM:3031-3050 (L2 normal

@@ -462,6 +462,11 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     return 0;
 }
 
+int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* X, int64_t ldx, int64_t N,
+                       double* work, uint32_t*, double* out, void* stream) {
+    return ttm_objective(p, k, h_coef_k, X, ldx, N, work, out, stream);
+}
+
 int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*) {
     const Prog g = make_prog(p);
     HostComp h;

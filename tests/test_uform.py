@@ -165,3 +165,26 @@ def test_class_results_match_oracle_through_uform(backend, name):
     assert relerr(tm.evaluate_pullback_density(Xq), om.evaluate_pullback_density(Xq)) < 1e-10
     Zin = npz['inv_Z']
     assert relerr(tm.inverse_map(Zin), om.inverse_map(Zin)) < 1e-10
+
+
+@pytest.mark.parametrize('name', ['c5_sep', 'c2b_sep'])
+def test_conditional_inverse_and_partial_sweeps_on_loader_kernels(backend, name, monkeypatch):
+    """Sweeps that start inside the map (conditional inverse with X_star on a map without skipped dimensions,
+    s() of a single component): the hot-record kernels preload the planned cache from the entry state of that
+    component.  Forced onto the loader-wave kernels (they are chosen by themselves only for large ensembles)."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case(name)
+    X = case_X(name, npz)
+    tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
+    tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
+    om = make_oracle(name, npz, desc)
+    monkeypatch.setenv('TTM_U_LOADER', '1')
+    Xq = X[:333]
+    E = 1 if tm.D == 2 else 7
+    Zq = om.map(Xq)
+    got = tm.inverse_map(Zq[:, E:], X_star=Xq[:, :E])
+    ref = om.inverse_map(Zq[:, E:], X_star=Xq[:, :E])
+    assert got.shape == ref.shape and relerr(got, ref) < 1e-10
+    Xs = (Xq - om.X_mean) / om.X_std
+    for k in sorted({0, tm.D // 2, tm.D - 1}):
+        assert relerr(tm.s(Xs, k), om.s(Xs, k)) < 1e-12

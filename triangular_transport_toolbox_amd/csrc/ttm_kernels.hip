@@ -1679,12 +1679,14 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k
 // ---------------------------------------------------------------------------
 
 #define TTM_RED_BLOCKS 1024
+#define TTM_HOSTCOEF_MAX 64
 
 // LDS: erf table | per-thread columns [scratch (nscr) | acc (nacc)]
 __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const double* __restrict__ coef_k,
                                                    const double* __restrict__ fold_k,
                                                    const double* __restrict__ X, int64_t ldx, int64_t N,
-                                                   int nscr, int nacc, double* __restrict__ partial) {
+                                                   int nscr, int nacc, double* __restrict__ partial,
+                                                   unsigned int* __restrict__ counter, double* __restrict__ out) {
     double* slots;
     CacheStore<double> cst;
     const Prog g = make_prog_lds(P, cst, slots);
@@ -1712,6 +1714,41 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
         v = wave_sum(v);
         if (lane == 0) partial[(int64_t)blockIdx.x * nacc + i] = v;
     }
+    if (out) {
+        // single-launch variant: the workgroup that draws the last ticket adds the partials up, in the very order
+        // k_reduce_partials uses (bit-identical sums), and writes the result - `out` may be pinned host memory
+        __shared__ int is_last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) is_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (is_last) {
+            __threadfence();
+            for (int i = wv; i < nacc; i += nw) {
+                double v = 0.0;
+                for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
+                v = wave_sum(v);
+                if (lane == 0) out[i] = v;
+            }
+            if (tid == 0) *counter = 0u;
+        }
+    }
+}
+
+// coefficients handed over BY VALUE (kernel arguments: no host-to-device copy, no extra launch): block 0 writes
+// them to the workspace and folds them
+struct HostCoef { double c[TTM_HOSTCOEF_MAX]; };
+
+__global__ __launch_bounds__(64) void k_fold_host(DevProg P, int k, HostCoef hc, int n, double* __restrict__ coef_dev,
+                                                  double* __restrict__ fold) {
+    const int D1 = P.D + 1;
+    const int* off = P.off;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) coef_dev[i] = hc.c[i];
+    __threadfence_block();
+    __syncthreads();
+    fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k], coef_dev, fold, threadIdx.x, blockDim.x);
+    __syncthreads();
+    fold_st8(P.fdesc + k * TTM_FDESC_LEN, P.fints, fold, threadIdx.x, blockDim.x);
 }
 
 // out[i] = sum_b partial[b*nout + i], one wave per output
@@ -2260,8 +2297,41 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     double* partial = work + TTM_OBJ_FOLD_MAX;
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, (int)k, coef_k, fold_k);
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k, coef_k,
-                       (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial);
+                       (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
+    return check_launch("k_objective");
+}
+
+int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa, int64_t ldx, int64_t N,
+                       double* work, uint32_t* counter, double* out, void* stream) {
+    int rc = validate(p, k, k + 1);
+    if (rc) return rc;
+    if (!h_coef_k || !Xsoa || !work || !counter || !out || N < 1 || ldx < N) return set_err(TTM_E_ARG, "ttm_objective_host: bad arguments%s");
+    if (p->monotonicity == TTM_MONO_INTEGRATED && p->rectifier != TTM_RECT_EXPONENTIAL && p->rectifier != TTM_RECT_SOFTPLUS &&
+        p->rectifier != TTM_RECT_EXPNEG)
+        return set_err(TTM_E_UNSUPPORTED, "rectifier has no evaluate_dfdc in the reference (TM:5119-5163)%s");
+    const int sep = p->monotonicity == TTM_MONO_SEPARABLE;
+    const int n_nm = p->h_n_nm[k];
+    const int ncoef = p->h_coef_off[k + 1] - p->h_coef_off[k];
+    const int n_mon = ncoef - n_nm;
+    if (ncoef > TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "ttm_objective_host: component %s%lld has more than 64 coefficients", "", k);
+    const int nacc = sep ? 1 + n_mon : 1 + n_nm + n_mon;
+    const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
+    const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
+    if (nfold > TTM_OBJ_FOLD_MAX - TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
+    const int bd = pick_block(nscr + nacc, 0);
+    if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", k);
+    int nb = grid_for(N, bd);
+    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    const DevProg P = dev_prog(p);
+    double* fold_k = work;
+    double* coef_dev = work + TTM_OBJ_FOLD_MAX - TTM_HOSTCOEF_MAX;
+    double* partial = work + TTM_OBJ_FOLD_MAX;
+    HostCoef hc;
+    for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = i < ncoef ? h_coef_k[i] : 0.0;
+    hipLaunchKernelGGL(k_fold_host, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, hc, ncoef, coef_dev, fold_k);
+    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k,
+                       (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)counter, out);
     return check_launch("k_objective");
 }
 

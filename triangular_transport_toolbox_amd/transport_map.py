@@ -725,8 +725,24 @@ class transport_map():
         nout = 1 + int(self._cm.n_mon[k]) + (0 if self.monotonicity.lower() == 'separable monotonicity'
                                               else int(self._cm.n_nm[k]))
         work = self._workspace(self._lib.ttm_reduce_work_size(nout))
+        coef_k = np.ascontiguousarray(coef_k, dtype=float)
+        if self._dist() is None and len(coef_k) <= 64:
+            # host-driven optimiser: coefficients as kernel arguments, result written to pinned host memory,
+            # one stream synchronisation per evaluation (no H2D / D2H copies, two launches)
+            torch = _torch()
+            if getattr(self, '_obj_out', None) is None:
+                pin = self._dev.type == 'cuda'
+                self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
+                self._obj_cnt = self._zeros(1, dtype=torch.int32)
+            _capi.check(self._lib.ttm_objective_host(self._pp, int(k), ctypes.c_void_p(coef_k.ctypes.data), self._ptr(self._Xs),
+                                                     self._Xs.shape[1], self._N, self._ptr(work),
+                                                     ctypes.c_void_p(self._obj_cnt.data_ptr()),
+                                                     ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+            if self._dev.type == 'cuda':
+                torch.cuda.current_stream().synchronize()
+            return self._obj_out[:nout].numpy().copy()
         out = self._empty(nout)
-        ck = self._to_dev(np.asarray(coef_k, dtype=float))
+        ck = self._to_dev(coef_k)
         _capi.check(self._lib.ttm_objective(self._pp, int(k), self._ptr(ck), self._ptr(self._Xs), self._Xs.shape[1],
                                             self._N, self._ptr(work), self._ptr(out), self._stream()))
         self._allreduce(out)
