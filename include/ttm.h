@@ -391,6 +391,15 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
 int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa,
                        int64_t ldx, int64_t N, double* work, uint32_t* counter, double* out, void* stream);
 
+/* Separable objective from a cached derivative basis: while one component is optimised its dPsi_mon (N x m_mon;
+ * the reference precalculates and keeps it, TM:789-821, 2978-3018) does not change, so the host computes it once with
+ * ttm_basis(which = 2) (m rows of N doubles, row stride ldp) and every evaluation is one streaming launch:
+ *   out[0] = sum_n log dS_n, out[1+i] = sum_n dPsi_{n,i}/dS_n, dS = dPsi.c + delta*rowsum(dPsi), m <= 16.
+ * h_coef_mon: HOST vector of the m trial coefficients (kernel arguments).  work: >= ttm_reduce_work_size(1+m) doubles;
+ * counter / out as ttm_objective_host.                                                                             */
+int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
+                             double delta, double* work, uint32_t* counter, double* out, void* stream);
+
 /* ---- K8: Gram matrix of [Psi_nonmon | Psi_mon] -------------------------------------
  * replaces the N x m passes of TM:2966-2975 (QR projection) and TM:3031-3050 (L2 normal
  * equations): out[i*m + j] = sum_n Psi_{n,i} Psi_{n,j}, m = n_nonmon + n_mon (full symmetric).

@@ -467,6 +467,24 @@ int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, 
     return ttm_objective(p, k, h_coef_k, X, ldx, N, work, out, stream);
 }
 
+int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
+                             double*, uint32_t*, double* out, void*) {
+    for (int i = 0; i <= m; ++i) out[i] = 0.0;
+    for (int64_t n = 0; n < N; ++n) {
+        double dS = 0.0, rowsum = 0.0;
+        for (int i = 0; i < m; ++i) {
+            const double d = dPsi[(int64_t)i * ldp + n];
+            dS = fma(h_coef_mon[i], d, dS);
+            rowsum += d;
+        }
+        dS += rowsum * delta;
+        out[0] += fast_log(dS);
+        const double inv = fast_rcp(dS);
+        for (int i = 0; i < m; ++i) out[1 + i] += dPsi[(int64_t)i * ldp + n] * inv;
+    }
+    return 0;
+}
+
 int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*) {
     const Prog g = make_prog(p);
     HostComp h;

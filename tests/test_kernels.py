@@ -161,3 +161,26 @@ def test_nan_and_inf_samples_propagate(backend, name):
     Xi[7, 0] = np.inf
     Zi = tm.map(Xi)
     assert np.array_equal(Zi[rows & (np.arange(len(X)) != 7)], Zc[rows & (np.arange(len(X)) != 7)])
+
+
+@pytest.mark.parametrize('name', ['c3_sep', 'c5_sep'])
+def test_separable_objective_from_cached_basis(backend, name):
+    """The one-launch evaluation on the cached derivative basis (ttm_objective_sep_cached) gives the sums of the
+    basis-recomputing reduction (ttm_objective), for odd N and several components."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case(name)
+    X = case_X(name, npz)[:2001]
+    tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
+    rng = np.random.default_rng(4)
+    for k in sorted({0, 1, tm.D - 1}):
+        A, _ = tm.separable_setup(k)
+        c = 0.05 + rng.random(int(tm._cm.n_mon[k]))
+        J0, G0 = tm.separable_objective(c, A, k)
+        tm._sep_cache_begin(k)
+        assert tm._sep_cache is not None
+        J1, G1 = tm.separable_objective(c, A, k)
+        J2, G2 = tm.separable_objective(2 * c, A, k)
+        tm._sep_cache_end()
+        assert abs(J1 - J0) <= 1e-12 * (1 + abs(J0)) and relerr(G1, G0) < 1e-12
+        J3, G3 = tm.separable_objective(2 * c, A, k)
+        assert abs(J2 - J3) <= 1e-12 * (1 + abs(J3)) and relerr(G2, G3) < 1e-12

@@ -1751,6 +1751,63 @@ __global__ __launch_bounds__(64) void k_fold_host(DevProg P, int k, HostCoef hc,
     fold_st8(P.fdesc + k * TTM_FDESC_LEN, P.fints, fold, threadIdx.x, blockDim.x);
 }
 
+// Separable objective from a cached derivative basis (TM:2978-3018 with the der_Psi_mon the reference precalculates,
+// TM:789-821): dPsi is m rows of N doubles (ttm_basis(which = 2)), constant while a component is optimised, so one
+// evaluation is a streaming pass: dS = dPsi.c + delta rowsum(dPsi); acc[0] += log dS, acc[1+i] += dPsi_i / dS.
+// Coefficients travel as kernel arguments; block partials, then the last workgroup finishes (fixed order).
+#define TTM_SEPC_MAXM 16
+struct SepCoef { double c[TTM_SEPC_MAXM]; };
+
+__global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __restrict__ dPsi, int64_t ldp, int64_t N, int m,
+                                                              SepCoef hc, double delta, double* __restrict__ partial,
+                                                              unsigned int* __restrict__ counter, double* __restrict__ out) {
+    __shared__ double red[4][TTM_SEPC_MAXM + 1];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double acc[TTM_SEPC_MAXM + 1];
+#pragma unroll
+    for (int i = 0; i <= TTM_SEPC_MAXM; ++i) acc[i] = 0.0;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + tid; n < N; n += (int64_t)gridDim.x * blockDim.x) {
+        double d[TTM_SEPC_MAXM];
+        double dS = 0.0, rowsum = 0.0;
+#pragma unroll
+        for (int i = 0; i < TTM_SEPC_MAXM; ++i) {
+            d[i] = i < m ? dPsi[(int64_t)i * ldp + n] : 0.0;
+            dS = fma(hc.c[i], d[i], dS);
+            rowsum += d[i];
+        }
+        dS += rowsum * delta;
+        acc[0] += fast_log(dS);
+        const double inv = fast_rcp(dS);
+#pragma unroll
+        for (int i = 0; i < TTM_SEPC_MAXM; ++i) acc[1 + i] += d[i] * inv;
+    }
+    const int nacc = 1 + m;
+#pragma unroll
+    for (int i = 0; i <= TTM_SEPC_MAXM; ++i) {
+        if (i < nacc) {
+            const double v = wave_sum(acc[i]);
+            if (lane == 0) red[wv][i] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < nacc) partial[(int64_t)blockIdx.x * nacc + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        for (int i = wv; i < nacc; i += 4) {
+            double v = 0.0;
+            for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
+            v = wave_sum(v);
+            if (lane == 0) out[i] = v;
+        }
+        if (tid == 0) *counter = 0u;
+    }
+}
+
 // out[i] = sum_b partial[b*nout + i], one wave per output
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblocks, int nout,
                                                          double* __restrict__ out) {
@@ -2333,6 +2390,20 @@ int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, 
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k,
                        (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)counter, out);
     return check_launch("k_objective");
+}
+
+int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
+                             double* work, uint32_t* counter, double* out, void* stream) {
+    if (!dPsi || !h_coef_mon || !work || !counter || !out || N < 1 || ldp < N || m < 1)
+        return set_err(TTM_E_ARG, "ttm_objective_sep_cached: bad arguments%s");
+    if (m > TTM_SEPC_MAXM) return set_err(TTM_E_LIMIT, "ttm_objective_sep_cached: more than %s%lld monotone terms", "", TTM_SEPC_MAXM);
+    SepCoef hc;
+    for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
+    int nb = grid_for(N, 256 * 4);
+    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    hipLaunchKernelGGL(k_objective_sep_cached, dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, (int)m, hc, delta,
+                       work + TTM_OBJ_FOLD_MAX, (unsigned int*)counter, out);
+    return check_launch("k_objective_sep_cached");
 }
 
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N, double* work, double* out,

@@ -832,10 +832,42 @@ class transport_map():
             return A, (lambda c: -(sol2 @ c))
         raise ValueError("separable monotonicity supports regularization None or 'l2' (TM:2959, 3021)")
 
+    def _sep_cache_begin(self, k):
+        """Cache dPsi_mon of component k on the device for the duration of its optimisation (what the reference's
+        precalculate() keeps as der_Psi_mon): every L-BFGS-B evaluation is then one streaming launch."""
+        self._sep_cache = None
+        m = int(self._cm.n_mon[k])
+        if self._dist() is not None or m < 1 or m > 16:
+            return
+        torch = _torch()
+        dpsi = self._cols(m, self._N)
+        _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(dpsi),
+                                        dpsi.shape[1], self._stream()))
+        if getattr(self, '_obj_out', None) is None:
+            pin = self._dev.type == 'cuda'
+            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
+            self._obj_cnt = self._zeros(1, dtype=torch.int32)
+        self._sep_cache = (int(k), dpsi)
+
+    def _sep_cache_end(self):
+        self._sep_cache = None
+
     def separable_objective(self, coeffs_mon, A, k):
         """TM:2978-3018: (objective, gradient) of the reduced problem."""
-        c = np.asarray(coeffs_mon, dtype=float)
-        sums = self._device_sums(k, np.concatenate((np.zeros(int(self._cm.n_nm[k])), c)))
+        c = np.ascontiguousarray(coeffs_mon, dtype=float)
+        cache = getattr(self, '_sep_cache', None)
+        if cache is not None and cache[0] == int(k):
+            m = len(c)
+            work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
+            _capi.check(self._lib.ttm_objective_sep_cached(self._ptr(cache[1]), cache[1].shape[1], self._N, m,
+                                                           ctypes.c_void_p(c.ctypes.data), float(self.delta), self._ptr(work),
+                                                           ctypes.c_void_p(self._obj_cnt.data_ptr()),
+                                                           ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+            if self._dev.type == 'cuda':
+                _torch().cuda.current_stream().synchronize()
+            sums = self._obj_out[:1 + m].numpy().copy()
+        else:
+            sums = self._device_sums(k, np.concatenate((np.zeros(int(self._cm.n_nm[k])), c)))
         N = self._Nglobal
         b = self.delta * np.sum(A, axis=-1)
         Ax = A @ c
@@ -871,8 +903,12 @@ class transport_map():
                 A, solve_nonmon = self.separable_setup(k)
                 bounds = [[self.optimization_constraints_lb[k][i], self.optimization_constraints_ub[k][i]]
                           for i in range(len(self.optimization_constraints_lb[k]))]
-                opt = minimize(fun=self.separable_objective, method='L-BFGS-B',
-                               x0=np.asarray(self.coeffs_mon[k], dtype=float), jac=True, bounds=bounds, args=(A, k))
+                self._sep_cache_begin(k)
+                try:
+                    opt = minimize(fun=self.separable_objective, method='L-BFGS-B',
+                                   x0=np.asarray(self.coeffs_mon[k], dtype=float), jac=True, bounds=bounds, args=(A, k))
+                finally:
+                    self._sep_cache_end()
                 self.coeffs_mon[k] = copy.deepcopy(opt.x)
                 self.coeffs_nonmon[k] = solve_nonmon(opt.x)
             J_local += float(opt.fun)
