@@ -97,6 +97,12 @@ def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
         assert relerr(tm.evaluate_pullback_density(X), p1) < 1e-10
         assert np.array_equal(tm.map(X[:1]), ZL[:1])
         assert np.array_equal(tm.map(X[:513]), ZL[:513])
+        monkeypatch.setenv('TTM_HL_NS', '4')                       # four samples per evaluating thread (1024-row tiles)
+        assert np.array_equal(tm.map(X), ZL)
+        assert np.array_equal(tm.map(X[:1025]), ZL[:1025])
+        I4 = tm.inverse_map(npz['inv_Z'])
+        monkeypatch.setenv('TTM_HL_NS', '2')
+        assert np.array_equal(tm.inverse_map(npz['inv_Z']), I4)
         # (the loader-wave inverse evaluates the offsets in U-form: same values to rounding, not bit for bit)
         assert relerr(tm.inverse_map(npz['inv_Z']), I1) < 1e-12
         assert relerr(tm.inverse_map(npz['inv_Z'][:1]), I1[:1]) < 1e-12

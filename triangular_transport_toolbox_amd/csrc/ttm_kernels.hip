@@ -715,6 +715,11 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 #define TTM_UL_CW 4           // evaluating waves per workgroup
 #endif
 #define TTM_UL_THREADS ((TTM_UL_CW + 2) * 64)
+#ifdef TTM_HL_WAVES          // tuning knob: register-allocate the hot kernels for this many waves per SIMD
+#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS, TTM_HL_WAVES)
+#else
+#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS)
+#endif
 #define TTM_UL_CT (TTM_UL_CW * 64)             // evaluating threads
 #define TTM_UL_ROWS (TTM_UL_CW * 128)          // rows per tile (evaluating waves x 64 lanes x 2 samples)
 // xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
@@ -960,21 +965,23 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_ul(const int* __rest
 // Hot-record variant of k_forward_ul (include/ttm.h "H section"): the evaluating waves read ONE fixed-stride record
 // per step (all scalar loads at known offsets, issued together) and run straight-line code: NG group records of
 // degree class CLS, every column from the planned cache.  Same loader waves, rings and barrier protocol.
-template <bool WANT_LD, int NG, int CLS>
-__global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+template <bool WANT_LD, int NG, int CLS, int NS>
+__global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
                                                     int D, int k0, int k1,
                                                     const double* __restrict__ X, int64_t ldx, int64_t N,
                                                     double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
                                                     const double* __restrict__ sigma, double* __restrict__ sumsq,
                                                     int tab_slot, int xlead, int tlead, int ways) {
-    typedef VecD<2> R;
+    typedef VecD<NS> R;
+    constexpr int ROWS = TTM_UL_CT * NS;         // rows per tile: NS / 2 blocks of 2 x TTM_UL_CT rows, thread t owns the
+    constexpr int NP = NS / 2;                   // adjacent pair (2t, 2t+1) of every block
     const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
     constexpr int HS = TTM_H_HDR + NG * GS;
     cdbl_p H = (cdbl_p)(U_ + h_off);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int ncomp = k1 - k0;
-    const int64_t ntiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+    const int64_t ntiles = (N + ROWS - 1) / ROWS;
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
 #else
     double* ring = g_smem;
 #endif
-    double* tabs = ring + (size_t)XSLOTS * TTM_UL_ROWS;
+    double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
     if (wv == TTM_UL_CW) {
@@ -1004,11 +1011,11 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
             }
             const int kc = ((cint_p)(H + (int64_t)pk * HS))[3];
             const double* col = X + (int64_t)kc * ldx;
-            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
+            double* slot = ring + (size_t)xs * ROWS;
             xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
 #pragma unroll
-            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
-                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
+            for (int c = 0; c < ROWS / 128; ++c) {
+                int64_t pair = ptile * ROWS + c * 128 + lane * 2;
                 pair = pair < last_pair ? pair : last_pair;
                 ul_dma16(col + pair, slot + c * 128);
             }
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
             const int md = hl_min_done(ctl);
             while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
             if (jp < ji) {
-                ul_wait_vmcnt((ji - jp - 1) * (TTM_UL_ROWS / 128));
+                ul_wait_vmcnt((ji - jp - 1) * (ROWS / 128));
                 ++jp;
                 if (lane == 0) ctl->ready[0] = jp;
                 spin = 0;
@@ -1034,11 +1041,11 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
         return;
 #else
         for (int j = 0; j < xlead; ++j) issue(j);
-        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+        ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
         TTM_RAW_BARRIER();
         for (int64_t s = 0; s < S; ++s) {
             issue(s + xlead);
-            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+            ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
             TTM_RAW_BARRIER();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1114,7 +1121,9 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
     cst.stride = TTM_UL_CT;
     (void)ways;
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
-    bool act0 = false, act1 = false;
+    bool act0[NP], act1[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { act0[q] = false; act1[q] = false; }
     int64_t ctile = blockIdx.x;
     int k = k0;
     R ld(0.0), ss(0.0);
@@ -1128,21 +1137,31 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
 #endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
-            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
-            act0 = n < N; act1 = n + 1 < N;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                act0[q] = n < N; act1[q] = n + 1 < N;
+            }
             ld = R(0.0); ss = R(0.0);
             if (k0 > 0) {                                                // (rare: sweeps that start inside the map)
-                XOffN<2> cx;
+                XOffN<NS> cx;
                 cx.X = (const char*)X; cx.ldb = ldx * 8;
-                cx.off[0] = (unsigned int)(act0 ? n : N - 1) * 8u;
-                cx.off[1] = (unsigned int)(act1 ? n + 1 : N - 1) * 8u;
-                PlanCache<XOffN<2>, R> x(cx, cst);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                    cx.off[2 * q] = (unsigned int)(act0[q] ? n : N - 1) * 8u;
+                    cx.off[2 * q + 1] = (unsigned int)(act1[q] ? n + 1 : N - 1) * 8u;
+                }
+                PlanCache<XOffN<NS>, R> x(cx, cst);
                 x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
             }
         }
-        const D2 xp = *(const D2*)(ring + (size_t)xs * TTM_UL_ROWS + 2 * tid);
         R xk;
-        xk.v[0] = xp.x; xk.v[1] = xp.y;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const D2 xp = *(const D2*)(ring + (size_t)xs * ROWS + q * (2 * TTM_UL_CT) + 2 * tid);
+            xk.v[2 * q] = xp.x; xk.v[2 * q + 1] = xp.y;
+        }
         const double* tab = tabs + (size_t)ts * tab_slot;
         xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
         ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
@@ -1150,20 +1169,26 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_hl(const int* __rest
         h_component<NG, DB, DA, GS, WANT_LD>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
         if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
         if (Z) {
-            double* zc = Z + (int64_t)(k - k0) * ldz + ctile * TTM_UL_ROWS + 2 * tid;
-            if (act1) { D2 o = {Sv.v[0], Sv.v[1]}; *(D2*)zc = o; }
-            else if (act0) *zc = Sv.v[0];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                double* zc = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                if (act1[q]) { D2 o = {Sv.v[2 * q], Sv.v[2 * q + 1]}; *(D2*)zc = o; }
+                else if (act0[q]) *zc = Sv.v[2 * q];
+            }
         }
         ss = vfma(Sv, Sv, ss);
         if (k + 1 == k1) {
-            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
-            if (WANT_LD) {
-                if (act1) { D2 o = {ld.v[0], ld.v[1]}; *(D2*)(logdet + n) = o; }
-                else if (act0) logdet[n] = ld.v[0];
-            }
-            if (sumsq) {
-                if (act1) { D2 o = {ss.v[0], ss.v[1]}; *(D2*)(sumsq + n) = o; }
-                else if (act0) sumsq[n] = ss.v[0];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                if (WANT_LD) {
+                    if (act1[q]) { D2 o = {ld.v[2 * q], ld.v[2 * q + 1]}; *(D2*)(logdet + n) = o; }
+                    else if (act0[q]) logdet[n] = ld.v[2 * q];
+                }
+                if (sumsq) {
+                    if (act1[q]) { D2 o = {ss.v[2 * q], ss.v[2 * q + 1]}; *(D2*)(sumsq + n) = o; }
+                    else if (act0[q]) sumsq[n] = ss.v[2 * q];
+                }
             }
             ctile += gridDim.x;
             k = k0;
@@ -1192,22 +1217,24 @@ __device__ __forceinline__ void ul_dma4(const void* g, void* lds_wave_base) {
 // computed np.linspace (yreg semantics of k_inverse_table).  Requires (nb + 1) % 4 == 0.
 // LDS (doubles): [z ring: (xlead+1) x 512 | table ring: (tlead+1) x tab_slot | column cache: 2 x ways x 2 x 256]
 // table slot: [xs: T rounded up to even | bucket index: nb + 1 int32]
-template <int NG, int CLS>
-__global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+template <int NG, int CLS, int NS>
+__global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
                                                     int D, int k0, int k1,
                                                     const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
                                                     const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
                                                     const double* __restrict__ tmin, const double* __restrict__ tmax,
                                                     const int* __restrict__ bkt, int nb, int truncate,
                                                     int tab_slot, int xlead, int tlead, int ways) {
-    typedef VecD<2> R;
+    typedef VecD<NS> R;
+    constexpr int ROWS = TTM_UL_CT * NS;
+    constexpr int NP = NS / 2;
     const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
     constexpr int HS = TTM_H_HDR + NG * GS;
     cdbl_p H = (cdbl_p)(U_ + h_off);
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int ncomp = k1 - k0;
-    const int64_t ntiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+    const int64_t ntiles = (N + ROWS - 1) / ROWS;
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
@@ -1217,10 +1244,10 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
 #else
     double* ring = g_smem;
 #endif
-    double* tabs = ring + (size_t)XSLOTS * TTM_UL_ROWS;
+    double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
     const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
-    double* etab = cache + (size_t)2 * ways * 2 * TTM_UL_CT;                   // 2^(j/32), behind the column cache
+    double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;                   // 2^(j/32), behind the column cache
 #ifdef TTM_HL_FLAGS
     // one-time LDS set-up by the first waves, then the only barrier of the kernel
     if (tid < 8) ((int*)g_smem)[tid] = 0;
@@ -1243,11 +1270,11 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
                 if (++pk == k1) { pk = k0; ptile += gridDim.x; }
             }
             const double* col = Z + (int64_t)(pk - k0) * ldz;
-            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
+            double* slot = ring + (size_t)xs * ROWS;
             xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
 #pragma unroll
-            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
-                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
+            for (int c = 0; c < ROWS / 128; ++c) {
+                int64_t pair = ptile * ROWS + c * 128 + lane * 2;
                 pair = pair < last_pair ? pair : last_pair;
                 ul_dma16(col + pair, slot + c * 128);
             }
@@ -1260,7 +1287,7 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
             const int md = hl_min_done(ctl);
             while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
             if (jp < ji) {
-                ul_wait_vmcnt((ji - jp - 1) * (TTM_UL_ROWS / 128));
+                ul_wait_vmcnt((ji - jp - 1) * (ROWS / 128));
                 ++jp;
                 if (lane == 0) ctl->ready[0] = jp;
                 spin = 0;
@@ -1273,11 +1300,11 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
         return;
 #else
         for (int j = 0; j < xlead; ++j) issue(j);
-        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+        ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
         TTM_RAW_BARRIER();
         for (int64_t s = 0; s < S; ++s) {
             issue(s + xlead);
-            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
+            ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
             TTM_RAW_BARRIER();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1361,7 +1388,9 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     cst.etab = etab;
-    bool act0 = false, act1 = false;
+    bool act0[NP], act1[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) { act0[q] = false; act1[q] = false; }
     int64_t ctile = blockIdx.x;
     int k = k0;
     int xs = 0, ts = 0;
@@ -1377,18 +1406,30 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
 #endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
-            const int64_t n = ctile * TTM_UL_ROWS + 2 * tid;
-            act0 = n < N; act1 = n + 1 < N;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                act0[q] = n < N; act1[q] = n + 1 < N;
+            }
             if (k0 > 0) {                                                // (conditional inverse: columns given in X)
-                XOffN<2> cx;
+                XOffN<NS> cx;
                 cx.X = (const char*)X; cx.ldb = ldx * 8;
-                cx.off[0] = (unsigned int)(act0 ? n : N - 1) * 8u;
-                cx.off[1] = (unsigned int)(act1 ? n + 1 : N - 1) * 8u;
-                PlanCache<XOffN<2>, R> x(cx, cst);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                    cx.off[2 * q] = (unsigned int)(act0[q] ? n : N - 1) * 8u;
+                    cx.off[2 * q + 1] = (unsigned int)(act1[q] ? n + 1 : N - 1) * 8u;
+                }
+                PlanCache<XOffN<NS>, R> x(cx, cst);
                 x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
             }
         }
-        const D2 zp = *(const D2*)(ring + (size_t)xs * TTM_UL_ROWS + 2 * tid);
+        double zv[NS];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const D2 zp = *(const D2*)(ring + (size_t)xs * ROWS + q * (2 * TTM_UL_CT) + 2 * tid);
+            zv[2 * q] = zp.x; zv[2 * q + 1] = zp.y;
+        }
         const double* xsl = tabs + (size_t)ts * tab_slot;
         const int* bkl = (const int*)(xsl + Teven);
         xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
@@ -1399,11 +1440,11 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
         const double scale = (double)nb * fast_rcp(hi - lo);
         const bool use_bkt = scale > 0.0 && scale < 1.0e300;
         const R off = h_offset<NG, DB, DA, GS, R>(rec, cst);
-        double tg[2];
-        int a[2];
+        double tg[NS];
+        int a[NS];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            double target = -off.v[e] + (e ? zp.y : zp.x);
+        for (int e = 0; e < NS; ++e) {
+            double target = -off.v[e] + zv[e];
             if (truncate) {                          // TM:4074-4076 (comparisons keep NaN untouched)
                 if (target < lo) target = lo;
                 if (target > hi) target = hi;
@@ -1416,18 +1457,19 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
         // np.searchsorted(xs, target) (left) = a + #{entries from a on that are < target}: both samples scan four
         // entries per round together (a finished sample re-counts 0); the table is followed by +inf sentinels
         for (int round = 0; round < 4096; ++round) {
-            int c[2];
+            int cmax = 0;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < NS; ++e) {
                 const double* q4 = xsl + a[e];
-                c[e] = (q4[0] < tg[e] ? 1 : 0) + (q4[1] < tg[e] ? 1 : 0) + (q4[2] < tg[e] ? 1 : 0) + (q4[3] < tg[e] ? 1 : 0);
-                a[e] += c[e];
+                const int c = (q4[0] < tg[e] ? 1 : 0) + (q4[1] < tg[e] ? 1 : 0) + (q4[2] < tg[e] ? 1 : 0) + (q4[3] < tg[e] ? 1 : 0);
+                a[e] += c;
+                cmax = c > cmax ? c : cmax;
             }
-            if (c[0] < 4 && c[1] < 4) break;
+            if (cmax < 4) break;
         }
         R r;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < NS; ++e) {
             const int i = a[e] < 1 ? 1 : (a[e] > T - 1 ? T - 1 : a[e]);
             const double x_lo = xsl[i - 1], x_hi = xsl[i];
             const double y_lo = (double)(i - 1) * ystep + y0;
@@ -1438,9 +1480,12 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_inverse_hl(const int* __rest
         h_put(rec, cst, r);
         {
             const int kc = ((cint_p)rec)[3];
-            double* xc = X + (int64_t)kc * ldx + ctile * TTM_UL_ROWS + 2 * tid;
-            if (act1) { D2 o = {r.v[0], r.v[1]}; *(D2*)xc = o; }
-            else if (act0) *xc = r.v[0];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                double* xc = X + (int64_t)kc * ldx + ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                if (act1[q]) { D2 o = {r.v[2 * q], r.v[2 * q + 1]}; *(D2*)xc = o; }
+                else if (act0[q]) *xc = r.v[2 * q];
+            }
         }
         if (k + 1 == k1) { ctile += gridDim.x; k = k0; }
         else ++k;
@@ -2094,26 +2139,39 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
             xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
             tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
-            const size_t lds_ul = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
+            // samples per evaluating thread of the hot kernels: four for the plain map (1024-row tiles, two workgroups
+            // per CU by LDS, ~100 VGPRs are then free: insensitive to the register allocation, which for the
+            // two-sample variant swings between 51 and 86 VGPRs with unrelated source changes and decides whether a
+            // third workgroup fits), two with the fused log-determinant (147 VGPRs with four)
+            int hNS = logdet ? 2 : 4;
+            if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
+            const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT");
+            const int rows = hot ? TTM_UL_CT * hNS : TTM_UL_ROWS;
+            const size_t lds_ul = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * (rows / TTM_UL_CT) * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
                                  ((uintptr_t)(fold + fold_base_size(p)) % 16 == 0);
             bool use_ul = aligned && N >= 64 * 1024 && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 / 2;
             if (const char* e = getenv("TTM_U_LOADER")) use_ul = aligned && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 && atoi(e) != 0;
-            if (use_ul && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT")) {
+            if (use_ul && hot) {
                 typedef void (*hkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*,
                                         int64_t, double*, const double*, double*, int, int, int, int);
                 hkern_t hk;
-#define TTM_HK(L, NGV) (p->u_h_cls == 1 ? k_forward_hl<L, NGV, 1> : p->u_h_cls == 2 ? k_forward_hl<L, NGV, 2> : k_forward_hl<L, NGV, 3>)
-                if (p->u_h_ng == 2) hk = logdet ? TTM_HK(true, 2) : TTM_HK(false, 2);
-                else hk = logdet ? TTM_HK(true, 4) : TTM_HK(false, 4);
+#define TTM_HK(L, NGV, NSV) (p->u_h_cls == 1 ? k_forward_hl<L, NGV, 1, NSV> : p->u_h_cls == 2 ? k_forward_hl<L, NGV, 2, NSV> : k_forward_hl<L, NGV, 3, NSV>)
+                if (hNS == 2) {
+                    if (p->u_h_ng == 2) hk = logdet ? TTM_HK(true, 2, 2) : TTM_HK(false, 2, 2);
+                    else hk = logdet ? TTM_HK(true, 4, 2) : TTM_HK(false, 4, 2);
+                } else {
+                    if (p->u_h_ng == 2) hk = logdet ? TTM_HK(true, 2, 4) : TTM_HK(false, 2, 4);
+                    else hk = logdet ? TTM_HK(true, 4, 4) : TTM_HK(false, 4, 4);
+                }
 #undef TTM_HK
                 int wgs = (int)((size_t)(160 * 1024) / lds_ul);
                 if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
                 if (wgs < 1) wgs = 1;
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
-                const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+                const int64_t tiles = (N + rows - 1) / rows;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
                 allow_big_lds((const void*)hk, lds_ul);
                 hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds_ul, (hipStream_t)stream, p->ucomp,
@@ -2121,7 +2179,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                                    logdet, sigma, sumsq, tab_slot, xlead, tlead, ways);
                 return check_launch("k_forward_hl");
             }
-            if (use_ul) {
+            if (use_ul && !hot) {
                 typedef void (*lkern_t)(const int*, const int*, const double*, int, int, int, const double*, int64_t, int64_t,
                                         double*, int64_t, double*, const double*, double*, int, int, int);
                 int mb = 0, ma = 0;
@@ -2270,7 +2328,10 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         const int Teven = (T + 4 + 1) & ~1;                              // entries + 4 sentinels, even
         const int tab_slot = Teven + (nb + 1 + 1) / 2;                   // doubles
         const int nops = ((((T * 8) & ~15) + 1023) >> 10) + ((T & 1) ? 1 : 0) + (((nb + 1) * 4 + 1023) >> 10);
-        const size_t lds = ((size_t)(xlead + 1) * TTM_UL_ROWS + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * 2 * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
+        int hNS = 2;
+        if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
+        const int rows = TTM_UL_CT * hNS;
+        const size_t lds = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * hNS * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
         const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
                              ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ((uintptr_t)bkt % 16 == 0) && ((uintptr_t)tab_x % 8 == 0);
         bool use = aligned && N >= 64 * 1024 && nops <= 15 && lds <= (size_t)160 * 1024 / 2;
@@ -2280,14 +2341,15 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                                     const double*, int, double, double, double, const double*, const double*, const int*, int, int,
                                     int, int, int, int);
             ikern_t ik;
-#define TTM_IK(NGV) (p->u_h_cls == 1 ? k_inverse_hl<NGV, 1> : p->u_h_cls == 2 ? k_inverse_hl<NGV, 2> : k_inverse_hl<NGV, 3>)
-            if (p->u_h_ng == 2) ik = TTM_IK(2); else ik = TTM_IK(4);
+#define TTM_IK(NGV, NSV) (p->u_h_cls == 1 ? k_inverse_hl<NGV, 1, NSV> : p->u_h_cls == 2 ? k_inverse_hl<NGV, 2, NSV> : k_inverse_hl<NGV, 3, NSV>)
+            if (hNS == 2) { if (p->u_h_ng == 2) ik = TTM_IK(2, 2); else ik = TTM_IK(4, 2); }
+            else { if (p->u_h_ng == 2) ik = TTM_IK(2, 4); else ik = TTM_IK(4, 4); }
 #undef TTM_IK
             int wgs = (int)((size_t)(160 * 1024) / lds);
             if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
             if (wgs < 1) wgs = 1;
             if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
-            const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
+            const int64_t tiles = (N + rows - 1) / rows;
             const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
             allow_big_lds((const void*)ik, lds);
             hipLaunchKernelGGL(ik, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
