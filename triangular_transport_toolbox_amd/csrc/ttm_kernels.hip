@@ -769,48 +769,94 @@ __device__ __forceinline__ void ul_wait_vmcnt(int n) {      // all but the n you
     }
 }
 
-// ---- flag hand-over between loader and evaluating waves (TTM_HL_FLAGS) -------------------------------------------
-// Progress words at the start of the workgroup's LDS: ready[0] / ready[1] = number of steps whose column / table has
-// landed (written by the loader after its counted vmcnt wait), done[w] = number of steps evaluating wave w has
-// finished (written after the step's last LDS read).  A loader issues step j into ring slot j % SLOTS once
-// min(done) >= j - SLOTS + 1; an evaluating wave starts step s once ready[0] > s and ready[1] > s.  No barrier in the
-// loop: the evaluating waves drift apart by up to the ring depth instead of meeting every step.  Every spin is
-// bounded (a protocol error ends in wrong numbers, which the parity tests catch, never in a hung GPU).
-struct HlCtl {
-    int ready[2];
-    int done[4];
-    int pad[2];
-};
-#define TTM_HL_SPIN_MAX (1 << 22)
-#ifndef TTM_HL_SLEEP
-#define TTM_HL_SLEEP 8       // s_sleep argument (x 64 cycles) of an idle loader's poll loop
-#endif
-
-__device__ __forceinline__ int hl_min_done(volatile HlCtl* c) {
-    const int a = c->done[0], b = c->done[1], d = c->done[2], e = c->done[3];
-    const int m = min(min(a, b), min(d, e));
-    return __builtin_amdgcn_readfirstlane(m);
-}
-__device__ __forceinline__ void hl_wait_ready(volatile HlCtl* c, int s) {
-    for (int i = 0; i < TTM_HL_SPIN_MAX; ++i) {
-        const int a = __builtin_amdgcn_readfirstlane(c->ready[0]), b = __builtin_amdgcn_readfirstlane(c->ready[1]);
-        if (a > s && b > s) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
-
 __device__ __forceinline__ void ul_dma16(const void* g, double* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// x loader: column of step `step` (clamped to the last step: duplicates) -> ring slot step % XSLOTS
-struct UlCursor {
-    int64_t tile;        // tile index of the cursor
-    int k;
-    int64_t step;
-};
+// Column loader wave: streams, for every step (tile, k) of the workgroup's flat step sequence, the 16-byte row pairs
+// of column col_of(k) of the tile into ring slot step % XSLOTS, xlead steps ahead of the evaluation, and meets the
+// evaluating waves at one barrier per step (A(0) before the first step, A(s + 1) after step s): it arrives only
+// after its counted vmcnt wait says the data of the next step has landed, and having passed A(s) it may overwrite
+// the slot of step s - 1.  Past the last step it keeps issuing (harmless duplicates of the last column) so that
+// the number of younger operations behind the vmcnt immediate stays what it is in the steady state.
+template <int ROWS, class ColOf>
+__device__ __forceinline__ void ul_column_loader(ColOf col_of, int k0, int k1, int64_t S, int64_t N, double* ring,
+                                                 int XSLOTS, int xlead, int lane) {
+    const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;               // first row of the last readable pair
+    int64_t ptile = blockIdx.x;
+    int pk = k0;
+    int64_t pstep = 0;                                                   // step the cursor (ptile, pk) stands for
+    int xs = 0;                                                          // ring slot of the next issue
+    auto issue = [&](int64_t step) {
+        while (pstep < step && pstep < S - 1) {                          // advance the cursor to min(step, S - 1)
+            ++pstep;
+            if (++pk == k1) { pk = k0; ptile += gridDim.x; }
+        }
+        const double* col = col_of(pk);
+        double* slot = ring + (size_t)xs * ROWS;
+        xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
+#pragma unroll
+        for (int c = 0; c < ROWS / 128; ++c) {
+            int64_t pair = ptile * ROWS + c * 128 + lane * 2;
+            pair = pair < last_pair ? pair : last_pair;
+            ul_dma16(col + pair, slot + c * 128);
+        }
+    };
+    for (int j = 0; j < xlead; ++j) issue(j);
+    ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
+    TTM_RAW_BARRIER();                                                   // A(0)
+    for (int64_t s = 0; s < S; ++s) {
+        issue(s + xlead);
+        ul_wait_vmcnt((xlead - 1) * (ROWS / 128));                       // the column of step s + 1 has landed
+        TTM_RAW_BARRIER();                                               // A(s + 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // drain before the LDS is released
+}
+
+// Table loader wave: issue_tab(k, slot) DMAs the per-component table of component k into `slot` and returns the
+// number of operations it issued (<= 15); same barrier protocol, tlead (1 or 2) steps ahead.
+template <class IssueTab>
+__device__ __forceinline__ void ul_table_loader(IssueTab issue_tab, int k0, int k1, int64_t S, double* tabs, int tab_slot,
+                                                int TSLOTS, int tlead) {
+    int pk = k0;
+    int64_t pstep = 0;
+    int ts = 0;                                                          // table slot of the next issue
+    auto issue = [&](int64_t step) -> int {
+        while (pstep < step && pstep < S - 1) {
+            ++pstep;
+            if (++pk == k1) pk = k0;
+        }
+        double* slot = tabs + (size_t)ts * tab_slot;
+        ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
+        return issue_tab(pk, slot);
+    };
+    issue(0);
+    const int n1 = tlead > 1 ? issue(1) : 0;
+    ul_wait_vmcnt(n1);
+    TTM_RAW_BARRIER();                                                   // A(0)
+    for (int64_t s = 0; s < S; ++s) {
+        const int n = issue(s + tlead);
+        ul_wait_vmcnt(tlead > 1 ? n : 0);                                // the table of step s + 1 has landed
+        TTM_RAW_BARRIER();                                               // A(s + 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// DMA of `bytes` (multiple of 16) from src to an LDS slot, 1 KB per wave-instruction; returns the instruction count
+__device__ __forceinline__ int ul_dma_block(const char* src, int bytes, double* slot, int lane) {
+    const int nch = (bytes + 1023) >> 10;
+    for (int c = 0; c < nch; ++c) {
+        const int off = c * 1024 + lane * 16;
+        if (off < bytes) ul_dma16(src + off, slot + c * 128);
+    }
+    return nch;
+}
+
+__device__ __forceinline__ void ul_dma4(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
 
 template <bool WANT_LD, int DB, int DA>
 __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_ul(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
@@ -835,71 +881,15 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_ul(const int* __rest
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
     if (wv == TTM_UL_CW) {
-        // ---- x loader -------------------------------------------------------------------------------------------
-        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;           // first row of the last readable pair
-        int64_t ptile = blockIdx.x;
-        int pk = k0;
-        int64_t pstep = 0;                                               // step the cursor (ptile, pk) stands for
-        int xs = 0;                                                      // ring slot of the next issue (steps in order)
-        auto issue = [&](int64_t step) {
-            // advance the cursor to min(step, S - 1)
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
-            }
-            const double* col = X + (int64_t)ucomp[pk * TTM_UC_LEN + TTM_UC_KC] * ldx;
-            double* slot = ring + (size_t)xs * TTM_UL_ROWS;
-            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
-#pragma unroll
-            for (int c = 0; c < TTM_UL_ROWS / 128; ++c) {
-                int64_t pair = ptile * TTM_UL_ROWS + c * 128 + lane * 2;
-                pair = pair < last_pair ? pair : last_pair;
-                ul_dma16(col + pair, slot + c * 128);
-            }
-        };
-        for (int j = 0; j < xlead; ++j) issue(j);
-        ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));
-        TTM_RAW_BARRIER();                                               // A(0)
-        for (int64_t s = 0; s < S; ++s) {
-            issue(s + xlead);
-            ul_wait_vmcnt((xlead - 1) * (TTM_UL_ROWS / 128));            // x(s + 1) has landed
-            TTM_RAW_BARRIER();                                           // A(s + 1)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // drain before the LDS is released
+        ul_column_loader<TTM_UL_ROWS>([&](int kk) { return X + (int64_t)ucomp[kk * TTM_UC_LEN + TTM_UC_KC] * ldx; }, k0, k1, S, N,
+                                      ring, XSLOTS, xlead, lane);
         return;
     }
     if (wv == TTM_UL_CW + 1) {
-        // ---- table loader ---------------------------------------------------------------------------------------
-        int pk = k0;
-        int64_t pstep = 0;
-        int ts = 0;                                                      // table slot of the next issue
-        auto issue = [&](int64_t step) -> int {
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) pk = k0;
-            }
-            const int nI = ucomp[pk * TTM_UC_LEN + TTM_UC_NI];
-            const int bytes = nI * (TTM_U_TSTRIDE * 8);
-            const char* src = (const char*)(U_ + ucomp[pk * TTM_UC_LEN + TTM_UC_TAB_OFF]);
-            double* slot = tabs + (size_t)ts * tab_slot;
-            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
-            const int nch = (bytes + 1023) >> 10;
-            for (int c = 0; c < nch; ++c) {
-                const int off = c * 1024 + lane * 16;
-                if (off < bytes) ul_dma16(src + off, slot + c * 128);
-            }
-            return nch;
-        };
-        issue(0);
-        const int n1 = tlead > 1 ? issue(1) : 0;
-        ul_wait_vmcnt(n1);
-        TTM_RAW_BARRIER();                                               // A(0)
-        for (int64_t s = 0; s < S; ++s) {
-            const int n = issue(s + tlead);
-            ul_wait_vmcnt(tlead > 1 ? n : 0);                            // table(s + 1) has landed
-            TTM_RAW_BARRIER();                                           // A(s + 1)
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ul_table_loader([&](int kk, double* slot) {
+            const int bytes = ucomp[kk * TTM_UC_LEN + TTM_UC_NI] * (TTM_U_TSTRIDE * 8);
+            return ul_dma_block((const char*)(U_ + ucomp[kk * TTM_UC_LEN + TTM_UC_TAB_OFF]), bytes, slot, lane);
+        }, k0, k1, S, tabs, tab_slot, TSLOTS, tlead);
         return;
     }
 
@@ -985,134 +975,21 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
-#ifdef TTM_HL_FLAGS
-    volatile HlCtl* ctl = (volatile HlCtl*)g_smem;                       // progress words (32 bytes)
-    double* ring = g_smem + 4;
-    if (tid < 8) ((int*)g_smem)[tid] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TTM_RAW_BARRIER();                                                   // the only barrier: progress words are zero
-#else
     double* ring = g_smem;
-#endif
     double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
     if (wv == TTM_UL_CW) {
-        // ---- x loader -------------------------------------------------------------------------------------------
-        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
-        int64_t ptile = blockIdx.x;
-        int pk = k0;
-        int64_t pstep = 0;
-        int xs = 0;
-        auto issue = [&](int64_t step) {
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
-            }
-            const int kc = ((cint_p)(H + (int64_t)pk * HS))[3];
-            const double* col = X + (int64_t)kc * ldx;
-            double* slot = ring + (size_t)xs * ROWS;
-            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
-#pragma unroll
-            for (int c = 0; c < ROWS / 128; ++c) {
-                int64_t pair = ptile * ROWS + c * 128 + lane * 2;
-                pair = pair < last_pair ? pair : last_pair;
-                ul_dma16(col + pair, slot + c * 128);
-            }
-        };
-#ifdef TTM_HL_FLAGS
-        // issue while slots are free, then wait for the oldest unpublished step to land and publish it
-        int ji = 0, jp = 0;
-        const int Si = (int)S;
-        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
-            const int md = hl_min_done(ctl);
-            while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
-            if (jp < ji) {
-                ul_wait_vmcnt((ji - jp - 1) * (ROWS / 128));
-                ++jp;
-                if (lane == 0) ctl->ready[0] = jp;
-                spin = 0;
-            } else {
-                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
-                ++spin;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ul_column_loader<ROWS>([&](int kk) { return X + (int64_t)((cint_p)(H + (int64_t)kk * HS))[3] * ldx; }, k0, k1, S, N, ring,
+                               XSLOTS, xlead, lane);
         return;
-#else
-        for (int j = 0; j < xlead; ++j) issue(j);
-        ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
-        TTM_RAW_BARRIER();
-        for (int64_t s = 0; s < S; ++s) {
-            issue(s + xlead);
-            ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
-            TTM_RAW_BARRIER();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-#endif
     }
     if (wv == TTM_UL_CW + 1) {
-        // ---- table loader ---------------------------------------------------------------------------------------
-        int pk = k0;
-        int64_t pstep = 0;
-        int ts = 0;
-        auto issue = [&](int64_t step) -> int {
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) pk = k0;
-            }
-            cint_p ri = (cint_p)(H + (int64_t)pk * HS);
-            const int nI = ri[2];
-            const int bytes = nI * (TTM_U_TSTRIDE * 8);
-            const char* src = (const char*)(U_ + ri[12]);
-            double* slot = tabs + (size_t)ts * tab_slot;
-            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
-            const int nch = (bytes + 1023) >> 10;
-            for (int c = 0; c < nch; ++c) {
-                const int off = c * 1024 + lane * 16;
-                if (off < bytes) ul_dma16(src + off, slot + c * 128);
-            }
-            return nch;
-        };
-#ifdef TTM_HL_FLAGS
-        int ji = 0, jp = 0;
-        const int Si = (int)S;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;                              // operations of the steps in flight, by step & 3
-        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
-            const int md = hl_min_done(ctl);
-            while (ji < Si && ji - md < TSLOTS && ji - jp < 3) {
-                const int n = issue(ji);
-                if ((ji & 3) == 0) c0 = n; else if ((ji & 3) == 1) c1 = n; else if ((ji & 3) == 2) c2 = n; else c3 = n;
-                ++ji;
-            }
-            if (jp < ji) {
-                int younger = 0;                                         // operations issued after step jp's
-                for (int q = jp + 1; q < ji; ++q) younger += (q & 3) == 0 ? c0 : ((q & 3) == 1 ? c1 : ((q & 3) == 2 ? c2 : c3));
-                ul_wait_vmcnt(younger);
-                ++jp;
-                if (lane == 0) ctl->ready[1] = jp;
-                spin = 0;
-            } else {
-                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
-                ++spin;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ul_table_loader([&](int kk, double* slot) {
+            cint_p ri = (cint_p)(H + (int64_t)kk * HS);
+            return ul_dma_block((const char*)(U_ + ri[12]), ri[2] * (TTM_U_TSTRIDE * 8), slot, lane);
+        }, k0, k1, S, tabs, tab_slot, TSLOTS, tlead);
         return;
-#else
-        issue(0);
-        const int n1 = tlead > 1 ? issue(1) : 0;
-        ul_wait_vmcnt(n1);
-        TTM_RAW_BARRIER();
-        for (int64_t s = 0; s < S; ++s) {
-            const int n = issue(s + tlead);
-            ul_wait_vmcnt(tlead > 1 ? n : 0);
-            TTM_RAW_BARRIER();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-#endif
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
@@ -1128,13 +1005,8 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
     int k = k0;
     R ld(0.0), ss(0.0);
     int xs = 0, ts = 0;
-#ifndef TTM_HL_FLAGS
     TTM_RAW_BARRIER();                                                   // A(0)
-#endif
     for (int64_t s = 0; s < S; ++s) {
-#ifdef TTM_HL_FLAGS
-        hl_wait_ready(ctl, (int)s);
-#endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
 #pragma unroll
@@ -1195,18 +1067,8 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
         } else {
             ++k;
         }
-#ifdef TTM_HL_FLAGS
-        asm volatile("" ::: "memory");
-        if (lane == 0) ctl->done[wv] = (int)s + 1;                       // (DS operations of a wave execute in order)
-#else
         TTM_RAW_BARRIER();                                               // A(s + 1)
-#endif
     }
-}
-
-__device__ __forceinline__ void ul_dma4(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
 // Table inverse from hot records with loader waves (same workgroup anatomy and barrier protocol as k_forward_hl):
@@ -1238,155 +1100,35 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
     if ((int64_t)blockIdx.x >= ntiles) return;
     const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
     const int64_t S = my_tiles * ncomp;
-#ifdef TTM_HL_FLAGS
-    volatile HlCtl* ctl = (volatile HlCtl*)g_smem;                       // progress words (32 bytes)
-    double* ring = g_smem + 4;
-#else
     double* ring = g_smem;
-#endif
     double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
     const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
     double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;                   // 2^(j/32), behind the column cache
-#ifdef TTM_HL_FLAGS
-    // one-time LDS set-up by the first waves, then the only barrier of the kernel
-    if (tid < 8) ((int*)g_smem)[tid] = 0;
-    if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
-    if (tid >= 64 && tid < 64 + TTM_EXPQ_TABLE_LEN) etab[tid - 64] = g_expq_table[tid - 64];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    TTM_RAW_BARRIER();
-#endif
 
     if (wv == TTM_UL_CW) {
-        // ---- z loader -------------------------------------------------------------------------------------------
-        const int64_t last_pair = ((N + 1) & ~(int64_t)1) - 2;
-        int64_t ptile = blockIdx.x;
-        int pk = k0;
-        int64_t pstep = 0;
-        int xs = 0;
-        auto issue = [&](int64_t step) {
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) { pk = k0; ptile += gridDim.x; }
-            }
-            const double* col = Z + (int64_t)(pk - k0) * ldz;
-            double* slot = ring + (size_t)xs * ROWS;
-            xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
-#pragma unroll
-            for (int c = 0; c < ROWS / 128; ++c) {
-                int64_t pair = ptile * ROWS + c * 128 + lane * 2;
-                pair = pair < last_pair ? pair : last_pair;
-                ul_dma16(col + pair, slot + c * 128);
-            }
-        };
-#ifdef TTM_HL_FLAGS
-        // issue while slots are free, then wait for the oldest unpublished step to land and publish it
-        int ji = 0, jp = 0;
-        const int Si = (int)S;
-        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
-            const int md = hl_min_done(ctl);
-            while (ji < Si && ji - md < XSLOTS && ji - jp < 7) issue(ji++);
-            if (jp < ji) {
-                ul_wait_vmcnt((ji - jp - 1) * (ROWS / 128));
-                ++jp;
-                if (lane == 0) ctl->ready[0] = jp;
-                spin = 0;
-            } else {
-                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
-                ++spin;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ul_column_loader<ROWS>([&](int kk) { return Z + (int64_t)(kk - k0) * ldz; }, k0, k1, S, N, ring, XSLOTS, xlead, lane);
         return;
-#else
-        for (int j = 0; j < xlead; ++j) issue(j);
-        ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
-        TTM_RAW_BARRIER();
-        for (int64_t s = 0; s < S; ++s) {
-            issue(s + xlead);
-            ul_wait_vmcnt((xlead - 1) * (ROWS / 128));
-            TTM_RAW_BARRIER();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-#endif
     }
     if (wv == TTM_UL_CW + 1) {
-        // ---- table loader: xs row (T doubles) + bucket row (nb + 1 int32) -----------------------------------------
-        int pk = k0;
-        int64_t pstep = 0;
-        int ts = 0;
-        const int bytes1 = (T * 8) & ~15, tail4 = (T * 8 - bytes1) / 4;       // 16-byte units, then 0 or 2 dwords
-        const int bytes2 = (nb + 1) * 4;
-        const int nch1 = (bytes1 + 1023) >> 10, nch2 = (bytes2 + 1023) >> 10;
-        auto issue = [&](int64_t step) -> int {
-            while (pstep < step && pstep < S - 1) {
-                ++pstep;
-                if (++pk == k1) pk = k0;
-            }
-            const char* src1 = (const char*)(tab_x + (int64_t)(pk - k0) * T);
-            const char* src2 = (const char*)(bkt + (int64_t)(pk - k0) * (nb + 1));
-            double* slot = tabs + (size_t)ts * tab_slot;
-            ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
-            for (int c = 0; c < nch1; ++c) {
-                const int off = c * 1024 + lane * 16;
-                if (off < bytes1) ul_dma16(src1 + off, slot + c * 128);
-            }
+        // xs row (T doubles: whole 16-byte units, then the odd double as two dwords) + bucket row (nb + 1 int32)
+        const int bytes1 = (T * 8) & ~15, tail4 = (T * 8 - bytes1) / 4;
+        ul_table_loader([&](int kk, double* slot) {
+            const char* src1 = (const char*)(tab_x + (int64_t)(kk - k0) * T);
+            int n = ul_dma_block(src1, bytes1, slot, lane);
             if (lane < tail4) ul_dma4(src1 + bytes1 + lane * 4, (char*)slot + bytes1);
-            for (int c = 0; c < nch2; ++c) {
-                const int off = c * 1024 + lane * 16;
-                if (off < bytes2) ul_dma16(src2 + off, slot + Teven + c * 128);
-            }
-            return nch1 + (tail4 ? 1 : 0) + nch2;
-        };
-#ifdef TTM_HL_FLAGS
-        int ji = 0, jp = 0;
-        const int Si = (int)S;
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;                              // operations of the steps in flight, by step & 3
-        for (int spin = 0; jp < Si && spin < TTM_HL_SPIN_MAX; ) {
-            const int md = hl_min_done(ctl);
-            while (ji < Si && ji - md < TSLOTS && ji - jp < 3) {
-                const int n = issue(ji);
-                if ((ji & 3) == 0) c0 = n; else if ((ji & 3) == 1) c1 = n; else if ((ji & 3) == 2) c2 = n; else c3 = n;
-                ++ji;
-            }
-            if (jp < ji) {
-                int younger = 0;                                         // operations issued after step jp's
-                for (int q = jp + 1; q < ji; ++q) younger += (q & 3) == 0 ? c0 : ((q & 3) == 1 ? c1 : ((q & 3) == 2 ? c2 : c3));
-                ul_wait_vmcnt(younger);
-                ++jp;
-                if (lane == 0) ctl->ready[1] = jp;
-                spin = 0;
-            } else {
-                __builtin_amdgcn_s_sleep(TTM_HL_SLEEP);
-                ++spin;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            n += tail4 ? 1 : 0;
+            return n + ul_dma_block((const char*)(bkt + (int64_t)(kk - k0) * (nb + 1)), (nb + 1) * 4, slot + Teven, lane);
+        }, k0, k1, S, tabs, tab_slot, TSLOTS, tlead);
         return;
-#else
-        issue(0);
-        const int n1 = tlead > 1 ? issue(1) : 0;
-        ul_wait_vmcnt(n1);
-        TTM_RAW_BARRIER();
-        for (int64_t s = 0; s < S; ++s) {
-            const int n = issue(s + tlead);
-            ul_wait_vmcnt(tlead > 1 ? n : 0);
-            TTM_RAW_BARRIER();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-#endif
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
     CacheStore<R> cst;
     cst.base = cache + tid;
     cst.stride = TTM_UL_CT;
-#ifndef TTM_HL_FLAGS
     if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     cst.etab = etab;
     bool act0[NP], act1[NP];
 #pragma unroll
@@ -1394,16 +1136,11 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
     int64_t ctile = blockIdx.x;
     int k = k0;
     int xs = 0, ts = 0;
-#ifndef TTM_HL_FLAGS
     // sentinels behind the table entries of every slot (the DMAs only ever write the first T doubles)
     if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     TTM_RAW_BARRIER();                                                   // A(0)
-#endif
     for (int64_t s = 0; s < S; ++s) {
-#ifdef TTM_HL_FLAGS
-        hl_wait_ready(ctl, (int)s);
-#endif
         cdbl_p rec = H + (int64_t)k * HS;
         if (k == k0) {
 #pragma unroll
@@ -1489,12 +1226,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         }
         if (k + 1 == k1) { ctile += gridDim.x; k = k0; }
         else ++k;
-#ifdef TTM_HL_FLAGS
-        asm volatile("" ::: "memory");
-        if (lane == 0) ctl->done[wv] = (int)s + 1;
-#else
         TTM_RAW_BARRIER();                                               // A(s + 1)
-#endif
     }
 }
 
@@ -2147,7 +1879,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
             const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT");
             const int rows = hot ? TTM_UL_CT * hNS : TTM_UL_ROWS;
-            const size_t lds_ul = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * (rows / TTM_UL_CT) * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
+            const size_t lds_ul = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * (rows / TTM_UL_CT) * TTM_UL_CT + TTM_EXPQ_TABLE_LEN) * 8;
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
@@ -2331,7 +2063,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         int hNS = 2;
         if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
         const int rows = TTM_UL_CT * hNS;
-        const size_t lds = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * hNS * TTM_UL_CT + TTM_EXPQ_TABLE_LEN + 4) * 8;
+        const size_t lds = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * hNS * TTM_UL_CT + TTM_EXPQ_TABLE_LEN) * 8;
         const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
                              ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ((uintptr_t)bkt % 16 == 0) && ((uintptr_t)tab_x % 8 == 0);
         bool use = aligned && N >= 64 * 1024 && nops <= 15 && lds <= (size_t)160 * 1024 / 2;
