@@ -14,7 +14,7 @@ data-path collective).
 
 prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel
 (forward map: algorithmic bytes 8 N (d_used + D)) and a
-`cpu_baseline` object (the CPU oracle timed on a bounded sample, rank 0, N=1).
+`cpu_baseline` object (the CPU oracle, one process per host core on a bounded sample each, rank 0, N=1).
 """
 import argparse
 import json
@@ -70,21 +70,47 @@ def d_used(tm):
     return len(cols)
 
 
-def cpu_baseline(workload, X, cfg, tm, n_cpu):
-    """The CPU oracle (NumPy restatement of the reference path) on the first n_cpu samples."""
+def _cpu_worker(args):
+    """One host core: the CPU oracle on its own n-sample ensemble of the workload (forward + inverse)."""
+    workload, n, seed = args
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[v] = '1'
     from oracle.ttm_oracle import OracleMap      # timed baseline only
-    Xc = X[:n_cpu]
+    from triangular_transport_toolbox_amd import specs
+    cfgname, _, fixture, _ = WORKLOADS[workload]
+    cfg = specs.config(cfgname)
+    Xc = cfg['sampler'](n, seed=seed)
     om = OracleMap(X=Xc, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], **cfg['kwargs'])
-    om.coeffs_mon = [np.array(c, copy=True) for c in tm.coeffs_mon]
-    om.coeffs_nonmon = [np.array(c, copy=True) for c in tm.coeffs_nonmon]
+    om.coeffs_mon, om.coeffs_nonmon = load_coeffs(fixture, om.D)
     t0 = time.perf_counter()
     Z = om.map(Xc)
     t1 = time.perf_counter()
     om.inverse_map(Z)
     t2 = time.perf_counter()
-    return dict(value=n_cpu * om.D / (t2 - t0), unit='map-evals/s', cores=1, kind='port',
-                sample='oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), forward+inverse on the '
-                       'first %d samples of the same ensemble: forward %.2f s, inverse %.2f s' % (n_cpu, t1 - t0, t2 - t1),
+    return n * om.D, t1 - t0, t2 - t1
+
+
+def cpu_baseline(workload, n_cpu, cores):
+    """The CPU oracle (NumPy restatement of the reference CPU path), one process per host core, every process on
+    its own n_cpu-sample ensemble - the sample-parallel use of the host the reference's `workers` pool
+    (TM:2789-2874) aims at.  Must run BEFORE this process initialises the GPU (the pool forks)."""
+    import multiprocessing as mp
+    seeds = [7000 + 13 * i for i in range(cores)]
+    t0 = time.perf_counter()
+    if cores > 1:
+        with mp.get_context('fork').Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(workload, n_cpu, sd) for sd in seeds])
+    else:
+        res = [_cpu_worker((workload, n_cpu, seeds[0]))]
+    wall = time.perf_counter() - t0
+    evals = sum(r[0] for r in res)
+    busy = max(r[1] + r[2] for r in res)
+    return dict(value=evals / busy, unit='map-evals/s', cores=cores, kind='port',
+                sample='oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), %d processes x %d samples of '
+                       'the workload each, forward+inverse; slowest process %.2f s (forward %.2f s, inverse %.2f s on '
+                       'average), %.1f s wall including start-up; one process alone: %.3g map-evals/s'
+                       % (cores, n_cpu, busy, float(np.mean([r[1] for r in res])), float(np.mean([r[2] for r in res])), wall,
+                          float(np.mean([r[0] / (r[1] + r[2]) for r in res]))),
                 host_cores_available=os.cpu_count())
 
 
@@ -97,15 +123,24 @@ def main():
     ap.add_argument('--n', type=int, default=0, help='override the ensemble size (testing only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimize', action='store_true')
-    ap.add_argument('--cpu-samples', type=int, default=0)
+    ap.add_argument('--cpu-samples', type=int, default=0, help='samples per host process of the CPU baseline')
+    ap.add_argument('--cpu-cores', type=int, default=0, help='host processes of the CPU baseline (default 1)')
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus and world > 1:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        # first, before anything touches the GPU: the host baseline forks one process per core
+        n_cpu = args.cpu_samples or {'C5': 300000, 'C3': 500000, 'C2b': 500000, 'C2a': 5000}[args.workload]
+        # one process by default: on the one-GPU boxes of this pool 8 (64) concurrent oracle processes took 7x (47x)
+        # longer each - the aggregate stayed at 1.3e6 (1.5e6) map-evals/s against 1.1e6 for one process alone
+        cores = args.cpu_cores or 1
+        cpu = cpu_baseline(args.workload, n_cpu, cores)
+    import torch
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -217,9 +252,8 @@ def main():
             'roundtrip_max_abs_err': err,
         }
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
-            n_cpu = args.cpu_samples or {'C5': 300000, 'C3': 500000, 'C2b': 500000, 'C2a': 5000}[args.workload]
-            out['cpu_baseline'] = cpu_baseline(args.workload, X, cfg, tm, min(n_cpu, N))
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
