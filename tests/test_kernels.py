@@ -190,3 +190,37 @@ def test_separable_objective_from_cached_basis(backend, name):
         assert abs(J1 - J0) <= 1e-12 * (1 + abs(J0)) and relerr(G1, G0) < 1e-12
         J3, G3 = tm.separable_objective(2 * c, A, k)
         assert abs(J2 - J3) <= 1e-12 * (1 + abs(J3)) and relerr(G2, G3) < 1e-12
+
+
+@pytest.mark.gpu
+def test_full_size_c5_properties():
+    """BASELINE configuration C5 at its full size (d = 40, N = 10^6) through the loader-wave kernels: oracle
+    agreement on a strided subset (forward, table inverse, pullback density), permutation equivariance (exact: samples
+    are independent), the round trip S(S^-1(z)) against the table resolution, and the fused sum of squares."""
+    from triangular_transport_toolbox_amd import specs
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    N = 1000000
+    cfg = specs.config('C5')
+    X = cfg['sampler'](N)
+    npz, desc = load_case('c5_sep')
+    tm = transport_map(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], verbose=False, **cfg['kwargs'])
+    tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
+    assert tm._cm.u_enabled and tm._cm.u_h_cls > 0
+    idx = np.arange(0, N, 4001)
+    om = OracleMap(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], **cfg['kwargs'])   # (moments, quantiles)
+    om.coeffs_mon, om.coeffs_nonmon = coeff_lists(npz, tm.D)
+    assert relerr(tm.X_mean, om.X_mean) < 1e-12 and relerr(tm.X_std, om.X_std) < 1e-12
+    Z = tm.map(X)
+    assert relerr(Z[idx], om.map(X[idx])) < 1e-11
+    perm = np.random.default_rng(3).permutation(N)
+    assert np.array_equal(tm.map(X[perm]), Z[perm])
+    Xi = tm.inverse_map(Z)
+    assert relerr(Xi[idx], om.inverse_map(Z[idx])) < 1e-9
+    # round trip: the table inverse interpolates linearly between 1001 points on [-10, 10] (TM:4039-4082)
+    assert np.max(np.abs(Xi - X) / tm.X_std) < 5e-4
+    assert relerr(tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])) < 1e-9
+    # fused sum of squares of the device entry point == row norms of Z
+    ss = tm._empty(N)
+    tm.forward_device(tm._Xs, N, sumsq=ss)
+    assert relerr(ss.cpu().numpy(), np.sum(Z * Z, axis=1)) < 1e-12
