@@ -43,7 +43,7 @@ def load_coeffs(fixture, D):
     return ([npz['coeffs_mon_%d' % k] for k in range(D)], [npz['coeffs_nonmon_%d' % k] for k in range(D)])
 
 
-def build_map(workload, rank, n_override=None):
+def build_map(workload, rank, n_override=None, **extra_kwargs):
     from triangular_transport_toolbox_amd import specs
     from triangular_transport_toolbox_amd.transport_map import transport_map
     cfgname, N, fixture, _ = WORKLOADS[workload]
@@ -52,7 +52,8 @@ def build_map(workload, rank, n_override=None):
     cfg = specs.config(cfgname)
     seed = {'C5': 12345, 'C3': 0, 'C2b': 0, 'C2a': 0}[workload] + 1000 * rank
     X = cfg['sampler'](N, seed=seed)
-    tm = transport_map(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], verbose=False, **cfg['kwargs'])
+    tm = transport_map(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], verbose=False, **cfg['kwargs'],
+                       **extra_kwargs)
     tm.coeffs_mon, tm.coeffs_nonmon = load_coeffs(fixture, tm.D)
     return tm, X, cfg
 
@@ -120,7 +121,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='C5', choices=sorted(WORKLOADS))
-    ap.add_argument('--n', type=int, default=0, help='override the ensemble size (testing only)')
+    ap.add_argument('--n', '--samples', dest='n', type=int, default=0, help='override the ensemble size (testing only)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimize', action='store_true')
     ap.add_argument('--cpu-samples', type=int, default=0, help='samples per host process of the CPU baseline')
@@ -141,14 +144,19 @@ def main():
         cores = args.cpu_cores or 1
         cpu = cpu_baseline(args.workload, n_cpu, cores)
     import torch
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU)
+    torch.cuda.set_device(local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_dev))
+        else:
+            dist.init_process_group(args.backend)
 
     tm, X, cfg = build_map(args.workload, rank, args.n or None)
     N, D, d = tm._N, tm.D, tm._cm.d_cols
+    du = d_used(tm)
     separable = tm.monotonicity == 'separable monotonicity'
     coef = tm._pack_coeffs()
     Xs = tm._Xs
@@ -216,9 +224,28 @@ def main():
         torch.cuda.synchronize()
         extra['optimize_s'] = time.perf_counter() - t0o
         tm.coeffs_mon, tm.coeffs_nonmon = saved
+    if world > 1 and not args.no_optimize:
+        # optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
+        # holds the same ensemble (seed of rank 0), optimises a strided subset of the components, coefficients are
+        # exchanged once and the summed objective is the one RCCL all-reduce.  Never fatal for the scaling run.
+        try:
+            del tm, Xs, Z, Xinv
+            tm2, _, _ = build_map(args.workload, 0, args.n or None, shard_components=True)
+            for k in range(tm2.D):
+                tm2.coeffs_mon[k] = tm2.coeffs_mon[k] * 0 + tm2.coeffs_init
+                tm2.coeffs_nonmon[k] = tm2.coeffs_nonmon[k] * 0 + tm2.coeffs_init
+            sync()
+            t0o = time.perf_counter()
+            tm2.optimize()
+            sync()
+            t = torch.tensor([time.perf_counter() - t0o], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            extra['optimize_component_sharded_s'] = float(t.item())
+            extra['optimize_objective_total'] = float(tm2.objective_total)
+        except Exception as exc:                       # noqa: BLE001
+            extra['optimize_component_sharded_error'] = repr(exc)
 
     if rank == 0:
-        du = d_used(tm)
         fwd_bytes = 8.0 * N * (du + D)
         inv_bytes = 8.0 * N * (2 * D)
         achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
