@@ -188,3 +188,113 @@ def test_conditional_inverse_and_partial_sweeps_on_loader_kernels(backend, name,
     Xs = (Xq - om.X_mean) / om.X_std
     for k in sorted({0, tm.D // 2, tm.D - 1}):
         assert relerr(tm.s(Xs, k), om.s(Xs, k)) < 1e-12
+
+
+def _synthetic_separable(D, band, hf_order, plain_order, n_irbf, family='hermite function', seed=0):
+    """Banded separable map: per component and conditioning column j in the band one plain term of order 1..plain_order
+    and Hermite-function terms of order 2..hf_order; monotone LET, n_irbf iRBF, RET (an RBF when n_irbf is odd)."""
+    mon, non = [], []
+    for k in range(D):
+        nm = [[]]
+        for j in range(max(0, k - band), k):
+            for o in range(1, plain_order + 1):
+                nm.append([j] * o)
+            for o in range(2, hf_order + 1):
+                nm.append([j] * o + ['HF'])
+        non.append(nm)
+        m = ['LET %d' % k] + ['iRBF %d' % k] * n_irbf + ['RET %d' % k]
+        if n_irbf % 2:
+            m.insert(1, 'RBF %d' % k)
+        mon.append(m)
+    return mon, non
+
+
+@pytest.mark.parametrize('D,band,hf_order,plain_order,n_irbf,expect', [
+    (6, 2, 3, 1, 2, (1, 2)),       # class (3,1), two group records  (the C5 shape)
+    (7, 4, 3, 1, 1, (1, 4)),       # class (3,1), four group records
+    (5, 2, 5, 3, 3, (2, 2)),       # class (5,5)
+    (6, 3, 7, 6, 2, (3, 4)),       # class (7,7), four group records
+    (5, 1, 4, 1, 0, (2, 2)),       # one group per component (padded records), LET + RET only
+])
+def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band, hf_order, plain_order, n_irbf, expect):
+    """Every degree class / record count of the hot-record kernels (k_forward_hl, k_inverse_hl), forced onto the
+    loader-wave path at small N, against the oracle: map, pullback density, table inverse, conditional inverse."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    rng = np.random.default_rng(100 * D + 10 * band + hf_order)
+    L = np.tril(rng.standard_normal((D, D)) * 0.4) + np.eye(D)
+    X = rng.standard_normal((1537, D)) @ L.T + 0.3 * rng.standard_normal((1537, D)) ** 2
+    mon, non = _synthetic_separable(D, band, hf_order, plain_order, n_irbf)
+    kw = dict(monotonicity='separable monotonicity')
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(D):
+        cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
+    assert tm._cm.u_enabled
+    assert (tm._cm.u_h_cls, tm._cm.u_h_ng) == expect
+    monkeypatch.setenv('TTM_U_LOADER', '1')
+    for ns in ('2', '4'):
+        monkeypatch.setenv('TTM_HL_NS', ns)
+        Z = tm.map(X)
+        assert relerr(Z, om.map(X)) < 1e-11
+        with np.errstate(all='ignore'):
+            pref = om.evaluate_pullback_density(X[:300])
+        pgot = tm.evaluate_pullback_density(X[:300])
+        ok = np.isfinite(pref)                       # (an RBF term can make dS/dx negative: log -> NaN on both sides)
+        assert np.array_equal(np.isfinite(pgot), ok) and relerr(pgot[ok], pref[ok]) < 1e-9
+        Zin = rng.standard_normal((700, D))
+        assert relerr(tm.inverse_map(Zin), om.inverse_map(Zin)) < 1e-9
+        E = D // 2
+        Zq = om.map(X[:200])
+        assert relerr(tm.inverse_map(Zq[:, E:], X_star=X[:200, :E]), om.inverse_map(Zq[:, E:], X_star=X[:200, :E])) < 1e-9
+    assert tm.uform_fit_error[:, 0].max() < 5e-14
+
+
+@pytest.mark.parametrize('case', ['dense', 'own_terms', 'skip_dims', 'other_family'])
+def test_generic_uform_kernels_against_the_oracle(backend, monkeypatch, case):
+    """U-form maps WITHOUT hot records (cache misses of dense maps, polynomial / Hermite-function terms in the
+    monotone list, skipped dimensions, another polynomial family): the generic U-form kernels (k_forward_u,
+    loader-wave k_forward_ul) and the direct inverse, against the oracle."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    rng = np.random.default_rng({'dense': 1, 'own_terms': 2, 'skip_dims': 3, 'other_family': 4}[case])
+    kw = dict(monotonicity='separable monotonicity')
+    if case == 'dense':
+        D, d = 6, 6
+        mon, non = specs.dense_separable_spec(D, 3)
+    elif case == 'own_terms':
+        D, d = 4, 4
+        mon, non = _synthetic_separable(D, 2, 3, 1, 1)
+        for k in range(D):
+            mon[k] = [[k]] + mon[k] + [[k, k, k, 'HF']]            # linear + a Hermite function of x_k in the monotone list
+    elif case == 'skip_dims':
+        D, d = 3, 4
+        mon, non = specs.entf_filter_spec(3)
+        kw.update(regularization='l2', regularization_lambda=0.05)
+    else:
+        D, d = 4, 4
+        mon, non = _synthetic_separable(D, 2, 1, 3, 2)              # plain polynomial terms only
+        kw.update(polynomial_type='legendre')
+    X = rng.standard_normal((1200, d)) @ (np.tril(rng.standard_normal((d, d)) * 0.3) + np.eye(d)).T
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(D):
+        cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
+    assert tm._cm.u_enabled and tm._cm.u_h_cls == 0
+    for loader in ('0', '1'):
+        monkeypatch.setenv('TTM_U_LOADER', loader)
+        assert relerr(tm.map(X), om.map(X)) < 1e-11
+        with np.errstate(all='ignore'):
+            pref = om.evaluate_pullback_density(X[:200])
+        pgot = tm.evaluate_pullback_density(X[:200])
+        ok = np.isfinite(pref)
+        assert np.array_equal(np.isfinite(pgot), ok) and relerr(pgot[ok], pref[ok]) < 1e-9
+    Zin = rng.standard_normal((500, D))
+    Xstar = X[:500, :d - D] if d > D else None
+    assert relerr(tm.inverse_map(Zin, X_star=Xstar), om.inverse_map(Zin, X_star=Xstar)) < 1e-9
