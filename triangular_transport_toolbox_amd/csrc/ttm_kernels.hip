@@ -714,6 +714,9 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 #ifndef TTM_UL_CW
 #define TTM_UL_CW 4           // evaluating waves per workgroup
 #endif
+#ifndef TTM_FWD_ETAB          // tuning knob: which forward hot kernels take exp(-x^2/4) from the 2^(j/32) table
+#define TTM_FWD_ETAB(NS) false
+#endif
 #define TTM_UL_THREADS ((TTM_UL_CW + 2) * 64)
 #ifdef TTM_HL_WAVES          // tuning knob: register-allocate the hot kernels for this many waves per SIMD
 #define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS, TTM_HL_WAVES)
@@ -725,12 +728,16 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 // xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
 // xlead + 1 and tlead + 1 slots.  xlead <= 4 and tlead <= 2 (the vmcnt immediates).
 
+#ifdef TTM_EXPERIMENT_NO_BARRIER   // timing experiment only (results are wrong): what do the per-step barriers cost?
+#define TTM_RAW_BARRIER() asm volatile("" ::: "memory")
+#else
 #define TTM_RAW_BARRIER()                       \
     do {                                        \
         asm volatile("" ::: "memory");          \
         __builtin_amdgcn_s_barrier();           \
         asm volatile("" ::: "memory");          \
     } while (0)
+#endif
 
 __device__ __forceinline__ void ul_wait_vmcnt(int n) {      // all but the n youngest vector-memory operations are done
     switch (n) {
@@ -996,7 +1003,12 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
     CacheStore<R> cst;
     cst.base = cache + tid;
     cst.stride = TTM_UL_CT;
-    (void)ways;
+    if (TTM_FWD_ETAB(NS)) {                                              // 2^(j/32) table behind the column cache
+        double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;
+        if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
+        cst.etab = etab;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (barrier A(0) follows)
+    }
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
     bool act0[NP], act1[NP];
 #pragma unroll
@@ -1038,7 +1050,7 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
         xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
         ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
         R Sv, dS;
-        h_component<NG, DB, DA, GS, WANT_LD>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
+        h_component<NG, DB, DA, GS, WANT_LD, TTM_FWD_ETAB(NS)>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
         if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
         if (Z) {
 #pragma unroll

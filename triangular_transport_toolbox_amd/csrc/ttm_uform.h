@@ -416,7 +416,7 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
 // loads of the step are at fixed offsets from `rec`.  A component that uses all NG records, has a spline and
 // stores exp(-x_k^2/4) - every component of a banded map but the first and last few - runs as ONE basic block, so
 // the scheduler can overlap the cache / table reads with the exp and Horner chains; the others take the guarded path.
-template <int NG, int DB, int DA, int GS, bool DER, class R>
+template <int NG, int DB, int DA, int GS, bool DER, bool ETAB = false, class R>
 TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheStore<R>& st, bool want_value, R& S, R& dS) {
     cint_p ri = (cint_p)rec;
     const int put2 = ri[0], flg = ri[1], nI = ri[2], n_grp = ri[13];
@@ -430,7 +430,7 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
         }
         R m, dm;
         u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
-        const R ek = fast_exp(-0.25 * (xk * xk));
+        const R ek = (ETAB ? exp_q_tab(st.etab, xk) : fast_exp(-0.25 * (xk * xk)));
         R s(rec[2]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -462,7 +462,7 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
         }
     }
     R ek(0.0);
-    if (flg & 1) ek = fast_exp(-0.25 * (xk * xk));
+    if (flg & 1) ek = (ETAB ? exp_q_tab(st.etab, xk) : fast_exp(-0.25 * (xk * xk)));
     R m(0.0), dm(0.0);
     if (nI > 0) u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
     S = s + m;
