@@ -274,20 +274,49 @@ TTM_HD void rect_all(int mode, double delta, const R& g, R& r, R& dr, R& logr) {
 // components, the inverse kernels read back columns they have just written.
 // ---------------------------------------------------------------------------
 
-template <class R>
-struct CacheStore {          // 8 values per sample: x of four columns, then their exp(-x^2/4)
+// PAIRED = false: value i of sample e at base[(i L + e) stride] (base = cache + tid): consecutive lanes read
+// consecutive doubles.  PAIRED = true (hot kernels): the two values of a slot (x_j, exp(-x_j^2/4)) are adjacent,
+// slot s of sample e at base[(s L + e) 2 stride] (base = cache + 2 tid): get2 / set2 move both with ONE 16-byte
+// LDS access (ds_read_b128: 256 B/clk, against 128 B/clk for the ds_read2st64_b64 the compiler makes of two gets).
+template <class R, bool PAIRED = false>
+struct CacheStore {          // 8 values per sample: x of four columns and their exp(-x^2/4)
     double* base;            // this thread's column
     int stride;              // doubles between consecutive slots of one element
     const double* etab = nullptr;    // 2^(j/32) table for exp_q_tab (hot kernels only)
+    static constexpr int L = lanes_of<R>::value;
+    TTM_HD double* at(int i, int e) const {
+        return PAIRED ? base + ((i >> 1) * L + e) * (2 * stride) + (i & 1) : base + (i * L + e) * stride;
+    }
     TTM_HD R get(int i) const {
         R r;
 #pragma unroll
-        for (int e = 0; e < lanes_of<R>::value; ++e) set_elem(r, e, base[(i * lanes_of<R>::value + e) * stride]);
+        for (int e = 0; e < L; ++e) set_elem(r, e, *at(i, e));
         return r;
     }
     TTM_HD void set(int i, const R& v) const {
 #pragma unroll
-        for (int e = 0; e < lanes_of<R>::value; ++e) base[(i * lanes_of<R>::value + e) * stride] = elem(v, e);
+        for (int e = 0; e < L; ++e) *at(i, e) = elem(v, e);
+    }
+    // both values of the slot whose first value has the (even) index i2
+    TTM_HD void get2(int i2, R& x, R& ev) const {
+        if (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < L; ++e) {
+                double a, b;
+                load_pair(at(i2, e), a, b);
+                set_elem(x, e, a); set_elem(ev, e, b);
+            }
+        } else {
+            x = get(i2); ev = get(i2 + 1);
+        }
+    }
+    TTM_HD void set2(int i2, const R& x, const R& ev) const {
+        if (PAIRED) {
+#pragma unroll
+            for (int e = 0; e < L; ++e) store_pair(at(i2, e), elem(x, e), elem(ev, e));
+        } else {
+            set(i2, x); set(i2 + 1, ev);
+        }
     }
 };
 
@@ -684,11 +713,11 @@ struct TaggedFetch {
 
 // statically planned cache (termtable.py:_plan_column_cache): the flag word of the group record says where
 // the column lives, no tag compares.  Way w keeps its column in slot 2w and exp(-x^2/4) in slot 2w+1.
-template <class XA, class R>
+template <class XA, class R, class ST = CacheStore<R>>
 struct PlanCache {
     const XA& xa;
-    CacheStore<R> st;
-    TTM_HD PlanCache(const XA& x, const CacheStore<R>& store) : xa(x), st(store) {}
+    ST st;
+    TTM_HD PlanCache(const XA& x, const ST& store) : xa(x), st(store) {}
     // contents on entry to a component (state words: column | TTM_PLAN_E, -1 = empty)
     TTM_HD void warm(cint_p state) {
         for (int w = 0; w < TTM_PLAN_WAYS; ++w) {

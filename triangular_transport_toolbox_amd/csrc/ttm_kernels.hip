@@ -718,13 +718,34 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 #define TTM_FWD_ETAB(NS) false
 #endif
 #define TTM_UL_THREADS ((TTM_UL_CW + 2) * 64)
-#ifdef TTM_HL_WAVES          // tuning knob: register-allocate the hot kernels for this many waves per SIMD
+#if defined(TTM_HL_MAXWAVES)  // tuning knob: tell the scheduler that no more than this many waves per SIMD will be resident
+#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS) __attribute__((amdgpu_waves_per_eu(1, TTM_HL_MAXWAVES)))
+#elif defined(TTM_HL_WAVES)   // tuning knob: register-allocate the hot kernels for this many waves per SIMD
 #define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS, TTM_HL_WAVES)
 #else
 #define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS)
 #endif
 #define TTM_UL_CT (TTM_UL_CW * 64)             // evaluating threads
 #define TTM_UL_ROWS (TTM_UL_CW * 128)          // rows per tile (evaluating waves x 64 lanes x 2 samples)
+// Evaluating waves per workgroup of the hot FORWARD kernel: two for the plain map (four workgroups per CU instead of
+// two: the waves of a workgroup move in lock step from barrier to barrier and want the same unit at the same time -
+// more, smaller workgroups interleave better: 0.172 -> 0.162 ms at C5), four with the fused log-determinant (more
+// arithmetic per step; the per-step table is then shared by twice the rows).  The inverse stays at TTM_UL_CW (its
+// 12 KB table per step wants the larger tile).
+#ifndef TTM_HL_CW_PLAIN
+#define TTM_HL_CW_PLAIN 2
+#endif
+#ifndef TTM_HL_CW_LD
+#define TTM_HL_CW_LD 4
+#endif
+#define TTM_HL_FWD_CW(WANT_LD) ((WANT_LD) ? TTM_HL_CW_LD : TTM_HL_CW_PLAIN)
+#if defined(TTM_HL_MAXWAVES)
+#define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64) __attribute__((amdgpu_waves_per_eu(1, TTM_HL_MAXWAVES)))
+#elif defined(TTM_HL_WAVES)
+#define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64, TTM_HL_WAVES)
+#else
+#define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64)
+#endif
 // xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
 // xlead + 1 and tlead + 1 slots.  xlead <= 4 and tlead <= 2 (the vmcnt immediates).
 
@@ -963,14 +984,15 @@ __global__ __launch_bounds__(TTM_UL_THREADS) void k_forward_ul(const int* __rest
 // per step (all scalar loads at known offsets, issued together) and run straight-line code: NG group records of
 // degree class CLS, every column from the planned cache.  Same loader waves, rings and barrier protocol.
 template <bool WANT_LD, int NG, int CLS, int NS>
-__global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+__global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
                                                     int D, int k0, int k1,
                                                     const double* __restrict__ X, int64_t ldx, int64_t N,
                                                     double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
                                                     const double* __restrict__ sigma, double* __restrict__ sumsq,
                                                     int tab_slot, int xlead, int tlead, int ways) {
     typedef VecD<NS> R;
-    constexpr int ROWS = TTM_UL_CT * NS;         // rows per tile: NS / 2 blocks of 2 x TTM_UL_CT rows, thread t owns the
+    constexpr int CW = TTM_HL_FWD_CW(WANT_LD), CT = CW * 64;             // evaluating waves / threads
+    constexpr int ROWS = CT * NS;         // rows per tile: NS / 2 blocks of 2 x CT rows, thread t owns the
     constexpr int NP = NS / 2;                   // adjacent pair (2t, 2t+1) of every block
     const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
@@ -986,12 +1008,18 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
     double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
-    if (wv == TTM_UL_CW) {
+#ifdef TTM_EXPERIMENT_EVAL_ONLY        // timing experiments only (results are wrong; both need TTM_EXPERIMENT_NO_BARRIER)
+    if (wv >= CW) return;
+#endif
+#ifdef TTM_EXPERIMENT_LOADERS_ONLY
+    if (wv < CW) return;
+#endif
+    if (wv == CW) {
         ul_column_loader<ROWS>([&](int kk) { return X + (int64_t)((cint_p)(H + (int64_t)kk * HS))[3] * ldx; }, k0, k1, S, N, ring,
                                XSLOTS, xlead, lane);
         return;
     }
-    if (wv == TTM_UL_CW + 1) {
+    if (wv == CW + 1) {
         ul_table_loader([&](int kk, double* slot) {
             cint_p ri = (cint_p)(H + (int64_t)kk * HS);
             return ul_dma_block((const char*)(U_ + ri[12]), ri[2] * (TTM_U_TSTRIDE * 8), slot, lane);
@@ -1000,11 +1028,12 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
-    CacheStore<R> cst;
-    cst.base = cache + tid;
-    cst.stride = TTM_UL_CT;
+    typedef CacheStore<R, true> Store;                                   // (x_j, exp(-x_j^2/4)) adjacent: 16-byte accesses
+    Store cst;
+    cst.base = cache + 2 * tid;
+    cst.stride = CT;
     if (TTM_FWD_ETAB(NS)) {                                              // 2^(j/32) table behind the column cache
-        double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;
+        double* etab = cache + (size_t)2 * ways * NS * CT;
         if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
         cst.etab = etab;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (barrier A(0) follows)
@@ -1023,7 +1052,7 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
         if (k == k0) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                const int64_t n = ctile * ROWS + q * (2 * CT) + 2 * tid;
                 act0[q] = n < N; act1[q] = n + 1 < N;
             }
             ld = R(0.0); ss = R(0.0);
@@ -1032,18 +1061,18 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
                 cx.X = (const char*)X; cx.ldb = ldx * 8;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                    const int64_t n = ctile * ROWS + q * (2 * CT) + 2 * tid;
                     cx.off[2 * q] = (unsigned int)(act0[q] ? n : N - 1) * 8u;
                     cx.off[2 * q + 1] = (unsigned int)(act1[q] ? n + 1 : N - 1) * 8u;
                 }
-                PlanCache<XOffN<NS>, R> x(cx, cst);
+                PlanCache<XOffN<NS>, R, Store> x(cx, cst);
                 x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
             }
         }
         R xk;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const D2 xp = *(const D2*)(ring + (size_t)xs * ROWS + q * (2 * TTM_UL_CT) + 2 * tid);
+            const D2 xp = *(const D2*)(ring + (size_t)xs * ROWS + q * (2 * CT) + 2 * tid);
             xk.v[2 * q] = xp.x; xk.v[2 * q + 1] = xp.y;
         }
         const double* tab = tabs + (size_t)ts * tab_slot;
@@ -1055,7 +1084,7 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
         if (Z) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                double* zc = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                double* zc = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + q * (2 * CT) + 2 * tid;
                 if (act1[q]) { D2 o = {Sv.v[2 * q], Sv.v[2 * q + 1]}; *(D2*)zc = o; }
                 else if (act0[q]) *zc = Sv.v[2 * q];
             }
@@ -1064,7 +1093,7 @@ __global__ TTM_HL_BOUNDS void k_forward_hl(const int* __restrict__ ucomp_, const
         if (k + 1 == k1) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
+                const int64_t n = ctile * ROWS + q * (2 * CT) + 2 * tid;
                 if (WANT_LD) {
                     if (act1[q]) { D2 o = {ld.v[2 * q], ld.v[2 * q + 1]}; *(D2*)(logdet + n) = o; }
                     else if (act0[q]) logdet[n] = ld.v[2 * q];
@@ -1136,7 +1165,10 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
     }
 
     // ---- evaluating waves -------------------------------------------------------------------------------------------
-    CacheStore<R> cst;
+    // (the paired 16-byte layout of the forward kernel is slower here, 0.265 against 0.253 ms at C5: every step
+    // ends with a put, and ds_write_b128 costs more than the two ds_write_b64 it replaces)
+    typedef CacheStore<R, false> Store;
+    Store cst;
     cst.base = cache + tid;
     cst.stride = TTM_UL_CT;
     if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];
@@ -1169,7 +1201,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
                     cx.off[2 * q] = (unsigned int)(act0[q] ? n : N - 1) * 8u;
                     cx.off[2 * q + 1] = (unsigned int)(act1[q] ? n + 1 : N - 1) * 8u;
                 }
-                PlanCache<XOffN<NS>, R> x(cx, cst);
+                PlanCache<XOffN<NS>, R, Store> x(cx, cst);
                 x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
             }
         }
@@ -1188,7 +1220,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         // last-bit difference between this reciprocal and the division of the index kernel does not matter
         const double scale = (double)nb * fast_rcp(hi - lo);
         const bool use_bkt = scale > 0.0 && scale < 1.0e300;
-        const R off = h_offset<NG, DB, DA, GS, R>(rec, cst);
+        const R off = h_offset<NG, DB, DA, GS, R, Store>(rec, cst);
         double tg[NS];
         int a[NS];
 #pragma unroll
@@ -1201,17 +1233,31 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
             tg[e] = target;
             int q = (int)((target - lo) * scale) - 1;
             q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
+#ifdef TTM_INV_ALIGNED_SCAN
+            a[e] = (use_bkt ? bkl[q] : 0) & ~1;      // even start: the scan reads 16-byte aligned pairs (entries before
+                                                     // a bucket start are < target, so the count is unchanged)
+#else
             a[e] = use_bkt ? bkl[q] : 0;
+#endif
         }
         // np.searchsorted(xs, target) (left) = a + #{entries from a on that are < target}: both samples scan four
-        // entries per round together (a finished sample re-counts 0); the table is followed by +inf sentinels
+        // entries per round together (a finished sample re-reads its last group); the table is followed by +inf sentinels
+        int pos[NS];
         for (int round = 0; round < 4096; ++round) {
             int cmax = 0;
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
+#ifdef TTM_INV_ALIGNED_SCAN
+                double q0, q1, q2, q3;
+                load_pair(xsl + a[e], q0, q1);
+                load_pair(xsl + a[e] + 2, q2, q3);
+#else
                 const double* q4 = xsl + a[e];
-                const int c = (q4[0] < tg[e] ? 1 : 0) + (q4[1] < tg[e] ? 1 : 0) + (q4[2] < tg[e] ? 1 : 0) + (q4[3] < tg[e] ? 1 : 0);
-                a[e] += c;
+                const double q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
+#endif
+                const int c = (q0 < tg[e] ? 1 : 0) + (q1 < tg[e] ? 1 : 0) + (q2 < tg[e] ? 1 : 0) + (q3 < tg[e] ? 1 : 0);
+                pos[e] = a[e] + c;
+                a[e] += c & 4;                                           // (a finished sample stays where it is)
                 cmax = c > cmax ? c : cmax;
             }
             if (cmax < 4) break;
@@ -1219,7 +1265,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         R r;
 #pragma unroll
         for (int e = 0; e < NS; ++e) {
-            const int i = a[e] < 1 ? 1 : (a[e] > T - 1 ? T - 1 : a[e]);
+            const int i = pos[e] < 1 ? 1 : (pos[e] > T - 1 ? T - 1 : pos[e]);
             const double x_lo = xsl[i - 1], x_hi = xsl[i];
             const double y_lo = (double)(i - 1) * ystep + y0;
             const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
@@ -1883,15 +1929,18 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
             xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
             tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
-            // samples per evaluating thread of the hot kernels: four for the plain map (1024-row tiles, two workgroups
-            // per CU by LDS, ~100 VGPRs are then free: insensitive to the register allocation, which for the
-            // two-sample variant swings between 51 and 86 VGPRs with unrelated source changes and decides whether a
-            // third workgroup fits), two with the fused log-determinant (147 VGPRs with four)
-            int hNS = logdet ? 2 : 4;
+            // samples per evaluating thread of the hot kernels: four (a wave issues at most one fp64 instruction every
+            // ~8 cycles and a dependent one only after ~30, tools/micro/fp64_peak.hip: the Horner chains of four
+            // samples interleave to that rate; with two the chains wait on themselves)
+            int hNS = 4;
             if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
             const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT");
-            const int rows = hot ? TTM_UL_CT * hNS : TTM_UL_ROWS;
-            const size_t lds_ul = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * (rows / TTM_UL_CT) * TTM_UL_CT + TTM_EXPQ_TABLE_LEN) * 8;
+            const int hcw = TTM_HL_FWD_CW(logdet != nullptr);            // evaluating waves per workgroup of the hot kernel
+            const int rows = hot ? hcw * 64 * hNS : TTM_UL_ROWS;
+            auto lds_for = [&](int xl) { return ((size_t)(xl + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * rows + TTM_EXPQ_TABLE_LEN) * 8; };
+            if (hot && xlead == 3 && !getenv("TTM_U_XLEAD") && (size_t)(160 * 1024) / lds_for(2) > (size_t)(160 * 1024) / lds_for(3))
+                xlead = 2;                                               // a shallower column ring when it buys a workgroup per CU
+            const size_t lds_ul = lds_for(xlead);
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
@@ -1912,13 +1961,13 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 }
 #undef TTM_HK
                 int wgs = (int)((size_t)(160 * 1024) / lds_ul);
-                if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
+                if (wgs > 32 / (hcw + 2)) wgs = 32 / (hcw + 2);
                 if (wgs < 1) wgs = 1;
                 if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
                 const int64_t tiles = (N + rows - 1) / rows;
                 const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
                 allow_big_lds((const void*)hk, lds_ul);
-                hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds_ul, (hipStream_t)stream, p->ucomp,
+                hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3((hcw + 2) * 64), lds_ul, (hipStream_t)stream, p->ucomp,
                                    fold + fold_base_size(p), (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz,
                                    logdet, sigma, sumsq, tab_slot, xlead, tlead, ways);
                 return check_launch("k_forward_hl");

@@ -363,8 +363,11 @@ TTM_HD void u_spline(const double* tab, int nI, double sp_a, double sp_b, double
     R p, dp(0.0);
 #pragma unroll
     for (int e = 0; e < lanes_of<R>::value; ++e) {
-        const double* c = tab + (ielem(col, e) + 1) * TTM_U_TSTRIDE;
+        const double* cp = tab + (ielem(col, e) + 1) * TTM_U_TSTRIDE;       // 16-byte aligned (even stride, even offsets)
         const double se = elem(s, e);
+        double c[TTM_U_DEG + 1];
+#pragma unroll
+        for (int j = 0; j <= TTM_U_DEG; j += 2) load_pair(cp + j, c[j], c[j + 1]);
         double a = c[TTM_U_DEG], da = 0.0;
 #pragma unroll
         for (int j = TTM_U_DEG - 1; j >= 0; --j) {
@@ -377,6 +380,61 @@ TTM_HD void u_spline(const double* tab, int nI, double sp_a, double sp_b, double
     g = p;
     dg = DER ? dp * sp_ds : dp;
 }
+
+// The same spline in phases, for the straight-line hot path: index arithmetic for all samples of the thread
+// (u_spline_index), the gather of the 12 coefficients of samples [E0, E0 + H) (u_spline_gather: issued together, so
+// that their LDS latencies overlap each other and whatever is scheduled behind them) ...
+template <class R>
+struct SplineIdx {
+    R s;                                         // local coordinates
+    typename int_of<R>::type col;                // spline columns
+};
+template <class R>
+TTM_HD void u_spline_index(int nI, double sp_a, double sp_b, const R& t, SplineIdx<R>& ix) {
+    const R u = vfma(t, sp_b, sp_a);
+    const R fl = vfloor(vmin(vmax(u, -1.0), (double)(nI - 2)));
+    ix.s = vfma(2.0, u - fl, -1.0);
+    ix.col = vtoint(fl);
+}
+template <int H>
+struct SplineRegs { double c[H][TTM_U_DEG + 1]; };
+template <int E0, int H, class R>
+TTM_HD void u_spline_gather(const double* tab, const SplineIdx<R>& ix, SplineRegs<H>& q) {
+#pragma unroll
+    for (int e = 0; e < H; ++e) {
+        const double* cp = tab + (ielem(ix.col, E0 + e) + 1) * TTM_U_TSTRIDE;
+#pragma unroll
+        for (int j = 0; j <= TTM_U_DEG; j += 2) load_pair(cp + j, q.c[e][j], q.c[e][j + 1]);
+    }
+}
+// ... and their Horner passes, interleaved over the samples (same operations per sample as u_spline: bitwise equal);
+// writes elements [E0, E0 + H) of g / dg (dg still to be scaled by the caller: d/dt = sp_ds d/ds)
+template <int E0, int H, bool DER, class R>
+TTM_HD void u_spline_eval(const SplineIdx<R>& ix, const SplineRegs<H>& q, R& g, R& dg) {
+    double a[H], da[H];
+#pragma unroll
+    for (int e = 0; e < H; ++e) { a[e] = q.c[e][TTM_U_DEG]; da[e] = 0.0; }
+#pragma unroll
+    for (int j = TTM_U_DEG - 1; j >= 0; --j) {
+#pragma unroll
+        for (int e = 0; e < H; ++e) {
+            const double se = elem(ix.s, E0 + e);
+            if (DER) da[e] = fma(da[e], se, a[e]);
+            a[e] = fma(a[e], se, q.c[e][j]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < H; ++e) { set_elem(g, E0 + e, a[e]); set_elem(dg, E0 + e, da[e]); }
+}
+
+// Scheduling fences between the phases (tuning knob, off): with them a lone workgroup evaluates 13 % faster (every
+// LDS latency is behind arithmetic), but next to the loader waves and the per-step barrier the kernel is slower
+// (0.22 against 0.17 ms at C5) - the waves of a workgroup then all want the LDS, then all the VALU, at the same time.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TTM_HL_PHASES)
+#define TTM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)      // nothing is scheduled across this point
+#else
+#define TTM_SCHED_FENCE() ((void)0)
+#endif
 
 // S_k and dS_k/dx_k of one component in U-form; afterwards x_k (and exp(-x_k^2/4) when a later group reads it)
 // goes into its planned cache slot.  x: a PlanCache.
@@ -416,21 +474,38 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
 // loads of the step are at fixed offsets from `rec`.  A component that uses all NG records, has a spline and
 // stores exp(-x_k^2/4) - every component of a banded map but the first and last few - runs as ONE basic block, so
 // the scheduler can overlap the cache / table reads with the exp and Horner chains; the others take the guarded path.
-template <int NG, int DB, int DA, int GS, bool DER, bool ETAB = false, class R>
-TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheStore<R>& st, bool want_value, R& S, R& dS) {
+template <int NG, int DB, int DA, int GS, bool DER, bool ETAB = false, class R, class ST>
+TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const ST& st, bool want_value, R& S, R& dS) {
     cint_p ri = (cint_p)rec;
     const int put2 = ri[0], flg = ri[1], nI = ri[2], n_grp = ri[13];
     if (n_grp == NG && nI > 0 && (flg & 1) && put2 >= 0 && want_value) {
+        // phase 1: cache pairs and the spline coefficients of the first half of the samples in flight together
+        constexpr int L = lanes_of<R>::value, H = L > 1 ? L / 2 : 1;
         R xv[NG], ev[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int slot2 = ((cint_p)(rec + TTM_H_HDR + g * GS))[0];
-            xv[g] = st.get(slot2);
-            ev[g] = st.get(slot2 + 1);
+            st.get2(slot2, xv[g], ev[g]);
         }
-        R m, dm;
-        u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
+        SplineIdx<R> ix;
+        u_spline_index(nI, rec[3], rec[4], xk, ix);
+        SplineRegs<H> q;
+        u_spline_gather<0, H>(tab, ix, q);
+        TTM_SCHED_FENCE();
+        // phase 2: arithmetic that needs none of them (the exp of the column cache) behind their latency
+#ifdef TTM_EXPERIMENT_NO_EXP
+        const R ek = xk * rec[3];
+#else
         const R ek = (ETAB ? exp_q_tab(st.etab, xk) : fast_exp(-0.25 * (xk * xk)));
+#endif
+        TTM_SCHED_FENCE();
+        // phase 3: spline of the first half; then the second half's gather behind the groups
+        R m, dm(0.0);
+        u_spline_eval<0, H, DER>(ix, q, m, dm);
+        if (L > 1) {
+            TTM_SCHED_FENCE();
+            u_spline_gather<(L > 1 ? H : 0), H>(tab, ix, q);
+        }
         R s(rec[2]);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -440,10 +515,14 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
             u_horner_fixed<DA, false>(gr + 2 + DB, xv[g], a, dv);
             s = vfma(ev[g], b, s) + a;
         }
+        if (L > 1) {
+            TTM_SCHED_FENCE();
+            u_spline_eval<(L > 1 ? H : 0), H, DER>(ix, q, m, dm);
+        }
+        if (DER) dm = dm * rec[5];
         S = s + m;
         dS = dm;
-        st.set(put2, xk);
-        st.set(put2 + 1, ek);
+        st.set2(put2, xk, ek);
         return;
     }
     R s(rec[2]);
@@ -453,7 +532,8 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
             if (g < n_grp) {
                 cdbl_p gr = rec + TTM_H_HDR + g * GS;
                 const int slot2 = ((cint_p)gr)[0];
-                const R xv = st.get(slot2), ev = st.get(slot2 + 1);
+                R xv, ev;
+                st.get2(slot2, xv, ev);
                 R b, a, dv;
                 u_horner_fixed<DB, false>(gr + 1, xv, b, dv);
                 u_horner_fixed<DA, false>(gr + 2 + DB, xv, a, dv);
@@ -468,15 +548,15 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const CacheS
     S = s + m;
     dS = dm;
     if (put2 >= 0) {
-        st.set(put2, xk);
-        if (flg & 1) st.set(put2 + 1, ek);
+        if (flg & 1) st.set2(put2, xk, ek);
+        else st.set(put2, xk);
     }
 }
 
 // nonmonotone part of a component from its hot record (what the inverse subtracts from z_k): same two paths as
 // h_component
-template <int NG, int DB, int DA, int GS, class R>
-TTM_HD R h_offset(cdbl_p rec, const CacheStore<R>& st) {
+template <int NG, int DB, int DA, int GS, class R, class ST>
+TTM_HD R h_offset(cdbl_p rec, const ST& st) {
     const int n_grp = ((cint_p)rec)[13];
     R s(rec[7]);
     if (n_grp == NG) {
@@ -484,8 +564,7 @@ TTM_HD R h_offset(cdbl_p rec, const CacheStore<R>& st) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int slot2 = ((cint_p)(rec + TTM_H_HDR + g * GS))[0];
-            xv[g] = st.get(slot2);
-            ev[g] = st.get(slot2 + 1);
+            st.get2(slot2, xv[g], ev[g]);
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -502,7 +581,8 @@ TTM_HD R h_offset(cdbl_p rec, const CacheStore<R>& st) {
         if (g < n_grp) {
             cdbl_p gr = rec + TTM_H_HDR + g * GS;
             const int slot2 = ((cint_p)gr)[0];
-            const R xv = st.get(slot2), ev = st.get(slot2 + 1);
+            R xv, ev;
+            st.get2(slot2, xv, ev);
             R b, a, dv;
             u_horner_fixed<DB, false>(gr + 1, xv, b, dv);
             u_horner_fixed<DA, false>(gr + 2 + DB, xv, a, dv);
@@ -513,12 +593,12 @@ TTM_HD R h_offset(cdbl_p rec, const CacheStore<R>& st) {
 }
 
 // put of a solved x_k (and exp(-x_k^2/4) when a later group reads it) into its planned cache slot
-template <class R>
-TTM_HD void h_put(cdbl_p rec, const CacheStore<R>& st, const R& xk) {
+template <class R, class ST>
+TTM_HD void h_put(cdbl_p rec, const ST& st, const R& xk) {
     const int put2 = ((cint_p)rec)[0], flg = ((cint_p)rec)[1];
     if (put2 >= 0) {
-        st.set(put2, xk);
-        if (flg & 1) st.set(put2 + 1, TTM_HL_EXP(st, xk));
+        if (flg & 1) st.set2(put2, xk, TTM_HL_EXP(st, xk));
+        else st.set(put2, xk);
     }
 }
 

@@ -41,6 +41,23 @@ struct VecI {
 template <class R> struct lanes_of { static constexpr int value = 1; };
 template <int N> struct lanes_of<VecD<N>> { static constexpr int value = N; };
 
+// 16-byte aligned pair of doubles moved as ONE access (device: ds_read_b128 / global_load_dwordx4 - the compiler
+// otherwise emits ds_read2_b64, which the LDS serves at half the rate and banks modulo 32); host: two plain loads
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double ttm_pair_t __attribute__((ext_vector_type(2)));
+TTM_HD void load_pair(const double* p, double& a, double& b) {
+    const ttm_pair_t q = *(const ttm_pair_t*)p;
+    a = q.x; b = q.y;
+}
+TTM_HD void store_pair(double* p, double a, double b) {
+    ttm_pair_t q = {a, b};
+    *(ttm_pair_t*)p = q;
+}
+#else
+TTM_HD void load_pair(const double* p, double& a, double& b) { a = p[0]; b = p[1]; }
+TTM_HD void store_pair(double* p, double a, double b) { p[0] = a; p[1] = b; }
+#endif
+
 // element access that also works for plain double
 TTM_HD double elem(double a, int) { return a; }
 template <int N> TTM_HD double elem(const VecD<N>& a, int i) { return a.v[i]; }
