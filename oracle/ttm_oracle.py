@@ -167,7 +167,8 @@ class OracleMap:
                  standardization='standard', ST_scale_factor=1.0, ST_scale_mode='dynamic',
                  coeffs_init=0., alternate_root_finding=True, root_search_truncation=True,
                  regularization=None, regularization_lambda=0.1, quadrature_input=None,
-                 rectifier_type='exponential', delta=1e-8, verbose=False, **ignored):
+                 rectifier_type='exponential', delta=1e-8, verbose=False, linearization=None,
+                 linearization_specified_as_quantiles=True, linearization_increment=1e-6, **ignored):
         self.monotone = copy.deepcopy(monotone)
         self.nonmonotone = copy.deepcopy(nonmonotone)
         self.rect = Rectifier(rectifier_type, delta)
@@ -187,6 +188,13 @@ class OracleMap:
         self.monotonicity = monotonicity
         if monotonicity.lower() not in ('integrated rectifier', 'separable monotonicity'):
             raise ValueError('monotonicity')
+        self.linearization = linearization                                       # TM:254-257
+        self.linearization_specified_as_quantiles = linearization_specified_as_quantiles
+        self.linearization_increment = linearization_increment
+        if linearization is not None and monotonicity.lower() == 'separable monotonicity':
+            # TM:2063-2080: the derivative functions of a separable map overwrite their input with min(x, lower
+            # threshold) in every column (inverted masks) - not restated
+            raise NotImplementedError('linearization with separable monotonicity (reference defect TM:2063-2080)')
         if polynomial_type.lower() not in _FAMILIES:
             raise Exception('Polynomial type not understood.')
         self.hf_allowed = polynomial_type.lower().startswith('hermite f') or polynomial_type.lower() == 'hermite_function'
@@ -280,17 +288,26 @@ class OracleMap:
         return dictionary
 
     def determine_special_term_locations(self):
-        """TM:2219-2389 (without linearisation thresholds)."""
+        """TM:2219-2389, linearisation thresholds TM:2364-2389."""
         for kc in np.arange(self.D) + self.skip_dimensions:
             if 'cross-terms' in self.special_terms[kc]:
                 self.special_terms[kc]['cross-terms'] = self._place(self.special_terms[kc]['cross-terms'])
             self.special_terms[kc] = self._place(self.special_terms[kc])
+        if self.linearization is not None:
+            self.linearization_threshold = np.zeros((self.X.shape[-1], 2))
+            for k in range(self.X.shape[-1]):
+                if self.linearization_specified_as_quantiles:
+                    self.linearization_threshold[k, 0] = np.quantile(self.X[:, k], q=self.linearization)
+                    self.linearization_threshold[k, 1] = np.quantile(self.X[:, k], q=1 - self.linearization)
+                else:
+                    self.linearization_threshold[k, 0] = -self.linearization
+                    self.linearization_threshold[k, 1] = +self.linearization
 
     # ------------------------------------------------------------------ a2
     def _plan(self):
         """Resolve every list entry to a term plan; apply the special-term
         cross-grid re-ordering of TM:1446-1483.  A plan is a list of factors:
-          ('const',) | ('poly', var, order, hf) | ('st', kind, var, cross, index)."""
+          ('const',) | ('poly', var, order, hf, lin) | ('st', kind, var, cross, index)."""
         self.plan_mon, self.plan_nonmon, self.n_mon = [], [], []
         for k in range(self.D):
             kc = k + self.skip_dimensions
@@ -313,11 +330,14 @@ class OracleMap:
                         terms.append([('const',)])
                     else:
                         hf = any(e == 'HF' for e in entry)
-                        if any(e == 'LIN' for e in entry):
-                            raise NotImplementedError("'LIN' is outside the oracle's scope")
+                        lin = any(e == 'LIN' for e in entry)
+                        if lin and self.linearization is None:                    # TM:1053-1054
+                            raise Exception("'LIN' modifier specified in variable monotone, but the variable "
+                                            "linearization is defined as None. Please specify a scalar linearization "
+                                            "or remove the 'LIN' modifier.")
                         ints = [e for e in entry if type(e) != str]
                         ui, ct = np.unique(ints, return_counts=True)
-                        terms.append([('poly', int(u), int(c), hf) for u, c in zip(ui, ct)])
+                        terms.append([('poly', int(u), int(c), hf, lin) for u, c in zip(ui, ct)])
                 if which == 'mon' and 'cross-terms' in self.special_terms[kc]:
                     rbf = [terms[i] for i in st_idx]
                     dims = sorted(set(t[0][2] for t in rbf))
@@ -346,7 +366,7 @@ class OracleMap:
         if f[0] == 'const':
             return np.ones(x.shape[:-1]) if derivative_wrt is None else np.zeros(x.shape[:-1])
         if f[0] == 'poly':
-            _, var, order, hf = f
+            _, var, order, hf, lin = f
             c = [0.] * order + [1.]
             if hf:
                 c[-1] = self._hfconst(order)
@@ -355,6 +375,13 @@ class OracleMap:
                 val = self.polyfunc(c)(xv)
                 if hf:
                     val = val * np.exp(-xv ** 2 / 4)
+                if lin:
+                    # TM:1375-1385 as it executes: "__x__" has already been replaced by "x" when the clipped /
+                    # extended variables are substituted, so BOTH sides of the blend evaluate the factor at the
+                    # unclipped x: P(x) (1 - vec/inc) + P(x) vec/inc = P(x) up to rounding (noise ~ |vec|/inc eps)
+                    thr = self.linearization_threshold[var]
+                    vec = np.where(xv - thr[0] >= 0, 0.0, xv - thr[0]) + np.where(xv - thr[1] <= 0, 0.0, xv - thr[1])
+                    val = val * (1 - vec / self.linearization_increment) + val * vec / self.linearization_increment
                 return val
             cder = self.polyfunc_der(c)
             if not hf:

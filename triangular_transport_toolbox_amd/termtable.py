@@ -193,7 +193,7 @@ class CompiledMap:
         return self.dpar
 
 
-def _parse_entry(entry, kc, which, counter, polynomial_type):
+def _parse_entry(entry, kc, which, counter, polynomial_type, linearization=None):
     """One list entry -> list of factors.
     factor = ('poly', var, order, hf) | ('st', kind, var, cross, index)."""
     if isinstance(entry, str):
@@ -210,9 +210,10 @@ def _parse_entry(entry, kc, which, counter, polynomial_type):
     if len(entry) == 0:
         return []
     hf = any(e == 'HF' for e in entry)
-    if any(e == 'LIN' for e in entry):
-        raise NotImplementedError("the 'LIN' tail-linearisation modifier (TM:1513-1541) is not supported by the "
-                                  "MI355X engine yet")
+    if any(e == 'LIN' for e in entry) and linearization is None:            # TM:1053-1054
+        raise Exception("'LIN' modifier specified in variable monotone, but the variable linearization is defined as "
+                        "None. Please specify a scalar linearization or remove the 'LIN' modifier.")
+    # (a 'LIN' factor evaluates to the plain factor: transport_map._linearization_thresholds)
     ints = [e for e in entry if not isinstance(e, str)]
     ui, ct = np.unique(ints, return_counts=True)
     return [('poly', int(u), int(c), bool(hf)) for u, c in zip(ui, ct)]
@@ -326,7 +327,7 @@ def _plan_column_cache(plan_seq, fdesc, fints, ways=None):
 
 
 def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function',
-                monotonicity='integrated rectifier'):
+                monotonicity='integrated rectifier', linearization=None):
     """Compile the specification lists into device tables (special-term
     constants are filled in later by CompiledMap.fill_special_terms)."""
     if polynomial_type.lower() not in FAMILIES:
@@ -350,11 +351,11 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         kc = k + skip
         # ---- parse --------------------------------------------------------
         counter = {}
-        nm_terms = [_parse_entry(e, kc, 'nonmon', counter, polynomial_type) for e in nonmonotone[k]]
+        nm_terms = [_parse_entry(e, kc, 'nonmon', counter, polynomial_type, linearization) for e in nonmonotone[k]]
         counter = {}
         mon_terms, st_idx = [], []
         for i, e in enumerate(monotone[k]):
-            t = _parse_entry(e, kc, 'mon', counter, polynomial_type)
+            t = _parse_entry(e, kc, 'mon', counter, polynomial_type, linearization)
             mon_terms.append(t)
             if isinstance(e, str):
                 st_idx.append(i)

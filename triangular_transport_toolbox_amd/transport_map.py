@@ -18,8 +18,10 @@ What is deliberately different from the reference:
   term tables (``termtable.compile_map``);
 * ``workers`` is accepted and ignored (the process pool of TM:2789-2874 is
   replaced by the GPU; components / samples shard over ranks instead);
-* ``adaptation`` (TM:373-656, 4575-4950) and the ``'LIN'`` modifier are outside
-  the hot path and raise NotImplementedError;
+* ``adaptation`` (TM:373-656, 4575-4950) is outside the hot path and raises
+  NotImplementedError; ``linearization`` / ``'LIN'`` are supported for the
+  integrated rectifier (see ``_linearization_thresholds``), with separable
+  monotonicity they raise (reference defect TM:2063-2080);
 * reference defects that are only reachable through invalid specifications are
   rejected instead of replicated (see ``termtable.compile_map``).
 Reference quirks on valid inputs are reproduced: the
@@ -89,8 +91,11 @@ class transport_map():
 
         if adaptation:
             raise NotImplementedError('map adaptation (TM:373-656, 4575-4950) is outside the MI355X hot path')
-        if linearization is not None:
-            raise NotImplementedError("tail linearisation ('LIN', TM:1513-1541) is not supported yet")
+        if linearization is not None and monotonicity.lower() == 'separable monotonicity':
+            # TM:2063-2080: with a linearisation the reference's derivative functions (the only consumers in
+            # separable mode) overwrite their input with min(x, lower threshold) in every column (inverted masks)
+            raise NotImplementedError('linearization with separable monotonicity is a defect of the reference '
+                                      '(TM:2063-2080) and is not reproduced')
         if monotone is None or nonmonotone is None:
             raise ValueError("'monotone' and 'nonmonotone' must be specified (map adaptation is not supported)")
 
@@ -151,7 +156,7 @@ class transport_map():
 
         # ---- compile the specification into term tables -----------------------
         self._cm = termtable.compile_map(self.monotone, self.nonmonotone, X.shape[-1], self.polynomial_type,
-                                         self.monotonicity)
+                                         self.monotonicity, linearization=self.linearization)
         self.special_terms = termtable.count_special_terms(self.monotone, self.nonmonotone, self.skip_dimensions)
         self.coeffs_mon = [np.ones(int(n)) * self.coeffs_init for n in self._cm.n_mon]
         self.coeffs_nonmon = [np.ones(int(n)) * self.coeffs_init for n in self._cm.n_nm]
@@ -410,6 +415,7 @@ class transport_map():
 
     def determine_special_term_locations(self, k=None):
         """TM:2219-2389: centres = quantiles of the standardised training columns."""
+        self._linearization_thresholds()
         req = termtable.quantile_requests(self.special_terms)
         if len(req) == 0:
             return
@@ -425,6 +431,24 @@ class transport_map():
         self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
         self._u_rejected = False
         self._refresh_uform()
+
+    def _linearization_thresholds(self):
+        """TM:2364-2389: per column the quantiles (linearization, 1 - linearization) of the standardised training
+        samples, or +-linearization.  The 'LIN' modifier itself leaves the map unchanged: as the reference's
+        generated code executes (TM:1375-1385, "__x__" is already replaced when the clipped / extended variables are
+        substituted) both sides of its blend evaluate the factor at the unclipped x, P(x)(1 - v/inc) + P(x) v/inc,
+        i.e. P(x) up to rounding noise of relative size |v|/inc * 1e-16; the factor is evaluated once here."""
+        if self.linearization is None:
+            return
+        d = self._cm.d_cols
+        thr = np.zeros((d, 2))
+        for j in range(d):
+            if self.linearization_specified_as_quantiles:
+                thr[j, 0] = self._device_quantile(self._Xs[j, :self._N], [self.linearization])[0]
+                thr[j, 1] = self._device_quantile(self._Xs[j, :self._N], [1 - self.linearization])[0]
+            else:
+                thr[j, 0], thr[j, 1] = -self.linearization, +self.linearization
+        self.linearization_threshold = thr
 
     def reset(self, X):
         """TM:710-748: new samples, coefficients back to coeffs_init."""
