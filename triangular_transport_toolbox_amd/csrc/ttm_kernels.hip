@@ -1147,6 +1147,12 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
     const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
     double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;                   // 2^(j/32), behind the column cache
 
+#ifdef TTM_EXPERIMENT_EVAL_ONLY        // timing experiments only (results are wrong; both need TTM_EXPERIMENT_NO_BARRIER)
+    if (wv >= TTM_UL_CW) return;
+#endif
+#ifdef TTM_EXPERIMENT_LOADERS_ONLY
+    if (wv < TTM_UL_CW) return;
+#endif
     if (wv == TTM_UL_CW) {
         ul_column_loader<ROWS>([&](int kk) { return Z + (int64_t)(kk - k0) * ldz; }, k0, k1, S, N, ring, XSLOTS, xlead, lane);
         return;
