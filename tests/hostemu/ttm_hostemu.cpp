@@ -410,7 +410,7 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
 }
 
 // TEST ONLY: the elementary functions of csrc/ttm_math.h on arrays (which: 0 exp, 1 erf, 2 exp(-t^2) from the
-// erf table, 3 log, 4 reciprocal, 5 a/b with b = second array)
+// erf table, 3 log, 4 reciprocal, 5 a/b with b = second array, 6 / 7 exp(-x^2/4) by table / series)
 int emu_math(int which, const double* a, const double* b, int64_t n, double* out) {
     for (int64_t i = 0; i < n; ++i) {
         double e, g;
@@ -421,6 +421,7 @@ int emu_math(int which, const double* a, const double* b, int64_t n, double* out
             case 3: out[i] = fast_log(a[i]); break;
             case 4: out[i] = fast_rcp(a[i]); break;
             case 6: out[i] = exp_q_tab(kExpQTab, a[i]); break;
+            case 7: out[i] = exp_q_fast(a[i]); break;
             default: out[i] = fast_div(a[i], b[i]); break;
         }
     }

@@ -86,3 +86,19 @@ def test_exp_q_table():
     assert np.abs(got[sub][~ok]).max(initial=0.0) < 1e-299
     assert np.isnan(run(6, [np.nan]))[0]
     assert run(6, [np.inf])[0] == 0.0 and run(6, [-np.inf])[0] == 0.0 and run(6, [1e200])[0] == 0.0
+
+
+def test_exp_q_fast():
+    """exp(-x^2/4) of the forward hot kernels (degree-12 series): <= 2 ulp, NaN in -> NaN out, underflow to 0."""
+    rng = np.random.default_rng(4)
+    x = np.concatenate([rng.uniform(-12, 12, 100000), rng.standard_normal(100000), np.linspace(-60, 60, 4001),
+                        [0.0, -0.0, 1e-200, 54.0, -54.0]])
+    got = run(7, x)
+    mp.mp.dps = 30
+    sub = np.r_[0:3000, 100000:103000, 200000:204006]
+    ref = np.array([float(mp.exp(mp.mpf(float(-0.25 * (v * v))))) for v in x[sub]])
+    ok = ref > 1e-300
+    assert ulps(got[sub][ok], ref[ok]).max() <= 2.0
+    assert np.abs(got[sub][~ok]).max(initial=0.0) < 1e-299
+    assert np.isnan(run(7, [np.nan]))[0]
+    assert run(7, [1e100])[0] == 0.0 and run(7, [100.0])[0] == 0.0 and run(7, [-1e8])[0] == 0.0

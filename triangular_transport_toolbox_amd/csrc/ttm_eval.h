@@ -364,7 +364,7 @@ struct VarCache {
         if (get_h(s)) {
             e = st.get(4 + s);
         } else {
-            e = fast_exp(-0.25 * (x * x));
+            e = exp_q_fast(x);
             st.set(4 + s, e);
             set_h(s, 1);
         }
@@ -725,7 +725,7 @@ struct PlanCache {
             if (v >= 0) {
                 const R x = xa(v & ~TTM_PLAN_E);
                 st.set(2 * w, x);
-                if (v & TTM_PLAN_E) st.set(2 * w + 1, st.etab ? exp_q_tab(st.etab, x) : fast_exp(-0.25 * (x * x)));
+                if (v & TTM_PLAN_E) st.set(2 * w + 1, st.etab ? exp_q_tab(st.etab, x) : exp_q_fast(x));
             }
         }
     }
@@ -742,7 +742,7 @@ struct PlanCache {
             if (fl & TTM_PLAN_EHIT) {
                 e = st.get(2 * slot + 1);
             } else {
-                e = fast_exp(-0.25 * (x * x));
+                e = exp_q_fast(x);
                 if (slot != 255) st.set(2 * slot + 1, e);
             }
         }

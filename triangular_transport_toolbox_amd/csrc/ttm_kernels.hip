@@ -1046,6 +1046,7 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
     int k = k0;
     R ld(0.0), ss(0.0);
     int xs = 0, ts = 0;
+    bool full = false;                                                   // (uniform) every row of the tile exists
     TTM_RAW_BARRIER();                                                   // A(0)
     for (int64_t s = 0; s < S; ++s) {
         cdbl_p rec = H + (int64_t)k * HS;
@@ -1055,6 +1056,9 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
                 const int64_t n = ctile * ROWS + q * (2 * CT) + 2 * tid;
                 act0[q] = n < N; act1[q] = n + 1 < N;
             }
+#ifndef TTM_EXPERIMENT_NO_FULL_TILE     // A/B timing switch
+            full = (ctile + 1) * ROWS <= N;
+#endif
             ld = R(0.0); ss = R(0.0);
             if (k0 > 0) {                                                // (rare: sweeps that start inside the map)
                 XOffN<NS> cx;
@@ -1082,11 +1086,20 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
         h_component<NG, DB, DA, GS, WANT_LD, TTM_FWD_ETAB(NS)>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
         if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
         if (Z) {
+            double* zt = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + 2 * tid;
+            if (full) {                                                  // all but the last tile: no per-lane masks
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                double* zc = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + q * (2 * CT) + 2 * tid;
-                if (act1[q]) { D2 o = {Sv.v[2 * q], Sv.v[2 * q + 1]}; *(D2*)zc = o; }
-                else if (act0[q]) *zc = Sv.v[2 * q];
+                for (int q = 0; q < NP; ++q) {
+                    D2 o = {Sv.v[2 * q], Sv.v[2 * q + 1]};
+                    *(D2*)(zt + q * (2 * CT)) = o;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    double* zc = zt + q * (2 * CT);
+                    if (act1[q]) { D2 o = {Sv.v[2 * q], Sv.v[2 * q + 1]}; *(D2*)zc = o; }
+                    else if (act0[q]) *zc = Sv.v[2 * q];
+                }
             }
         }
         ss = vfma(Sv, Sv, ss);

@@ -446,7 +446,7 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
     const bool own_hf = own && ((ug_all + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + uc[TTM_UC_N_GRP]))[TTM_UG_FLAGS] & TTM_PLAN_HF);
     const bool put_e = (flags & TTM_UCF_PUT_E) && slot >= 0;
     R ek(0.0);
-    if (put_e || own_hf) ek = fast_exp(-0.25 * (xk * xk));
+    if (put_e || own_hf) ek = exp_q_fast(xk);
     R m(0.0), dm(0.0);
     if (own) u_own<DER>(uc, ug_all, U, xk, ek, m, dm);
     if (nI > 0) {
@@ -467,7 +467,7 @@ TTM_HD void u_component(cint_p uc, cint_p ug_all, cdbl_p U, const double* tab, c
 // exp(-x^2/4) of the hot paths: from the 2^(j/32) table when the kernel staged one (CacheStore::etab - the inverse
 // kernel: -6 % instructions), else the generic exp (the forward kernel: with the table lookup in its long basic
 // block the compiler keeps 30 more VGPRs live and a workgroup per CU is lost - measured slower)
-#define TTM_HL_EXP(st, x) ((st).etab ? exp_q_tab((st).etab, (x)) : fast_exp(-0.25 * ((x) * (x))))
+#define TTM_HL_EXP(st, x) ((st).etab ? exp_q_tab((st).etab, (x)) : exp_q_fast(x))
 
 // S_k and dS_k/dx_k from a hot record (include/ttm.h "H section"): NG group records of degree (DB, DA) and stride
 // GS, every column from the planned cache (st; slot s of a sample set = st.get(s)), then the put of x_k.  All scalar
@@ -496,7 +496,7 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const ST& st
 #ifdef TTM_EXPERIMENT_NO_EXP
         const R ek = xk * rec[3];
 #else
-        const R ek = (ETAB ? exp_q_tab(st.etab, xk) : fast_exp(-0.25 * (xk * xk)));
+        const R ek = (ETAB ? exp_q_tab(st.etab, xk) : exp_q_fast(xk));
 #endif
         TTM_SCHED_FENCE();
         // phase 3: spline of the first half; then the second half's gather behind the groups
@@ -542,7 +542,7 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const ST& st
         }
     }
     R ek(0.0);
-    if (flg & 1) ek = (ETAB ? exp_q_tab(st.etab, xk) : fast_exp(-0.25 * (xk * xk)));
+    if (flg & 1) ek = (ETAB ? exp_q_tab(st.etab, xk) : exp_q_fast(xk));
     R m(0.0), dm(0.0);
     if (nI > 0) u_spline<DER>(tab, nI, rec[3], rec[4], rec[5], xk, m, dm);
     S = s + m;
