@@ -189,6 +189,14 @@ def main():
                 step()
             torch.cuda.synchronize()
             prewarm_steps += 50
+        if dist is not None:
+            # the ranks leave the time-based loop up to one batch apart; the one that waits at a barrier idles and would
+            # start its timed steps on the ramp.  Align them once, then give every rank the same number of steps, so
+            # that all arrive at the barrier in front of the timed region within a fraction of a millisecond
+            sync()
+            for _ in range(150):
+                step()
+            prewarm_steps += 150
     for _ in range(args.warmup):
         step()
     sync()                                   # (nothing else between the warm-up and the timed steps: see above)
