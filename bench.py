@@ -15,6 +15,10 @@ data-path collective).
 prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel
 (forward map: algorithmic bytes 8 N (d_used + D)) and a
 `cpu_baseline` object (the CPU oracle, one process per host core on a bounded sample each, rank 0, N=1).
+The headline workload is C5 (BASELINE.json configs[4], the one north_star's target is quoted on; it fits one GPU);
+at N=1 the same line carries, under `other_configs`, the secondary numbers of the other single-GPU configurations
+(configs[1] = C2b / C2a spiral d=2 order 5 N=1e6 forward + inverse + pullback, configs[2] = C3 d=4 order 4 N=5e5 with
+optimize()).  Timing discipline (pre-warm, no pause before the timed steps): DESIGN.md section 6, "Clock state".
 """
 import argparse
 import json
@@ -115,6 +119,71 @@ def cpu_baseline(workload, n_cpu, cores):
                 host_cores_available=os.cpu_count())
 
 
+def other_configs(torch, names, steps=40):
+    """The other single-GPU configurations of BASELINE.json (secondary numbers of the same JSON line): per workload
+    forward / inverse launch times with HIP events (back to back behind a short untimed run), map-evals/s of forward +
+    inverse over `steps` steps, the fused pullback pass for separable maps, optimize() wall-clock from coeffs_init."""
+    out = {}
+    for name in names:
+        tm, X, cfg = build_map(name, 0)
+        N, D, d = tm._N, tm.D, tm._cm.d_cols
+        separable = tm.monotonicity == 'separable monotonicity'
+        coef = tm._pack_coeffs()
+        Xs, Z, Xinv = tm._Xs, tm._cols(D, N), tm._cols(d, N, zero=True)
+
+        def step():
+            tm.forward_device(Xs, N, coef=coef, Z=Z)
+            tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        n_warm = 200 if separable else 5            # (a bisection inverse of 1e6 samples is ~17 ms)
+        n = steps if separable else max(3, steps // 8)
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        for a, b, c in ev:
+            a.record(); tm.forward_device(Xs, N, coef=coef, Z=Z); b.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); c.record()
+        torch.cuda.synchronize()
+        r = dict(workload=WORKLOADS[name][3], N=N, D=D, steps=n, ms_per_step=1e3 * el / n, value=N * D * n / el,
+                 forward_ms=float(np.mean([a.elapsed_time(b) for a, b, c in ev])),
+                 inverse_ms=float(np.mean([b.elapsed_time(c) for a, b, c in ev])),
+                 inverse='table' if separable else 'bisection (reference sequence)',
+                 roundtrip_max_abs_err=float((Xinv[:, :N] - Xs[:, :N]).abs().max().item()),
+                 # (the max sits in the tails, where the reference's 1001-point table inverse clips / interpolates
+                 # coarsely or the bisection window runs away; the median is the inverse's working accuracy)
+                 roundtrip_median_abs_err=float((Xinv[:, :N] - Xs[:, :N]).abs().median().item()))
+        r['forward_GBps_algorithmic'] = 8.0 * N * (d_used(tm) + D) / (r['forward_ms'] * 1e-3) / 1e9
+        if separable:
+            ld, ss = tm._empty(N), tm._empty(N)
+            sigma = tm._to_dev(np.asarray(tm.X_std[:D], dtype=float))
+            for _ in range(100):
+                tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss)
+            evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for a, b in evp:
+                a.record(); tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss); b.record()
+            torch.cuda.synchronize()
+            r['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        Nopt = N if separable else 100000            # (integrated-rectifier optimize(): BASELINE.md quotes N = 1e5)
+        if Nopt != N:
+            del tm, Xs, Z, Xinv
+            tm, _, _ = build_map(name, 0, Nopt)
+        for k in range(tm.D):
+            tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
+            tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tm.optimize()
+        torch.cuda.synchronize()
+        r['optimize_s'], r['optimize_N'] = time.perf_counter() - t0, Nopt
+        out[name] = r
+        del tm
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -129,6 +198,8 @@ def main():
                     help="torch.distributed backend for --gpus > 1 ('nccl' = RCCL; 'gloo' only to rehearse on one GPU)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimize', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the secondary numbers of the other single-GPU BASELINE configurations (C2b, C2a, C3)')
     ap.add_argument('--cpu-samples', type=int, default=0, help='samples per host process of the CPU baseline')
     ap.add_argument('--cpu-cores', type=int, default=0, help='host processes of the CPU baseline (default 1)')
     args = ap.parse_args()
@@ -252,6 +323,11 @@ def main():
         torch.cuda.synchronize()
         extra['optimize_s'] = time.perf_counter() - t0o
         tm.coeffs_mon, tm.coeffs_nonmon = saved
+    if world == 1 and not args.no_other_configs and args.workload == 'C5':
+        try:
+            extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3'])
+        except Exception as exc:                       # noqa: BLE001  (never fatal for the headline line)
+            extra['other_configs_error'] = repr(exc)
     if world > 1 and not args.no_optimize:
         # optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
         # holds the same ensemble (seed of rank 0), optimises a strided subset of the components, coefficients are

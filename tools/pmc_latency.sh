@@ -11,6 +11,6 @@ for set in "SQ_INST_LEVEL_SMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_LEVEL_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/lat_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-optimize "$@" > $R/gpurun_out/lat_$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/lat_$i --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-optimize --no-other-configs "$@" > $R/gpurun_out/lat_$i.log 2>&1
 done
 cd $R && python3 tools/pmc_summary.py gpurun_out/lat_* > gpurun_out/lat_summary.json

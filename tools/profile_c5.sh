@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 # kernel-trace statistics: the default bench command (pre-warmed clocks, 200 timed steps) without the host-side extras;
 # counter passes: a few dispatches are enough and the counters do not depend on the clock
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-optimize > $R/gpurun_out/prof_stats.log 2>&1
-ARGS="--steps 5 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-optimize"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-optimize --no-other-configs > $R/gpurun_out/prof_stats.log 2>&1
+ARGS="--steps 5 --warmup 1 --prewarm-seconds 0 --no-cpu-baseline --no-optimize --no-other-configs"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/prof_write --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM -d $R/gpurun_out/prof_sq --output-format csv -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_sq.log 2>&1

@@ -7,7 +7,7 @@ for v in "$@"; do
   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -DNDEBUG $v -o triangular_transport_toolbox_amd/libttm.so triangular_transport_toolbox_amd/csrc/ttm_kernels.hip 2>gpurun_out/variant_build.err || { echo "build failed [$v]"; continue; }
   for e in ${ENVS:-_=_}; do
   echo "== variant [$v] env [$e]"
-  env $e timeout -k 10 200 python bench.py --no-cpu-baseline --no-optimize --workload C5 --prewarm-seconds ${PREWARM:-1.0} > gpurun_out/b.json 2> gpurun_out/b.err
+  env $e timeout -k 10 200 python bench.py --no-cpu-baseline --no-optimize --no-other-configs --workload C5 --prewarm-seconds ${PREWARM:-1.0} > gpurun_out/b.json 2> gpurun_out/b.err
   python -c "
 import json
 d=json.load(open('gpurun_out/b.json'))
