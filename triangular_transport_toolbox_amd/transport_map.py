@@ -35,7 +35,7 @@ import ctypes
 
 import numpy as np
 
-from . import _capi, quantile, termtable
+from . import _capi, lbfgsb, quantile, termtable
 
 __all__ = ['transport_map']
 
@@ -899,6 +899,38 @@ class transport_map():
         grad = Ax - sums[1:] / N + b
         return objective, grad
 
+    def _sep_objective_fast(self, A, k):
+        """separable_objective(., A, k) for the optimiser's inner loop: everything that does not depend on the
+        coefficient vector (pointers, stream handle, workspace, b = delta * rowsum(A)) is prepared once per component;
+        one evaluation = one ctypes call, one stream synchronisation and O(m^2) host arithmetic.  Same operations on
+        the same values as separable_objective (which stays the public method)."""
+        cache = getattr(self, '_sep_cache', None)
+        if cache is None or cache[0] != int(k) or self._dev.type != 'cuda':
+            return None
+        torch = _torch()
+        dpsi = cache[1]
+        m = int(self._cm.n_mon[k])
+        work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
+        stream = torch.cuda.current_stream()
+        fn = self._lib.ttm_objective_sep_cached
+        a_dpsi, a_ld, a_N, a_m = self._ptr(dpsi), dpsi.shape[1], self._N, m
+        a_delta, a_work = float(self.delta), self._ptr(work)
+        a_cnt, a_out = ctypes.c_void_p(self._obj_cnt.data_ptr()), ctypes.c_void_p(self._obj_out.data_ptr())
+        a_stream = ctypes.c_void_p(stream.cuda_stream)
+        out_np = self._obj_out.numpy()                       # (view of the pinned result buffer)
+        N = self._Nglobal
+        b = self.delta * np.sum(A, axis=-1)
+        check, sync = _capi.check, stream.synchronize
+
+        def fun(coeffs_mon, *_):
+            c = np.ascontiguousarray(coeffs_mon, dtype=float)
+            check(fn(a_dpsi, a_ld, a_N, a_m, ctypes.c_void_p(c.ctypes.data), a_delta, a_work, a_cnt, a_out, a_stream))
+            sync()
+            sums = out_np[:1 + m].copy()
+            Ax = A @ c
+            return c @ Ax / 2 - sums[0] / N + np.inner(c, b), Ax - sums[1:] / N + b
+        return fun
+
     def optimize(self, K=None):
         """TM:2714-2901: per-component SciPy minimisation (BFGS / L-BFGS-B as
         TM:3252-3257 / TM:3108-3114) driven by the device reductions."""
@@ -929,8 +961,10 @@ class transport_map():
                           for i in range(len(self.optimization_constraints_lb[k]))]
                 self._sep_cache_begin(k)
                 try:
-                    opt = minimize(fun=self.separable_objective, method='L-BFGS-B',
-                                   x0=np.asarray(self.coeffs_mon[k], dtype=float), jac=True, bounds=bounds, args=(A, k))
+                    # (scipy.optimize.minimize(method='L-BFGS-B') as TM:3108-3114, minus its per-evaluation wrappers)
+                    fast = self._sep_objective_fast(A, k)
+                    opt = lbfgsb.minimize_lbfgsb(fast if fast is not None else self.separable_objective,
+                                                 np.asarray(self.coeffs_mon[k], dtype=float), bounds, (A, k))
                 finally:
                     self._sep_cache_end()
                 self.coeffs_mon[k] = copy.deepcopy(opt.x)
