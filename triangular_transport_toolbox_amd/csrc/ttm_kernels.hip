@@ -1203,6 +1203,9 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
     int64_t ctile = blockIdx.x;
     int k = k0;
     int xs = 0, ts = 0;
+#ifndef TTM_INV_EXACT_LERP
+    const double dy_last = ylast - ((double)(T - 2) * ystep + y0);
+#endif
     // sentinels behind the table entries of every slot (the DMAs only ever write the first T doubles)
     if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1291,8 +1294,15 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
             const int i = pos[e] < 1 ? 1 : (pos[e] > T - 1 ? T - 1 : pos[e]);
             const double x_lo = xsl[i - 1], x_hi = xsl[i];
             const double y_lo = (double)(i - 1) * ystep + y0;
+#ifndef TTM_INV_EXACT_LERP
+            // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-15 of the step; the last interval,
+            // whose end point np.linspace forces, keeps its own difference): no second abscissa, no compare
+            const double dy = (i == T - 1) ? dy_last : ystep;
+            const double slope = fast_div(dy, x_hi - x_lo);
+#else
             const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
             const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
+#endif
             r.v[e] = slope * (tg[e] - x_lo) + y_lo;
         }
         h_put(rec, cst, r);
