@@ -974,7 +974,10 @@ TTM_HD double table_lookup(const double* xs, const double* ys, int T, double tar
     }
     int i = lo < 1 ? 1 : (lo > T - 1 ? T - 1 : lo);
     const double x_lo = xs[i - 1], x_hi = xs[i], y_lo = ys[i - 1], y_hi = ys[i];
-    const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);
+    // (x_hi == x_lo can only happen at the clamped start of a table with a flat tail, where target == x_lo: interp1d's
+    // inf * 0 = NaN there is an accident of rounding - which of two noise-level table entries is larger - so the tie
+    // returns the first abscissa, as the untied neighbour case does)
+    const double slope = fast_div(y_hi - y_lo, fmax(x_hi - x_lo, 1e-300));
     return slope * (target - x_lo) + y_lo;
 }
 

@@ -1298,10 +1298,10 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
             // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-15 of the step; the last interval,
             // whose end point np.linspace forces, keeps its own difference): no second abscissa, no compare
             const double dy = (i == T - 1) ? dy_last : ystep;
-            const double slope = fast_div(dy, x_hi - x_lo);
+            const double slope = fast_div(dy, fmax(x_hi - x_lo, 1e-300));          // (tie at a flat start: table_lookup)
 #else
             const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
-            const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
+            const double slope = fast_div(y_hi - y_lo, fmax(x_hi - x_lo, 1e-300));          // interp1d slope form (TM:4062-4065)
 #endif
             r.v[e] = slope * (tg[e] - x_lo) + y_lo;
         }
@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
                 } else {
                     y_lo = ys[i - 1]; y_hi = ys[i];
                 }
-                const double slope = fast_div(y_hi - y_lo, x_hi - x_lo);          // interp1d slope form (TM:4062-4065)
+                const double slope = fast_div(y_hi - y_lo, fmax(x_hi - x_lo, 1e-300));          // interp1d slope form (TM:4062-4065)
                 const double re = slope * (target - x_lo) + y_lo;
                 set_elem(r, e, re);
                 if (act[e]) X[(int64_t)kc * ldx + xa.n[e]] = re;
