@@ -167,6 +167,19 @@ def other_configs(torch, names, steps=40):
                 a.record(); tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss); b.record()
             torch.cuda.synchronize()
             r['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        if not separable:
+            # the same inversion with the engine's safeguarded Newton root search (root_finder='newton', an extension:
+            # same roots to |S - z| <= 1e-9, not the reference's midpoint sequence)
+            tm.root_finder = 'newton'
+            for _ in range(3):
+                tm.inverse_device(Z, N, coef=coef, X=Xinv)
+            evn = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in evn:
+                a.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); b.record()
+            torch.cuda.synchronize()
+            r['inverse_newton_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evn]))
+            r['roundtrip_median_abs_err_newton'] = float((Xinv[:, :N] - Xs[:, :N]).abs().median().item())
+            tm.root_finder = 'reference'
         Nopt = N if separable else 100000            # (integrated-rectifier optimize(): BASELINE.md quotes N = 1e5)
         if Nopt != N:
             del tm, Xs, Z, Xinv

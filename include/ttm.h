@@ -370,6 +370,17 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
                        const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                        int32_t* iters, const int32_t* cap, void* stream);
 
+/* ---- K5 (second mode): safeguarded Newton inverse - NOT the reference's method ------------
+ * Same start, window doubling and stopping rule (|S - z| <= 1e-9, at most 100 trial points) as
+ * ttm_inverse_bisect; inside the bracket the trial points are Newton steps with the analytic
+ * dS/dx_k (midpoint when a step leaves the bracket).  Converges to the same root in ~6 instead of
+ * ~33 evaluations of S; the last trial point is not the reference's last midpoint (difference
+ * <= 1e-9 / (dS/dx)).  Opt-in of the host class (root_finder='newton'); the default stays
+ * ttm_inverse_bisect.  iters: as above (maximum number of Newton / midpoint trial points).        */
+int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
+                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
+                       int32_t* iters, void* stream);
+
 /* ---- K6/K7: objective + gradient reductions for optimize() -------------------------
  * integrated: TM:3300-3376 objective_function, TM:3435-3569 objective_function_jacobian
  *   out[0] = sum_n ( S^2/2 - log(r(g)+delta) ), out[1..] = sum_n d/dc of the same, [nonmon | mon]

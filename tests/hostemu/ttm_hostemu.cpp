@@ -663,4 +663,28 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
     return 0;
 }
 
+int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
+                       int64_t ldz, double* X, int64_t ldx, int64_t N, int32_t* iters, void*) {
+    const Prog g = make_prog(p);
+    std::vector<double> scr(4096);
+    std::vector<HostComp> hc(k1 - k0);
+    for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
+    for (int64_t n = 0; n < N; ++n) {
+        XSoA xa{X, ldx, n};
+        double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
+        for (int k = k0; k < k1; ++k) {
+            const Comp& c = hc[k - k0].c;
+            VecSlots w{scr.data()};
+            const double off = nonmon_sum<double>(c, g, x);
+            mon_weights<double>(c, g, x, w);
+            int it = 0;
+            const double r = sample_newton<-1>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, it);
+            X[(int64_t)c.kc * ldx + n] = r;
+            x.put(c.kc, r);
+            if (it > iters[k - k0]) iters[k - k0] = it;
+        }
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -51,6 +51,8 @@ _SIGNATURES = {
                                          c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     'ttm_inverse_bisect': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                           c_i64, c_vp, c_vp, c_vp]),
+    'ttm_inverse_newton': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
+                                          c_i64, c_vp, c_vp]),
     'ttm_reduce_work_size': (c_i64, [c_i32]),
     'ttm_objective': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'ttm_objective_host': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),

@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(256) void k_inverse_table(DevProg P, int k0, int k1
 // K5: bisection inverse
 // ---------------------------------------------------------------------------
 
-template <int MONO>
+template <int MONO, bool NEWTON>
 __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k1, const double* __restrict__ coef,
                                                         const double* __restrict__ fold,
                                                         const double* __restrict__ Z, int64_t ldz,
@@ -1524,12 +1524,13 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k
                 const double off = nonmon_sum<double>(c, g, x);
                 const int capk = cap ? cap[k - k0] : -1;
                 double r;
+                const double zk = Z[(int64_t)(k - k0) * ldz + n];
                 if (c.n_mnt == 0) {
                     const UniformW uw{c.fold + c.off_wb};
-                    r = sample_bisect<MONO>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], uw, capk, it);
+                    r = NEWTON ? sample_newton<MONO>(c, g, off, zk, uw, it) : sample_bisect<MONO>(c, g, off, zk, uw, capk, it);
                 } else {
                     mon_weights<double>(c, g, x, w);
-                    r = sample_bisect<MONO>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, capk, it);
+                    r = NEWTON ? sample_newton<MONO>(c, g, off, zk, w, it) : sample_bisect<MONO>(c, g, off, zk, w, capk, it);
                 }
                 X[(int64_t)c.kc * ldx + n] = r;
                 x.put(c.kc, r);
@@ -2208,10 +2209,24 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
     const int ns = map_slots(p, k0, k1);
     const int bd = pick_block(ns, 0);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_bisect: %s%lld scratch slots do not fit the LDS budget", "", ns);
-    auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE> : k_inverse_bisect<TTM_MONO_INTEGRATED>;
+    auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, false> : k_inverse_bisect<TTM_MONO_INTEGRATED, false>;
     hipLaunchKernelGGL(kern, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1,
                        coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, cap);
     return check_launch("k_inverse_bisect");
+}
+
+int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,
+                       int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, int32_t* iters, void* stream) {
+    int rc = validate(p, k0, k1);
+    if (rc) return rc;
+    if (!coef || !fold || !Zsoa || !Xsoa || !iters || N < 1 || ldx < N || ldz < N) return set_err(TTM_E_ARG, "ttm_inverse_newton: bad arguments%s");
+    const int ns = map_slots(p, k0, k1);
+    const int bd = pick_block(ns, 0);
+    if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_newton: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, true> : k_inverse_bisect<TTM_MONO_INTEGRATED, true>;
+    hipLaunchKernelGGL(kern, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1,
+                       coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, (const int*)nullptr);
+    return check_launch("k_inverse_newton");
 }
 
 // workspace: [folded coefficients of the component (<= 4096) | per-block partials]
