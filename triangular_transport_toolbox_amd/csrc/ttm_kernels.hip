@@ -1244,7 +1244,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
         // bucket number of a target: (target - lo) nb / (hi - lo); the search starts one bucket lower, so the
         // last-bit difference between this reciprocal and the division of the index kernel does not matter
-        const double scale = (double)nb * fast_rcp(hi - lo);
+        const double scale = (double)nb * approx_rcp(hi - lo);           // (2^-23 of a bucket: the search starts a bucket early)
         const bool use_bkt = scale > 0.0 && scale < 1.0e300;
         const R off = h_offset<NG, DB, DA, GS, R, Store>(rec, cst);
         double tg[NS];
@@ -1298,7 +1298,7 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
             // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-15 of the step; the last interval,
             // whose end point np.linspace forces, keeps its own difference): no second abscissa, no compare
             const double dy = (i == T - 1) ? dy_last : ystep;
-            const double slope = fast_div(dy, fmax(x_hi - x_lo, 1e-300));          // (tie at a flat start: table_lookup)
+            const double slope = fast_div1(dy, fmax(x_hi - x_lo, 1e-300));         // (tie at a flat start: table_lookup)
 #else
             const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
             const double slope = fast_div(y_hi - y_lo, fmax(x_hi - x_lo, 1e-300));          // interp1d slope form (TM:4062-4065)

@@ -42,6 +42,28 @@ TTM_HD double fast_div(double a, double b) {
 #endif
 }
 
+// a / b with one Newton step on v_rcp_f64 (2^-23 -> 2^-46) and the residual correction (-> < 1 ulp of the quotient
+// for normal operands): two instructions fewer than fast_div; for quotients whose consumer tolerates 2 ulp
+TTM_HD double fast_div1(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+#else
+    return a / b;
+#endif
+}
+
+// 1 / b to the 23 bits v_rcp_f64 delivers (bucket numbers, start values)
+TTM_HD double approx_rcp(double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(b);
+#else
+    return 1.0 / b;
+#endif
+}
+
 // Taylor coefficients 1/13! .. 1/2!, kept in constant memory: read by scalar loads into SGPRs and
 // fed to v_fma_f64 as scalar operands (hoisting them into VGPRs costs 24 registers and a v_mov per step)
 #if defined(__HIPCC__)
