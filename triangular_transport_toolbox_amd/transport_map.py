@@ -18,7 +18,8 @@ What is deliberately different from the reference:
   term tables (``termtable.compile_map``);
 * ``workers`` is accepted and ignored (the process pool of TM:2789-2874 is
   replaced by the GPU; components / samples shard over ranks instead);
-* ``adaptation`` (TM:373-656, 4575-4950) is outside the hot path and raises
+* ``adaptation`` with ``adaptation_map_type='separable'`` (TM:373-636) is built
+  (``adapt_map``); the cross-term variant (TM:4575-4950) raises
   NotImplementedError; ``linearization`` / ``'LIN'`` are supported for the
   integrated rectifier (see ``_linearization_thresholds``), with separable
   monotonicity they raise (reference defect TM:2063-2080);
@@ -90,15 +91,25 @@ class transport_map():
         self._dev = torch.device(self._DEVICE, torch.cuda.current_device()) if self._DEVICE == 'cuda' \
             else torch.device(self._DEVICE)
 
-        if adaptation:
-            raise NotImplementedError('map adaptation (TM:373-656, 4575-4950) is outside the MI355X hot path')
+        if adaptation and adaptation_map_type.lower() != 'separable':
+            raise NotImplementedError("map adaptation: only adaptation_map_type = 'separable' (TM:405-636) is built; the "
+                                      "cross-term variant (TM:4575-4950) is not")
         if linearization is not None and monotonicity.lower() == 'separable monotonicity':
             # TM:2063-2080: with a linearisation the reference's derivative functions (the only consumers in
             # separable mode) overwrite their input with min(x, lower threshold) in every column (inverted masks)
             raise NotImplementedError('linearization with separable monotonicity is a defect of the reference '
                                       '(TM:2063-2080) and is not reproduced')
+        self.adaptation_map_type = adaptation_map_type.lower()
+        self.adaptation_max_order = adaptation_max_order
+        self.adaptation_skip_dimensions = adaptation_skip_dimensions
+        self.adaptation_max_iterations = adaptation_max_iterations
+        if adaptation:
+            # TM:327-340: a dummy map (one constant term in both lists of every component) until adapt_map() runs
+            n_comp = np.asarray(X).shape[-1] - adaptation_skip_dimensions
+            monotone = [[[]] for _ in range(n_comp)]
+            nonmonotone = [[[]] for _ in range(n_comp)]
         if monotone is None or nonmonotone is None:
-            raise ValueError("'monotone' and 'nonmonotone' must be specified (map adaptation is not supported)")
+            raise ValueError("'monotone' and 'nonmonotone' must be specified (or adaptation = True)")
 
         self.monotone = copy.deepcopy(monotone)
         self.nonmonotone = copy.deepcopy(nonmonotone)
@@ -157,9 +168,17 @@ class transport_map():
                             'D = number of dimensions. Current shape of X is ' + str(X.shape))
         self.D = len(monotone)
         self.skip_dimensions = X.shape[-1] - self.D
+        self._build_program(X.shape[-1])
 
+        # ---- samples: upload, standardise, place special terms -----------------
+        self._load_samples(X)
+
+    def _build_program(self, d_cols):
+        """Compile self.monotone / self.nonmonotone into term tables and the device program (what the reference's
+        function_constructor_alternative does with generated source, TM:1263-2134); coefficients back to coeffs_init."""
+        torch = _torch()
         # ---- compile the specification into term tables -----------------------
-        self._cm = termtable.compile_map(self.monotone, self.nonmonotone, X.shape[-1], self.polynomial_type,
+        self._cm = termtable.compile_map(self.monotone, self.nonmonotone, d_cols, self.polynomial_type,
                                          self.monotonicity, linearization=self.linearization)
         self.special_terms = termtable.count_special_terms(self.monotone, self.nonmonotone, self.skip_dimensions)
         self.coeffs_mon = [np.ones(int(n)) * self.coeffs_init for n in self._cm.n_mon]
@@ -184,12 +203,10 @@ class transport_map():
         self._pp = ctypes.byref(self._prog)
         self._u_checked = None
         self._u_rejected = False
+        self._ugrp_d = None                      # (static U-form tables belong to the specification just compiled)
         self._refresh_uform()
         self._work = None
         self._obj_cache = None
-
-        # ---- samples: upload, standardise, place special terms -----------------
-        self._load_samples(X)
 
     # ------------------------------------------------------------------------
     # device plumbing
@@ -911,6 +928,101 @@ class transport_map():
         objective = c @ Ax / 2 - sums[0] / N + np.inner(c, b)
         grad = Ax - sums[1:] / N + b
         return objective, grad
+
+    def _respecify(self, monotone, nonmonotone):
+        """New term lists on the resident ensemble (TM:432-438: function_constructor_alternative + precalculate)."""
+        self.monotone = copy.deepcopy(monotone)
+        self.nonmonotone = copy.deepcopy(nonmonotone)
+        self._build_program(self._cm.d_cols)
+        self._obj_cache = None
+        self.determine_special_term_locations()
+
+    def adapt_map(self, coeffs={}, maxorder_mon=10, maxorder_nonmon=10, threshold_sw=0.1, threshold_prec=0.1,
+                  sequential_updates=False, map_finished=None):
+        """TM:373-636, adaptation_map_type = 'separable': (1) marginal phase - every component starts as [[k]] and gets
+        one more 'iRBF k' per round until its pushforward marginal passes a Shapiro-Wilk test (p >= threshold_sw) or
+        maxorder_mon is reached; (2) off-diagonal phase - for every pair (k, j < k) whose standardised precision
+        (first round) / correlation (later rounds) of the pushforward exceeds threshold_prec, one more nonmonotone
+        term [j]*order (+ 'HF' from order 2 on) per round, until all pairs are finished or maxorder_nonmon rounds.
+        Every round re-specifies the map (coefficients back to coeffs_init, special terms re-placed), optimises all
+        components and maps the training ensemble - the hot path; the statistics on the N x D pushforward are the
+        reference's NumPy / SciPy calls on the host."""
+        if self.adaptation_map_type != 'separable':
+            raise Exception("Currently, only adaptation_map_type = 'cross-terms' is implemented.")      # (TM:648, sic)
+        import scipy.stats
+        D = self.D
+        nonmonotone = [[[]] for x in np.arange(D)]
+        monotone = [[[x]] for x in np.arange(D)]
+        Gaussianized = np.zeros(D, dtype=bool)
+        iterate, iteration = True, 0
+        maporders = np.zeros((D, D), dtype=int)
+        np.fill_diagonal(maporders, 1)
+        pvals_mat = np.zeros((maxorder_mon, D))
+        while iterate:
+            iteration += 1
+            self._respecify(monotone, nonmonotone)
+            self.optimize()
+            Z = self.map()
+            pval = np.zeros(D)
+            for k in range(D):
+                pval[k] = scipy.stats.shapiro(Z[:, k]).pvalue
+            pvals_mat[iteration - 1, :] = copy.copy(pval)
+            for idx in np.where(pval >= threshold_sw)[0]:
+                Gaussianized[np.arange(D)[idx]] = True
+            for k in np.where(~Gaussianized)[0]:
+                if maporders[k, k + self.skip_dimensions] < maxorder_mon:
+                    maporders[k, k + self.skip_dimensions] += 1
+                    monotone[k] += ['iRBF ' + str(k)]
+            if np.sum(Gaussianized) == D:
+                iterate = False
+            if iteration >= maxorder_mon - 1:
+                iterate = False
+        covmat = np.abs(np.cov(Z.T))
+        diagval = np.sqrt(np.diag(covmat))
+        covmat /= diagval[np.newaxis, :]
+        covmat /= diagval[:, np.newaxis]
+        precmat = np.abs(np.linalg.inv(np.cov(Z.T)))
+        diagval = np.sqrt(np.diag(precmat))
+        precmat /= diagval[np.newaxis, :]
+        precmat /= diagval[:, np.newaxis]
+        self.covmat, self.precmat = copy.copy(covmat), copy.copy(precmat)
+        iterate, iteration = True, 0
+        if map_finished is None:
+            map_finished = np.zeros((D, D), dtype=bool)
+        while iterate:
+            iteration += 1
+            self._respecify(monotone, nonmonotone)
+            self.optimize()
+            Z = self.map()
+            try:
+                if iteration == 1:
+                    precmat = np.abs(np.linalg.inv(np.cov(Z.T)))
+                    diagval = np.sqrt(np.diag(precmat))
+                    precmat /= diagval[np.newaxis, :]
+                    precmat /= diagval[:, np.newaxis]
+                else:
+                    precmat = np.corrcoef(Z.T)
+                for k in range(D):
+                    for j in range(k):
+                        if precmat[k, j] > threshold_prec and not map_finished[k, j]:
+                            maporders[k, j] += 1
+                            if maporders[k, j] == 1:
+                                nonmonotone[k].append([j] * maporders[k, j])
+                            else:
+                                nonmonotone[k].append([j] * maporders[k, j] + ['HF'])
+                        else:
+                            map_finished[k, j] = True
+                    nonmonotone[k].sort()
+            except Exception:                  # noqa: BLE001  (TM:614: anything that fails here ends the iteration)
+                iterate = False
+            if np.sum(map_finished) >= D * (D - 1) / 2:
+                iterate = False
+            if iteration >= maxorder_nonmon:
+                print("WARNING: Map adaptation stopped at maximum number of iterations.")
+                iterate = False
+        self._respecify(monotone, nonmonotone)
+        self.optimize()
+        self.maporders = maporders
 
     def _sep_objective_fast(self, A, k):
         """separable_objective(., A, k) for the optimiser's inner loop: everything that does not depend on the
