@@ -1,7 +1,8 @@
 """
-Map adaptation, adaptation_map_type = 'separable' (reference TM:373-636): the greedy loop
-(re-specify -> optimize -> map -> Shapiro-Wilk / precision statistics -> add terms) against fixtures produced by the
-reference's adapt_map() (tests/golden/make_golden.py adapt).  The decisions are discrete (which terms get added), so the
+Map adaptation: adaptation_map_type = 'separable' (reference TM:373-636; re-specify -> optimize ->
+map -> Shapiro-Wilk / precision statistics -> add terms) and 'cross-terms' (TM:4575-4950; multi-index sets grown by
+finite-difference scores of the objective) against fixtures produced by the reference's adapt_map()
+(tests/golden/make_golden.py adapt adaptcross).  The decisions are discrete (which terms get added), so the
 final term lists and map orders must be IDENTICAL; coefficients and the pushforward agree to the optimiser's own
 tolerance (L-BFGS-B stops at a projected gradient of 1e-5).
 """
@@ -46,8 +47,27 @@ def test_adapt_map_reproduces_the_reference(backend, name):
     assert relerr(tm.inverse_map(Z), npz['X'][:50]) < 1e-3
 
 
-def test_cross_term_adaptation_is_not_built(backend):
+@pytest.mark.parametrize('name', ['adapt_cross_d2', 'adapt_cross_d3'])
+def test_cross_term_adaptation_reproduces_the_reference(backend, name):
+    """adaptation_map_type = 'cross-terms' (TM:4575-4950): the multi-index sets grow by the same cells in the same
+    order (term lists and index matrix identical); the coefficients come out of L-BFGS-B runs whose gradients are
+    finite differences of the objective (the reference passes no Jacobian there), so they agree to that noise."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case(name)
+    tm = transport_map(X=npz['X'], monotonicity='integrated rectifier', adaptation=True, adaptation_map_type='cross-terms',
+                       verbose=False, **desc['ctor_kwargs'])
+    tm.adapt_map()
+    assert _plain(tm.monotone) == desc['monotone']
+    assert _plain(tm.nonmonotone) == desc['nonmonotone']
+    assert np.array_equal(tm.multi_index_matrix, npz['multi_index_matrix'])
+    for k in range(tm.D):
+        assert relerr(tm.coeffs_mon[k], npz['coeffs_mon_%d' % k]) < 5e-3
+        assert relerr(tm.coeffs_nonmon[k], npz['coeffs_nonmon_%d' % k]) < 5e-3
+    assert relerr(tm.map(npz['X']), npz['Z']) < 5e-3
+
+
+def test_unknown_adaptation_type_is_rejected(backend):
     from triangular_transport_toolbox_amd.transport_map import transport_map
     X = np.random.default_rng(0).standard_normal((64, 2))
-    with pytest.raises(NotImplementedError, match='TM:4575-4950'):
-        transport_map(X=X, adaptation=True, verbose=False)          # (the reference's default type is 'cross-terms')
+    with pytest.raises(Exception, match="adaptation_map_type"):
+        transport_map(X=X, adaptation=True, adaptation_map_type='greedy', verbose=False)

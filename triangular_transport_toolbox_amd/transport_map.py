@@ -18,9 +18,9 @@ What is deliberately different from the reference:
   term tables (``termtable.compile_map``);
 * ``workers`` is accepted and ignored (the process pool of TM:2789-2874 is
   replaced by the GPU; components / samples shard over ranks instead);
-* ``adaptation`` with ``adaptation_map_type='separable'`` (TM:373-636) is built
-  (``adapt_map``); the cross-term variant (TM:4575-4950) raises
-  NotImplementedError; ``linearization`` / ``'LIN'`` are supported for the
+* ``adaptation`` (``adapt_map``: 'separable' TM:373-636, 'cross-terms'
+  TM:4575-4950) re-specifies the map on the resident ensemble instead of
+  regenerating source; ``linearization`` / ``'LIN'`` are supported for the
   integrated rectifier (see ``_linearization_thresholds``), with separable
   monotonicity they raise (reference defect TM:2063-2080);
 * reference defects that are only reachable through invalid specifications are
@@ -91,9 +91,8 @@ class transport_map():
         self._dev = torch.device(self._DEVICE, torch.cuda.current_device()) if self._DEVICE == 'cuda' \
             else torch.device(self._DEVICE)
 
-        if adaptation and adaptation_map_type.lower() != 'separable':
-            raise NotImplementedError("map adaptation: only adaptation_map_type = 'separable' (TM:405-636) is built; the "
-                                      "cross-term variant (TM:4575-4950) is not")
+        if adaptation and adaptation_map_type.lower() not in ('separable', 'cross-terms'):
+            raise Exception("Currently, only adaptation_map_type = 'cross-terms' is implemented.")          # (TM:648, sic)
         if linearization is not None and monotonicity.lower() == 'separable monotonicity':
             # TM:2063-2080: with a linearisation the reference's derivative functions (the only consumers in
             # separable mode) overwrite their input with min(x, lower threshold) in every column (inverted masks)
@@ -947,6 +946,8 @@ class transport_map():
         Every round re-specifies the map (coefficients back to coeffs_init, special terms re-placed), optimises all
         components and maps the training ensemble - the hot path; the statistics on the N x D pushforward are the
         reference's NumPy / SciPy calls on the host."""
+        if self.adaptation_map_type == 'cross-terms':
+            return self.adaptation_cross_terms(*coeffs)                                                  # (TM:642)
         if self.adaptation_map_type != 'separable':
             raise Exception("Currently, only adaptation_map_type = 'cross-terms' is implemented.")      # (TM:648, sic)
         import scipy.stats
@@ -1023,6 +1024,110 @@ class transport_map():
         self._respecify(monotone, nonmonotone)
         self.optimize()
         self.maporders = maporders
+
+    def _respecify_component(self, k, monotone_k, nonmonotone_k):
+        """New term lists for component k only (the reference's function_constructor_alternative(k = k), TM:1304-1310):
+        the other components keep their coefficients."""
+        keep = ([np.array(c, copy=True) for c in self.coeffs_mon], [np.array(c, copy=True) for c in self.coeffs_nonmon])
+        mon, non = copy.deepcopy(self.monotone), copy.deepcopy(self.nonmonotone)
+        mon[k], non[k] = copy.deepcopy(monotone_k), copy.deepcopy(nonmonotone_k)
+        self._respecify(mon, non)
+        for j in range(self.D):
+            if j != k:
+                self.coeffs_mon[j], self.coeffs_nonmon[j] = keep[0][j], keep[1][j]
+
+    def adaptation_cross_terms(self, increment=1E-6, chronicle=False):
+        """TM:4575-4950 (integrated rectifier): per component a multi-index set grows one cell per round.  Active cells
+        propose their axis neighbours; a proposal is admissible when all its lower neighbours are active (its proposal
+        count, boundary coordinates counted as given, reaches the number of variables); every admissible cell is scored
+        by a one-sided finite difference of the objective in its new coefficient, the best one is added and the
+        component is re-optimised (L-BFGS-B on the objective alone, gradients by SciPy's finite differences, as the
+        reference calls it).  Cell (i_0, ..., i_k) is the term [0]*i_0 + ... + [k]*i_k (+ 'HF'); cells with i_k > 0 are
+        monotone terms.  The bookkeeping that carries coefficients over - positions in the order of np.where over the
+        index set, not in [nonmonotone | monotone] order - is the reference's and is kept."""
+        from scipy.optimize import minimize
+        hf = self.polynomial_type.lower() == 'hermite function'
+
+        def cell_term(cell):
+            term = []
+            for var, order in enumerate(cell):
+                term += [int(var)] * int(order)
+            return term + ['HF'] if (hf and len(term) > 0) else term
+
+        def lists_of(M):
+            mono, nonmono, proposed, original = [], [], [], []
+            for pos, cell in enumerate(np.asarray(np.where(M != 0)).T):
+                (proposed if M[tuple(cell)] < 0 else original).append(pos)
+                (mono if cell[-1] > 0 else nonmono).append(cell_term(cell))
+            return mono, nonmono, proposed, original
+
+        history = {}
+        for k in range(self.D):
+            nvar = k + 1 + self.skip_dimensions
+            M = np.zeros(tuple([self.adaptation_max_order + 1] * nvar), dtype=int)
+            M[tuple([0] * nvar)] = 1
+            M[tuple([0] * (nvar - 1) + [1])] = 1
+            self.multi_index_matrix = M
+            coeffs = np.asarray(list(copy.copy(self.coeffs_nonmon[k])) + list(copy.copy(self.coeffs_mon[k])))
+            div = len(self.coeffs_nonmon[k])
+            opt = minimize(method='BFGS', fun=self.objective_function, jac=self.objective_function_jacobian, x0=coeffs,
+                           args=(k, div))
+            coeffs = copy.copy(opt.x)
+            self.coeffs_nonmon[k], self.coeffs_mon[k] = copy.copy(coeffs[:div]), copy.copy(coeffs[div:])
+            rounds = 0
+            history[k] = {}
+            while True:
+                rounds += 1
+                for cell in np.asarray(np.where(M > 0)).T:
+                    for ax in range(nvar):
+                        for step in (-1, +1):
+                            if 0 <= cell[ax] + step < self.adaptation_max_order + 1:
+                                nb = list(cell)
+                                nb[ax] += step
+                                if M[tuple(nb)] <= 0:
+                                    M[tuple(nb)] -= 1
+                if len(np.asarray(np.where(M < 0)).T) == 0:
+                    break
+                for cell in np.asarray(np.where(M < 0)).T:
+                    for val in cell:
+                        if val == 0:
+                            M[tuple(cell)] -= 1
+                candidates = np.asarray(np.where(M <= -nvar)).T
+                if self.verbose:
+                    print(M)
+                coeffs = copy.copy(np.asarray(list(copy.copy(self.coeffs_nonmon[k])) + list(copy.copy(self.coeffs_mon[k]))))
+                obj_ref = self.objective_function(coeffs=coeffs, k=k, div=div)
+                grads = np.zeros(len(candidates))
+                for ci, cell in enumerate(candidates):
+                    M[M < 0] = 0
+                    M[tuple(cell)] = -1
+                    mono, nonmono, _, orig = lists_of(M)
+                    self._respecify_component(k, mono, nonmono)
+                    trial = np.ones(len(nonmono) + len(mono)) * self.coeffs_init + increment
+                    trial[orig] = copy.copy(coeffs)
+                    div = len(nonmono)
+                    grads[ci] = (self.objective_function(coeffs=trial, k=k, div=div) - obj_ref) / increment
+                best = np.where(np.abs(grads) == np.max(np.abs(grads)))[0][0]
+                M[M < 0] = 0
+                added = candidates[best]
+                M[tuple(added)] = -1
+                mono, nonmono, _, orig = lists_of(M)
+                M[tuple(added)] = 1
+                start = np.ones(len(nonmono) + len(mono)) * self.coeffs_init
+                start[orig] = copy.copy(coeffs)
+                div = len(nonmono)
+                self._respecify_component(k, mono, nonmono)
+                opt = minimize(method='L-BFGS-B', fun=self.objective_function, x0=start, args=(k, div))
+                coeffs = copy.copy(opt.x)
+                self.coeffs_nonmon[k], self.coeffs_mon[k] = copy.copy(coeffs[:div]), copy.copy(coeffs[div:])
+                history[k][rounds] = dict(monotone=copy.deepcopy(self.monotone[k]), nonmonotone=copy.deepcopy(self.nonmonotone[k]),
+                                          coeffs_nonmon=copy.copy(self.coeffs_nonmon[k]), coeffs_mon=copy.copy(self.coeffs_mon[k]),
+                                          multi_index_matrix=copy.copy(M))
+                if rounds >= self.adaptation_max_iterations:
+                    break
+        if chronicle:
+            import pickle
+            pickle.dump(history, open('dictionary_adaptation_chronicle.p', 'wb'))
 
     def _sep_objective_fast(self, A, k):
         """separable_objective(., A, k) for the optimiser's inner loop: everything that does not depend on the
