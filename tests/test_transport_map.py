@@ -269,3 +269,22 @@ def test_entf_cycles_match_reference(backend):
         assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
         ens = entf.rk4(Xa, 0.05, 2)
         assert relerr(ens, npz['forecast_%d' % t]) < 1e-6
+
+
+def test_ents_backward_smoother_matches_reference(backend):
+    """Ensemble Transport Smoother (example_07.py:368-465): the 6-column block map (skip_dimensions = 3, probabilist's
+    Hermite polynomials with 'HF' terms, L2), three backward steps of reset -> optimize -> map -> inverse_map with
+    X_star, against the reference's smoothing ensembles."""
+    from triangular_transport_toolbox_amd import entf, specs
+    npz, desc = load_case('ents')
+    mon, non = specs.ents_smoother_spec(int(npz['maxorder']))
+    assert mon == desc['monotone'] and non == desc['nonmonotone']
+    tm = entf.make_smoother_map(npz['analyses'].shape[1], maxorder=int(npz['maxorder']), lmbda=float(npz['lmbda']))
+    assert tm.D == 3 and tm.skip_dimensions == 3
+    Xs = entf.smooth(tm, npz['forecasts'], npz['analyses'])
+    assert Xs.shape == npz['smoothed'].shape
+    for t in range(len(Xs)):
+        assert relerr(Xs[t], npz['smoothed'][t]) < 1e-6
+    for k in range(tm.D):                     # (coefficients of the last update, t = 0)
+        assert relerr(tm.coeffs_mon[k], npz['last_coeffs_mon_%d' % k]) < 1e-4
+        assert relerr(tm.coeffs_nonmon[k], npz['last_coeffs_nonmon_%d' % k]) < 1e-4

@@ -1,6 +1,6 @@
 """
-Ensemble Transport Filter harness (the caller of the hot path in
-Examples C/Example 06: example_06.py:252-328).
+Ensemble Transport Filter / Smoother harnesses (the callers of the hot path in Examples C: the filter of
+example_06.py:252-328 and the backward smoother of example_07.py:424-465).
 
 One assimilation cycle = three one-observation-at-a-time composite-map updates
 (`reset -> optimize -> map -> inverse_map` with the observed value as X_star) followed by an RK4
@@ -61,3 +61,30 @@ def assimilate(tm, ensemble, observation, noises):
         ret = tm.inverse_map(X_star=Y_star, Z=Z_pushforward)
         Xa = ret[:, perm]
     return Xa
+
+
+def make_smoother_map(N, maxorder=3, lmbda=0.05, D=3, rng=None, **kwargs):
+    """The 2D-column backward-smoothing map of example_07.py:368-408 (dummy samples until the first reset)."""
+    from .transport_map import transport_map
+    mon, non = specs.ents_smoother_spec(maxorder, D)
+    rng = np.random.default_rng(0) if rng is None else rng
+    return transport_map(monotone=mon, nonmonotone=non, X=rng.uniform(size=(N, 2 * D)),
+                         polynomial_type="probabilist's hermite", monotonicity='separable monotonicity',
+                         regularization='l2', regularization_lambda=lmbda, verbose=False, **kwargs)
+
+
+def smooth(tm, forecasts, analyses):
+    """Backward pass of the Ensemble Transport Smoother (example_07.py:424-465).
+    forecasts[t], analyses[t]: N x D filtering forecast / analysis ensembles of time t (t = 0..T-1).  Returns the
+    smoothing ensembles, T x N x D: the last one is the last filtering analysis; going backward, the joint ensemble
+    (forecast at t+1, analysis at t) is mapped and conditioned on the smoothing samples of t+1
+    (reset -> optimize -> map -> inverse_map with X_star)."""
+    analyses = np.asarray(analyses, dtype=float)
+    Xs = np.array(analyses, copy=True)
+    for t in range(len(analyses) - 2, -1, -1):
+        map_input = copy.copy(np.column_stack((forecasts[t + 1], analyses[t])))
+        tm.reset(copy.copy(map_input))
+        tm.optimize()
+        Z_pushforward = tm.map(map_input)
+        Xs[t] = tm.inverse_map(X_star=copy.copy(Xs[t + 1]), Z=Z_pushforward)
+    return Xs

@@ -10,6 +10,7 @@ part of the contract):
 * spiral (C1/C2a)      - Examples A/Example 01/example_01.py:121-170
 * temperature (C2b/C3) - Examples B/Example 03/example_03.py:108-159
 * EnTF filter map (C4) - Examples C/Example 06/example_06.py:186-214
+* EnTS smoother map    - Examples C/Example 07/example_07.py:368-392
 * banded d=40 (C5)     - BASELINE.md section 3 (synthetic, no reference script)
 
 Only NumPy/SciPy host code lives here; nothing in this file touches the GPU.
@@ -132,6 +133,21 @@ def entf_filter_spec(maxorder):
             ['LET 1'] + ['iRBF 1'] * (maxorder - 1) + ['RET 1'],
             [[2]],
             [[3]]]
+    return monotone, nonmonotone
+
+
+def ents_smoother_spec(maxorder, D=3):
+    """The 2D-column backward-smoothing map of example_07.py:368-392 (X is N x 2D: forecast at s+1, analysis at s;
+    skip_dimensions = D): dense nonmonotone blocks over all earlier columns, linear monotone terms."""
+    def block(cols):
+        out = [[]]
+        for j in cols:
+            out.append([j])
+            if maxorder > 1:
+                out += [[j] * od + ['HF'] for od in range(1, maxorder + 1)]
+        return out
+    nonmonotone = [block(range(D + k)) for k in range(D)]
+    monotone = [[[D + k]] for k in range(D)]
     return monotone, nonmonotone
 
 
