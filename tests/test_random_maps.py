@@ -159,5 +159,8 @@ def test_random_integrated_maps(backend, seed):
         div = len(tm.coeffs_nonmon[k])
         c = np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k]))
         J, Jo = tm.objective_function(c.copy(), k, div), om.objective_function(c.copy(), k, div)
+        if not np.isfinite(Jo):                       # (plain high-order polynomials under the exponential rectifier overflow)
+            assert not np.isfinite(J)
+            continue
         assert abs(J - Jo) <= 1e-10 * (1 + abs(Jo))
         assert relerr(tm.objective_function_jacobian(c.copy(), k, div), om.objective_function_jacobian(c.copy(), k, div)) < 1e-9
