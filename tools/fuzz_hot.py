@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""One-off sweep: random banded separable maps at large N through the loader-wave hot kernels (k_forward_hl, k_inverse_hl)
+against the oracle on a subset of the samples."""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings('ignore')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.ttm_oracle import OracleMap  # noqa: E402
+from tests.test_uform import _synthetic_separable  # noqa: E402
+from tests.util import relerr  # noqa: E402
+from triangular_transport_toolbox_amd.transport_map import transport_map  # noqa: E402
+
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+fails = 0
+for seed in range(lo, hi):
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.integers(4, 11))
+    band = int(rng.integers(1, 5))
+    hf_order = int(rng.integers(2, 8))
+    plain_order = int(rng.integers(1, min(hf_order, 7) + 1))
+    n_irbf = int(rng.integers(0, 5))
+    N = int(rng.integers(65536, 180000))
+    L = np.tril(rng.standard_normal((D, D)) * 0.4) + np.eye(D)
+    X = rng.standard_normal((N, D)) @ L.T + 0.3 * rng.standard_normal((N, D)) ** 2
+    mon, non = _synthetic_separable(D, band, hf_order, plain_order, n_irbf)
+    kw = dict(monotonicity='separable monotonicity')
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(D):
+        cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
+    sub = np.concatenate((np.arange(0, 700), rng.integers(0, N, 600), np.arange(N - 700, N)))
+    tag = 'seed %d D %d band %d hf %d plain %d irbf %d N %d cls %s ng %s' % (seed, D, band, hf_order, plain_order, n_irbf, N,
+                                                                            tm._cm.u_h_cls, tm._cm.u_h_ng)
+    try:
+        Z = tm.map(X)
+        e1 = relerr(Z[sub], om.map(X[sub]))
+        p = tm.evaluate_pullback_density(X)
+        po = om.evaluate_pullback_density(X[sub])
+        ok = np.isfinite(po) & (po > 1e-300)
+        e2 = relerr(p[sub][ok], po[ok])
+        Zin = rng.standard_normal((N, D))
+        Xi = tm.inverse_map(Zin)
+        Xo = om.inverse_map(Zin[sub])
+        fin = np.isfinite(Xo).all(axis=1) & (np.abs((Xo - om.X_mean) / om.X_std) < 9.9).all(axis=1)
+        e3 = relerr(Xi[sub][fin], Xo[fin])
+        bad = e1 > 1e-11 or e2 > 1e-9 or e3 > 1e-9           # (targets outside a table's range are left out of e3)
+        print(('FAIL ' if bad else 'ok   ') + tag, 'map %.1e pullback %.1e inverse %.1e' % (e1, e2, e3), flush=True)
+        fails += bad
+    except Exception as exc:          # noqa: BLE001
+        fails += 1
+        print('EXC  ' + tag, repr(exc)[:200], flush=True)
+print('seeds', lo, hi, 'fails', fails)
