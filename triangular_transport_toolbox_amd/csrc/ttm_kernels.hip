@@ -1257,7 +1257,11 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         // last-bit difference between this reciprocal and the division of the index kernel does not matter
         const double scale = (double)nb * approx_rcp(hi - lo);           // (2^-23 of a bucket: the search starts a bucket early)
         const bool use_bkt = scale > 0.0 && scale < 1.0e300;
+#ifdef TTM_EXPERIMENT_INV_NO_OFFSET      // timing experiments only (results are wrong): marginal cost of the parts
+        R off(rec[7]);
+#else
         const R off = h_offset<NG, DB, DA, GS, R, Store>(rec, cst);
+#endif
         double tg[NS];
         int a[NS];
 #pragma unroll
@@ -1280,7 +1284,15 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
         // np.searchsorted(xs, target) (left) = a + #{entries from a on that are < target}: both samples scan four
         // entries per round together (a finished sample re-reads its last group); the table is followed by +inf sentinels
         int pos[NS];
+#ifdef TTM_EXPERIMENT_INV_NO_SCAN
+#pragma unroll
+        for (int e = 0; e < NS; ++e) pos[e] = a[e] + 1;
+#endif
+#ifdef TTM_EXPERIMENT_INV_NO_SCAN
+        for (int round = 0; round < 0; ++round) {
+#else
         for (int round = 0; round < 4096; ++round) {
+#endif
             int cmax = 0;
 #pragma unroll
             for (int e = 0; e < NS; ++e) {
@@ -1316,7 +1328,11 @@ __global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const
 #endif
             r.v[e] = slope * (tg[e] - x_lo) + y_lo;
         }
+#ifdef TTM_EXPERIMENT_INV_NO_PUTEXP
+        { const int put2 = ((cint_p)rec)[0]; if (put2 >= 0) { cst.set(put2, r); cst.set(put2 + 1, r * rec[7]); } }
+#else
         h_put(rec, cst, r);
+#endif
         {
             const int kc = ((cint_p)rec)[3];
 #pragma unroll
