@@ -1998,10 +1998,19 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT");
             const int hcw = TTM_HL_FWD_CW(logdet != nullptr);            // evaluating waves per workgroup of the hot kernel
             const int rows = hot ? hcw * 64 * hNS : TTM_UL_ROWS;
-            auto lds_for = [&](int xl) { return ((size_t)(xl + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * rows + TTM_EXPQ_TABLE_LEN) * 8; };
-            if (hot && xlead == 3 && !getenv("TTM_U_XLEAD") && (size_t)(160 * 1024) / lds_for(2) > (size_t)(160 * 1024) / lds_for(3))
-                xlead = 2;                                               // a shallower column ring when it buys a workgroup per CU
-            const size_t lds_ul = lds_for(xlead);
+            auto lds_for = [&](int xl, int tl) { return ((size_t)(xl + 1) * rows + (size_t)(tl + 1) * tab_slot + (size_t)2 * ways * rows + TTM_EXPQ_TABLE_LEN) * 8; };
+            if (hot && !getenv("TTM_U_XLEAD") && !getenv("TTM_U_TLEAD")) {
+                // shallower rings when they buy a workgroup per CU (more independent phases per CU outweigh the look-ahead:
+                // 0.155 -> 0.152 ms at C5 with five workgroups and one-step rings)
+                static const int cand[4][2] = {{3, 2}, {2, 2}, {2, 1}, {1, 1}};
+                size_t best = 0;
+                for (int c = 0; c < 4; ++c) {
+                    size_t w = (size_t)(160 * 1024) / lds_for(cand[c][0], cand[c][1]);
+                    if (w > (size_t)(32 / (hcw + 2))) w = 32 / (hcw + 2);
+                    if (w > best) { best = w; xlead = cand[c][0]; tlead = cand[c][1]; }
+                }
+            }
+            const size_t lds_ul = lds_for(xlead, tlead);
             const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
