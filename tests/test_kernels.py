@@ -224,3 +224,38 @@ def test_full_size_c5_properties():
     ss = tm._empty(N)
     tm.forward_device(tm._Xs, N, sumsq=ss)
     assert relerr(ss.cpu().numpy(), np.sum(Z * Z, axis=1)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_c_abi_reports_bad_arguments_instead_of_launching():
+    """Every entry point validates its arguments on the host and returns a negative TTM_E_* code with a message
+    (include/ttm.h): no kernel is launched on a null pointer, an empty ensemble, a leading dimension shorter than N or
+    a component range outside the map."""
+    import ctypes
+    from triangular_transport_toolbox_amd import _capi
+    tm = small_map()
+    lib = tm._lib
+    coef = tm._pack_coeffs()
+    N = tm._N
+    Z = tm._cols(tm.D, N)
+    st = tm._stream()
+    p, c, f, X = tm._pp, tm._ptr(coef), tm._ptr(coef._ttm_fold), tm._ptr(tm._Xs)
+    ldx = tm._Xs.shape[1]
+
+    def expect(rc, code):
+        assert rc == code, (rc, lib.ttm_last_error_string().decode())
+        assert len(lib.ttm_last_error_string().decode()) > 0
+
+    expect(lib.ttm_forward(p, c, f, None, ldx, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st), -1)       # null X
+    expect(lib.ttm_forward(p, c, f, X, ldx, 0, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st), -1)          # N = 0
+    expect(lib.ttm_forward(p, c, f, X, N - 1, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st), -1)        # ldx < N
+    expect(lib.ttm_forward(p, c, f, X, ldx, N, 0, tm.D + 1, tm._ptr(Z), Z.shape[1], None, None, None, st), -1)      # k1 > D
+    expect(lib.ttm_forward(p, c, f, X, ldx, N, 2, 1, tm._ptr(Z), Z.shape[1], None, None, None, st), -1)             # k0 > k1
+    iters = tm._zeros(tm.D, dtype=__import__('torch').int32)
+    expect(lib.ttm_inverse_bisect(p, c, f, 0, tm.D, None, Z.shape[1], X, ldx, N, ctypes.c_void_p(iters.data_ptr()), None, st), -1)
+    expect(lib.ttm_inverse_newton(p, c, f, 0, tm.D, tm._ptr(Z), Z.shape[1], X, ldx, N, None, st), -1)
+    expect(lib.ttm_basis(p, tm.D, 0, X, ldx, N, tm._ptr(Z), Z.shape[1], st), -1)                                     # component out of range
+    with pytest.raises(_capi.TTMError, match='libttm error -1'):
+        _capi.check(lib.ttm_forward(p, c, f, None, ldx, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st))
+    # ... and a valid call still works afterwards
+    _capi.check(lib.ttm_forward(p, c, f, X, ldx, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st))
