@@ -50,8 +50,11 @@ for seed in range(lo, hi):
         Xo = om.inverse_map(Zin[sub])
         fin = np.isfinite(Xo).all(axis=1) & (np.abs((Xo - om.X_mean) / om.X_std) < 9.9).all(axis=1)
         e3 = relerr(Xi[sub][fin], Xo[fin])
-        bad = e1 > 1e-11 or e2 > 1e-9 or e3 > 1e-9           # (targets outside a table's range are left out of e3)
-        print(('FAIL ' if bad else 'ok   ') + tag, 'map %.1e pullback %.1e inverse %.1e' % (e1, e2, e3), flush=True)
+        # conditioning: the same comparison through the forward map (high plain orders make offsets of ~1e3 and flat
+        # table stretches, where a 1e-13 difference of the target moves x by 1e-8)
+        e4 = relerr(om.map(Xi[sub][fin]), om.map(Xo[fin]))
+        bad = e1 > 1e-11 or e2 > 1e-9 or (e3 > 1e-9 and e4 > 1e-10)   # (targets outside a table's range are left out)
+        print(('FAIL ' if bad else 'ok   ') + tag, 'map %.1e pullback %.1e inverse %.1e (through S: %.1e)' % (e1, e2, e3, e4), flush=True)
         fails += bad
     except Exception as exc:          # noqa: BLE001
         fails += 1
