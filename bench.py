@@ -12,9 +12,14 @@ data-path collective).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C5|C2a|C2b|C3]
 
-prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel
-(forward map: algorithmic bytes 8 N (d_used + D)) and a
-`cpu_baseline` object (the CPU oracle, one process per host core on a bounded sample each, rank 0, N=1).
+prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel - whichever of the two map
+kernels has the longer measured launch (today the table inverse; algorithmic bytes 8 N (d_used + D) forward,
+8 N (2 D + E) inverse) - the fractions of the other kernel and of the pair, an `fp64` block
+(arithmetic rate next to the byte rate) and a `cpu_baseline` object (rank 0, N=1).
+
+`--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts the N ranks itself: N fresh
+child processes, one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, before this
+process has touched the GPU; rank 0's JSON line is relayed.  Under torchrun (WORLD_SIZE set) every process is a rank.
 The headline workload is C5 (BASELINE.json configs[4], the one north_star's target is quoted on; it fits one GPU);
 at N=1 the same line carries, under `other_configs`, the secondary numbers of the other single-GPU configurations
 (configs[1] = C2b / C2a spiral d=2 order 5 N=1e6 forward + inverse + pullback, configs[2] = C3 d=4 order 4 N=5e5 with
@@ -32,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6      # vector fp64: half the 157.3 TFLOP/s fp32 vector peak of the same guide (16 lanes/clk/SIMD)
 
 WORKLOADS = {
     # name: (config, N, golden coefficient fixture, description)
@@ -75,11 +81,7 @@ def d_used(tm):
     return len(cols)
 
 
-def _cpu_worker(args):
-    """One host core: the CPU oracle on its own n-sample ensemble of the workload (forward + inverse)."""
-    workload, n, seed = args
-    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
-        os.environ[v] = '1'
+def _oracle_for(workload, n, seed):
     from oracle.ttm_oracle import OracleMap      # timed baseline only
     from triangular_transport_toolbox_amd import specs
     cfgname, _, fixture, _ = WORKLOADS[workload]
@@ -87,6 +89,15 @@ def _cpu_worker(args):
     Xc = cfg['sampler'](n, seed=seed)
     om = OracleMap(X=Xc, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], **cfg['kwargs'])
     om.coeffs_mon, om.coeffs_nonmon = load_coeffs(fixture, om.D)
+    return om, Xc
+
+
+def _numpy_leg(args):
+    """One host core: the NumPy oracle on its own n-sample ensemble of the workload (forward + inverse)."""
+    workload, n, seed = args
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[v] = '1'
+    om, Xc = _oracle_for(workload, n, seed)
     t0 = time.perf_counter()
     Z = om.map(Xc)
     t1 = time.perf_counter()
@@ -95,28 +106,56 @@ def _cpu_worker(args):
     return n * om.D, t1 - t0, t2 - t1
 
 
-def cpu_baseline(workload, n_cpu, cores):
-    """The CPU oracle (NumPy restatement of the reference CPU path), one process per host core, every process on
-    its own n_cpu-sample ensemble - the sample-parallel use of the host the reference's `workers` pool
-    (TM:2789-2874) aims at.  Must run BEFORE this process initialises the GPU (the pool forks)."""
+def cpu_baseline(workload, seconds):
+    """The CPU baseline beside the GPU number, two legs, each bounded to about `seconds`:
+    (1) the C++/OpenMP restatement of the reference's forward map + table inverse (oracle/ttm_oracle_omp.cpp) on ALL
+        usable host cores - `value`; separable workloads only;
+    (2) the NumPy oracle (oracle/ttm_oracle.py, the reference's own vectorised NumPy formulation) on one core, in a
+        forked worker so that its thread pools are pinned to one thread.
+    Must run BEFORE this process initialises the GPU (leg 2 forks)."""
     import multiprocessing as mp
-    seeds = [7000 + 13 * i for i in range(cores)]
-    t0 = time.perf_counter()
-    if cores > 1:
-        with mp.get_context('fork').Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(workload, n_cpu, sd) for sd in seeds])
-    else:
-        res = [_cpu_worker((workload, n_cpu, seeds[0]))]
-    wall = time.perf_counter() - t0
-    evals = sum(r[0] for r in res)
-    busy = max(r[1] + r[2] for r in res)
-    return dict(value=evals / busy, unit='map-evals/s', cores=cores, kind='port',
-                sample='oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), %d processes x %d samples of '
-                       'the workload each, forward+inverse; slowest process %.2f s (forward %.2f s, inverse %.2f s on '
-                       'average), %.1f s wall including start-up; one process alone: %.3g map-evals/s'
-                       % (cores, n_cpu, busy, float(np.mean([r[1] for r in res])), float(np.mean([r[2] for r in res])), wall,
-                          float(np.mean([r[0] / (r[1] + r[2]) for r in res]))),
-                host_cores_available=os.cpu_count())
+    from oracle import omp
+    cores, core_info = omp.usable_cores()
+    out = {'unit': 'map-evals/s', 'kind': 'port', 'host': core_info}
+    # leg 2: NumPy, one core; sample sized from a short calibration run
+    with mp.get_context('fork').Pool(1) as pool:
+        n0 = {'C5': 20000, 'C3': 50000, 'C2b': 100000, 'C2a': 500}[workload]
+        ev, tf, ti = pool.map(_numpy_leg, [(workload, n0, 7000)])[0]
+        n1 = int(max(n0, min(20 * n0, n0 * seconds / max(tf + ti, 1e-3))))
+        ev, tf, ti = pool.map(_numpy_leg, [(workload, n1, 7013)])[0]
+    out['numpy_1core'] = {'value': ev / (tf + ti), 'cores': 1, 'samples': n1, 'forward_s': tf, 'inverse_s': ti,
+                          'what': 'oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), one process, one thread'}
+    if workload == 'C2a':
+        out.update(value=out['numpy_1core']['value'], cores=1,
+                   sample='NumPy oracle, %d samples of the workload, forward + bisection inverse, one core '
+                          '(the OpenMP leg restates the separable path only)' % n1)
+        return out
+    # leg 1: C++ / OpenMP on all usable cores
+    n0 = 200000
+    om, Xc = _oracle_for(workload, n0, 7026)
+    m = omp.OmpMap(om)
+    Xs = (Xc - om.X_mean) / om.X_std
+
+    def run(Xs_):
+        t0 = time.perf_counter()
+        Z = m.forward_std(Xs_, cores)
+        t1 = time.perf_counter()
+        m.inverse_std(Z, cores)
+        return t1 - t0, time.perf_counter() - t1
+    tf, ti = run(Xs)                                  # calibration (also warms the thread pool)
+    reps = int(max(1, min(200, seconds / max(tf + ti, 1e-4))))
+    t_f = t_i = 0.0
+    for _ in range(reps):
+        a, b = run(Xs)
+        t_f += a
+        t_i += b
+    out.update(value=reps * n0 * om.D / (t_f + t_i), cores=cores,
+               sample='oracle/ttm_oracle_omp.cpp (C++/OpenMP restatement of the reference forward map TM:2391-2567 + table '
+                      'inverse TM:3987-4084, term by term, libm erf/exp, fresh 1001-point tables per call), %d threads, '
+                      '%d passes over a %d-sample ensemble of the workload: forward %.2f s, inverse %.2f s'
+                      % (cores, reps, n0, t_f, t_i),
+               forward_s=t_f, inverse_s=t_i, samples=reps * n0)
+    return out
 
 
 def other_configs(torch, names, steps=40):
@@ -197,6 +236,91 @@ def other_configs(torch, names, steps=40):
     return out
 
 
+def entf_config(torch, N=100000, cycles=200):
+    """BASELINE configs[3] (C4): Lorenz-63 Ensemble Transport Filter, Example-06 map (4 columns, D = 3), N = 1e5:
+    `cycles` assimilation cycles timed end to end, each = three one-observation updates
+    (reset -> optimize -> map -> inverse_map with the observation as X_star) + the RK4 forecast."""
+    from triangular_transport_toolbox_amd import entf
+    rng = np.random.default_rng(0)
+    truth = np.array([1.0, 1.0, 25.0])
+    ens = rng.standard_normal((N, 3)) * [8, 9, 8] + [0, 0, 25]
+    flt = entf.Filter(N, seed=0) if hasattr(entf, 'Filter') else None
+    if flt is not None:
+        return flt.benchmark(ens, truth, cycles)
+    tm = entf.make_filter_map(N)
+
+    def cycle(ens, truth):
+        truth = entf.rk4(truth[None, :], 0.05, 2)[0]
+        obs = truth + 2.0 * rng.standard_normal(3)
+        ens = entf.rk4(ens, 0.05, 2)
+        noises = [2.0 * rng.standard_normal(N) for _ in range(3)]
+        return entf.assimilate(tm, ens, obs, noises), truth
+    for _ in range(3):
+        ens, truth = cycle(ens, truth)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        ens, truth = cycle(ens, truth)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return dict(workload='C4: Lorenz-63 EnTF, Example-06 map (4 columns, D = 3, order 3, L2 0.05), host-driven loop', N=N,
+                cycles=cycles, ms_per_cycle=1e3 * el / cycles, updates_per_cycle=3,
+                rmse_last=float(np.sqrt(np.mean((ens.mean(axis=0) - truth) ** 2))))
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON line.
+    Runs before this process has touched the GPU (torch.cuda.device_count() does not initialise it); the children are
+    new interpreters, never an exec of a process that holds the device."""
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if args.backend == 'nccl' and ndev < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible - RCCL needs one GPU per rank '
+                         "('--backend gloo' rehearses the multi-rank path with several ranks per GPU)" % (args.gpus, ndev))
+    if ndev < 1:
+        raise SystemExit('bench.py: no HIP device visible')
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit('bench.py: rank exit codes %s' % rcs)
+
+
+def flops_per_eval(tm):
+    """fp64 operations per component evaluation of the two U-form map kernels, counted from the arithmetic they
+    execute (FMA = 2): forward = spline of the summed special terms (degree TTM_U_DEG = 11 Horner + 4 of index
+    arithmetic) + exp(-x_k^2/4) of the column cache (degree-12 series + reduction, 2 x 15) + per nonmonotone group the
+    two Horner passes of its degree class and the combination; inverse = the groups + bucket arithmetic (4) + four
+    compares + interpolation (division: 10) + exp.  Returns (forward, inverse) averaged over the components, or None
+    for maps without a U-form."""
+    cm = tm._cm
+    if not getattr(cm, 'u_enabled', False) or not getattr(cm, 'u_h_cls', 0):
+        return None
+    db, da = {1: (3, 1), 2: (5, 5), 3: (7, 7)}[int(cm.u_h_cls)]
+    ngrp = float(np.mean(np.asarray(cm.ucomp).reshape(-1)[:cm.D * 8].reshape(cm.D, 8)[:, 2]))
+    grp = ngrp * (2 * db + 2 * da + 3)
+    fwd = grp + (2 * 11 + 4) + 30
+    inv = grp + 4 + 4 + (10 + 6) + 30
+    return fwd, inv
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -204,7 +328,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--prewarm-seconds', type=float, default=2.0,
                     help='untimed back-to-back steps before the warm-up, until the chip holds its clock under load '
-                         '(MI355X_MICROARCH.md, DVFS item 6: >= 2 s); 0 = none')
+                         '(MI355X_MICROARCH.md, DVFS item 6: >= 2 s); 0 = none.  The same K steps timed WITHOUT it are '
+                         'reported as cold_ms_per_step')
     ap.add_argument('--workload', default='C5', choices=sorted(WORKLOADS))
     ap.add_argument('--n', '--samples', dest='n', type=int, default=0, help='override the ensemble size (testing only)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -212,26 +337,30 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-optimize', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true',
-                    help='skip the secondary numbers of the other single-GPU BASELINE configurations (C2b, C2a, C3)')
-    ap.add_argument('--cpu-samples', type=int, default=0, help='samples per host process of the CPU baseline')
-    ap.add_argument('--cpu-cores', type=int, default=0, help='host processes of the CPU baseline (default 1)')
+                    help='skip the secondary numbers of the other single-GPU BASELINE configurations (C2b, C2a, C3, C4)')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of each CPU baseline leg')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return spawn_ranks(args)                 # (before anything touches the GPU)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
-        # first, before anything touches the GPU: the host baseline forks one process per core
-        n_cpu = args.cpu_samples or {'C5': 300000, 'C3': 500000, 'C2b': 500000, 'C2a': 5000}[args.workload]
-        # one process by default: on the one-GPU boxes of this pool 8 (64) concurrent oracle processes took 7x (47x)
-        # longer each - the aggregate stayed at 1.3e6 (1.5e6) map-evals/s against 1.1e6 for one process alone
-        cores = args.cpu_cores or 1
-        cpu = cpu_baseline(args.workload, n_cpu, cores)
+        # first, before anything touches the GPU (the NumPy leg forks a worker)
+        cpu = cpu_baseline(args.workload, args.cpu_seconds)
     import torch
-    local_dev = local_rank % max(1, torch.cuda.device_count())       # (rehearsals put several ranks on one GPU)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py: no HIP device visible')
+    if world > 1 and args.backend == 'nccl' and ndev < world:
+        raise SystemExit('bench.py: %d ranks over RCCL need %d GPUs, %d visible' % (world, world, ndev))
+    local_dev = local_rank % ndev                                     # (gloo rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local_dev)
     dist = None
     if world > 1:
@@ -254,15 +383,34 @@ def main():
         tm.forward_device(Xs, N, coef=coef, Z=Z)
         tm.inverse_device(Z, N, coef=coef, X=Xinv)
 
+    def step_uncached():
+        # what a caller pays who changes the coefficients between calls (and what the reference does on every
+        # inverse_map, TM:4047-4058): pack + fold + U-form build + table build + index, then the two lookups
+        c = tm._pack_coeffs()
+        tm.forward_device(Xs, N, coef=c, Z=Z)
+        tm.inverse_device(Z, N, coef=c, X=Xinv)
+
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # After any idle gap of a millisecond or more (and from a cold start) the chip runs this workload 10-30 % slower
-    # for the next ~50 launches (20 ms) before it holds its clock again (tools/ramp_probe.py: forward launches of
-    # 0.17-0.20 ms after a 1-100 ms pause against 0.153 ms back to back; a bare stream synchronisation costs nothing).
-    # So the card is first kept busy with the same steps, untimed, for --prewarm-seconds, the W warm-up steps follow
+    def timed(fn, n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync()
+        return time.perf_counter() - t0
+
+    # (a) the contract's W + K steps straight from the cold start (no pre-warm): cold_ms_per_step
+    step()                                           # (builds the tables kept with `coef`; first-launch costs)
+    for _ in range(args.warmup):
+        step()
+    cold = timed(step, args.steps)
+    # (b) After any idle gap of a millisecond or more (and from a cold start) the chip runs this workload 10-30 % slower
+    # for the next ~50 launches (20 ms) before it holds its clock again (tools/ramp_probe.py).  For the headline the
+    # card is first kept busy with the same steps, untimed, for --prewarm-seconds, the W warm-up steps follow
     # without a pause, and only the barrier + synchronisation of the contract separates them from the K timed steps.
     # What is timed is unchanged: exactly K full steps between barriers.
     prewarm_steps = 0
@@ -274,23 +422,17 @@ def main():
             torch.cuda.synchronize()
             prewarm_steps += 50
         if dist is not None:
-            # the ranks leave the time-based loop up to one batch apart; the one that waits at a barrier idles and would
-            # start its timed steps on the ramp.  Align them once, then give every rank the same number of steps, so
-            # that all arrive at the barrier in front of the timed region within a fraction of a millisecond
+            # the ranks leave the time-based loop up to one batch apart; align them once, then give every rank the same
+            # number of steps, so that all arrive at the barrier in front of the timed region together
             sync()
             for _ in range(150):
                 step()
             prewarm_steps += 150
     for _ in range(args.warmup):
         step()
-    sync()                                   # (nothing else between the warm-up and the timed steps: see above)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    # per-kernel timing of the dominant kernel (forward map) with HIP events on the launch stream, directly behind
-    # the timed steps (same clock state)
+    elapsed = timed(step, args.steps)
+    # per-kernel timing with HIP events on the launch stream, directly behind the timed steps (same clock state)
+    lib = tm._lib
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_inv = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for (a, b), (c, e) in zip(ev, ev_inv):
@@ -303,10 +445,19 @@ def main():
     torch.cuda.synchronize()
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     inv_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_inv]))
+    tm.forward_device(Xs, N, coef=coef, Z=Z)
+    fwd_kernel = lib.ttm_last_kernel().decode()
+    tm.inverse_device(Z, N, coef=coef, X=Xinv)
+    inv_kernel = lib.ttm_last_kernel().decode()
+    # (c) the un-cached step, same clock state
+    n_unc = max(5, min(args.steps, 50))
+    for _ in range(3):
+        step_uncached()
+    uncached = timed(step_uncached, n_unc)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed, cold, uncached], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, cold, uncached = [float(v) for v in t.tolist()]
     # round trip sanity inside the bench: S^{-1}(S(x)) == x up to the inverse's own accuracy
     err = float((Xinv[:, :N] - Xs[:, :N]).abs().max().item())
     extra = {}
@@ -341,6 +492,10 @@ def main():
             extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3'])
         except Exception as exc:                       # noqa: BLE001  (never fatal for the headline line)
             extra['other_configs_error'] = repr(exc)
+        try:
+            extra['other_configs']['C4'] = entf_config(torch)
+        except Exception as exc:                       # noqa: BLE001
+            extra['other_configs_C4_error'] = repr(exc)
     if world > 1 and not args.no_optimize:
         # optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
         # holds the same ensemble (seed of rank 0), optimises a strided subset of the components, coefficients are
@@ -359,18 +514,22 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             extra['optimize_component_sharded_s'] = float(t.item())
             extra['optimize_objective_total'] = float(tm2.objective_total)
+            tm = tm2
         except Exception as exc:                       # noqa: BLE001
             extra['optimize_component_sharded_error'] = repr(exc)
 
     if rank == 0:
         fwd_bytes = 8.0 * N * (du + D)
         inv_bytes = 8.0 * N * (2 * D)
-        achieved = fwd_bytes / (fwd_ms * 1e-3) / 1e9
-        traffic = None
+        ms_step = 1e3 * elapsed / args.steps
+        gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9          # noqa: E731
+        traffic = {}
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get(args.workload, {}).get('k_forward_hbm_bytes_per_launch')
+            traffic = json.load(open(tpath)).get(args.workload, {})
+        dominant = 'inverse' if inv_ms >= fwd_ms else 'forward'
+        dom_bytes, dom_ms, dom_kernel = (inv_bytes, inv_ms, inv_kernel) if dominant == 'inverse' else (fwd_bytes, fwd_ms, fwd_kernel)
+        achieved = gbps(dom_bytes, dom_ms)
         out = {
             'metric': 'map-evals/sec (forward+inverse, N samples x D comps)',
             'value': world * N * D * args.steps / elapsed,
@@ -378,7 +537,7 @@ def main():
             'n_gpus': world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps,
+            'ms_per_step': ms_step,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -386,18 +545,49 @@ def main():
             'data': 'synthetic',
             'config': {'workload': args.workload + ': ' + WORKLOADS[args.workload][3],
                        'N_per_gpu': N, 'D': D, 'columns': d, 'inverse': 'table' if separable else 'bisection',
-                       'layout': 'column-major resident in HBM', 'coefficients': 'reference-optimised (tests/golden)'},
+                       'layout': 'column-major resident in HBM', 'coefficients': 'reference-optimised (tests/golden)',
+                       'world_size': (dist.get_world_size() if dist is not None else 1),
+                       'backend': (('rccl' if args.backend == 'nccl' else args.backend) if dist is not None else None)},
+            # the dominant kernel = the one with the longer measured launch
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_forward_hl (forward map; k_forward_u / k_forward_plan for maps without hot records)',
-                         'algorithmic_bytes_per_launch': fwd_bytes, 'avg_launch_ms': fwd_ms},
+                         'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': traffic.get('%s_hbm_bytes_per_launch' % dom_kernel.split('<')[0]),
+                         'kernel': dom_kernel, 'which': dominant,
+                         'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
+                         'forward_frac': gbps(fwd_bytes, fwd_ms) / HBM_PEAK_GBS, 'forward_kernel': fwd_kernel,
+                         'inverse_frac': gbps(inv_bytes, inv_ms) / HBM_PEAK_GBS, 'inverse_kernel': inv_kernel,
+                         # forward + inverse as one unit of work against the same roof: by kernel time and by the
+                         # wall-clock step (launch gaps included)
+                         'pair_frac': gbps(fwd_bytes + inv_bytes, fwd_ms + inv_ms) / HBM_PEAK_GBS,
+                         'pair_frac_wallclock': gbps(fwd_bytes + inv_bytes, ms_step) / HBM_PEAK_GBS},
             'forward_ms': fwd_ms, 'inverse_ms': inv_ms,
-            'inverse_GBps_algorithmic': inv_bytes / (inv_ms * 1e-3) / 1e9,
+            'forward_GBps_algorithmic': gbps(fwd_bytes, fwd_ms),
+            'inverse_GBps_algorithmic': gbps(inv_bytes, inv_ms),
             'roundtrip_max_abs_err': err,
+            # the same K steps behind W warm-up steps only, from the cold start (no pre-warm)
+            'cold_ms_per_step': 1e3 * cold / args.steps,
+            'cold_value': world * N * D * args.steps / cold,
+            # coefficient-dependent precompute (fold, U-form splines, 1001-point tables + index) is cached per
+            # coefficient vector and is NOT inside `value`; a step that redoes it every time:
+            'uncached_ms_per_step': 1e3 * uncached / n_unc,
+            'setup_us': 1e3 * (1e3 * uncached / n_unc - ms_step),
+            'cached': 'folded coefficients, U-form section and inverse tables are functions of the coefficient vector '
+                      'and are built once before the timed region; uncached_ms_per_step rebuilds them every step '
+                      '(the reference rebuilds its table in every inverse_map, TM:4047-4058)',
             'prewarm': {'seconds': args.prewarm_seconds, 'steps': prewarm_steps,
                         'why': 'untimed steps before the warm-up so that the timed steps run at the clock the chip holds under '
-                               'sustained load (after an idle gap >= 1 ms the next ~50 launches run 10-30 % slower)'},
+                               'sustained load (after an idle gap >= 1 ms the next ~50 launches run 10-30 % slower); '
+                               'cold_ms_per_step is the same measurement without it'},
         }
+        fl = flops_per_eval(tm) if separable else None
+        if fl is not None:
+            tf = lambda f, ms: f * N * D / (ms * 1e-3) / 1e12          # noqa: E731
+            out['fp64'] = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'forward': {'flop_per_eval': fl[0], 'achieved': tf(fl[0], fwd_ms), 'frac': tf(fl[0], fwd_ms) / FP64_PEAK_TFLOPS},
+                           'inverse': {'flop_per_eval': fl[1], 'achieved': tf(fl[1], inv_ms), 'frac': tf(fl[1], inv_ms) / FP64_PEAK_TFLOPS},
+                           'note': 'arithmetic the kernels execute per component evaluation (FMA = 2 flop, bench.py:flops_per_eval), '
+                                   'vector fp64 peak of MI355X_MICROARCH.md; the measured VALU instruction counts are in '
+                                   'profiles/*_pmc_summary.json'}
         out.update(extra)
         if cpu is not None:
             out['cpu_baseline'] = cpu

@@ -269,6 +269,9 @@ typedef struct ttm_program {
 
 const char* ttm_last_error_string(void);
 int  ttm_version(void);
+/* name of the (last) kernel the most recent launching entry point of this thread dispatched, e.g. "k_inverse_hl":
+ * lets a benchmark name the kernel its timings belong to (which variant runs is decided inside the library) */
+const char* ttm_last_kernel(void);
 /* sizeof(ttm_program) as the library was compiled: bindings check their mirror of the struct against it */
 int64_t ttm_program_sizeof(void);
 /* number of visible HIP devices; 0 with an error string when there is none */
@@ -417,6 +420,28 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
  * work: >= ttm_reduce_work_size(m*m) doubles.                                                      */
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N,
              double* work, double* out, void* stream);
+
+/* ---- C1: the one collective of the path (RCCL over xGMI) ---------------------------------------------
+ * Replaces nothing in the reference (its only parallelism is the fork pool of TM:2789-2845, whose "collective" is
+ * pool.map collecting per-component results, TM:2829-2845); it is what SURVEY.md section 8e needs when samples
+ * (objective / gradient sums, Gram matrices, column moments, bisection caps) or components (summed objective,
+ * coefficient exchange) are spread over the GPUs of a node.  One communicator per process (= per GPU):
+ *   ttm_comm_unique_id : rank 0 draws the 128-byte rendezvous id; the host distributes it to the other ranks
+ *                        (any side channel: the Python class uses torch.distributed's store / broadcast);
+ *   ttm_comm_create    : every rank, on its current HIP device; collective;
+ *   ttm_allreduce_f64 / _i32 : in place on a device buffer, op TTM_OP_SUM / TTM_OP_MAX, enqueued on `stream`
+ *                        (no host synchronisation; results are valid in stream order);
+ *   ttm_comm_destroy.
+ * RCCL is bound at run time; without it the functions return TTM_E_UNSUPPORTED (ttm_comm_last_error says why).   */
+#define TTM_OP_SUM 0
+#define TTM_OP_MAX 1
+typedef struct ttm_comm ttm_comm;
+const char* ttm_comm_last_error(void);
+int ttm_comm_unique_id(void* id128);
+int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** out);
+int ttm_comm_destroy(ttm_comm* comm);
+int ttm_allreduce_f64(ttm_comm* comm, double* buf, int64_t count, int32_t op, void* stream);
+int ttm_allreduce_i32(ttm_comm* comm, int32_t* buf, int64_t count, int32_t op, void* stream);
 
 #ifdef __cplusplus
 }

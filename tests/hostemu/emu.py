@@ -26,6 +26,17 @@ DEPS = [SRC, os.path.join(CSRC, 'ttm_eval.h'), os.path.join(CSRC, 'ttm_math.h'),
 
 _lib = None
 
+_ALLREDUCE_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32)
+
+
+@_ALLREDUCE_CB
+def _allreduce_cb(buf, count, is_f64, op):
+    import torch
+    import torch.distributed as dist
+    ctype = ctypes.c_double if is_f64 else ctypes.c_int32
+    arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctype)), shape=(int(count),))
+    dist.all_reduce(torch.from_numpy(arr), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+
 
 def build():
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in DEPS):
@@ -43,6 +54,11 @@ def lib():
         for name, (res, args) in _capi._SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        # the collective: performed by torch.distributed (gloo) on the host buffer the double hands over
+        l.ttm_hostemu_set_allreduce.restype = None
+        l.ttm_hostemu_set_allreduce.argtypes = [_ALLREDUCE_CB]
+        l.ttm_hostemu_set_allreduce(_allreduce_cb)
+        l.ttm_hostemu_allreduce_calls.restype = ctypes.c_int64
         _lib = l
     return _lib
 

@@ -177,6 +177,38 @@ extern "C" {
 
 const char* ttm_last_error_string(void) { return "hostemu"; }
 int ttm_version(void) { return TTM_VERSION; }
+const char* ttm_last_kernel(void) { return "hostemu"; }
+
+// the collective of the path (include/ttm.h "C1"): the test double has no RCCL; the harness registers a callback that
+// performs the reduction on the host buffer (tests: torch.distributed over gloo), so the class under test goes
+// through the same ttm_comm_* / ttm_allreduce_* calls as on the GPU
+typedef void (*ttm_hostemu_allreduce_cb)(void* buf, int64_t count, int32_t is_f64, int32_t op);
+static ttm_hostemu_allreduce_cb g_allreduce_cb = nullptr;
+static int64_t g_allreduce_calls = 0;
+void ttm_hostemu_set_allreduce(ttm_hostemu_allreduce_cb cb) { g_allreduce_cb = cb; }
+int64_t ttm_hostemu_allreduce_calls(void) { return g_allreduce_calls; }
+const char* ttm_comm_last_error(void) { return g_allreduce_cb ? "" : "hostemu: no all-reduce callback registered"; }
+int ttm_comm_unique_id(void* id128) { if (!id128) return TTM_E_ARG; memset(id128, 0, 128); return TTM_OK; }
+int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** out) {
+    if (!id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return TTM_E_ARG;
+    *out = (ttm_comm*)new int32_t[2]{rank, nranks};
+    return TTM_OK;
+}
+int ttm_comm_destroy(ttm_comm* c) { delete[] (int32_t*)c; return TTM_OK; }
+int ttm_allreduce_f64(ttm_comm* c, double* buf, int64_t count, int32_t op, void*) {
+    if (!c || !buf || count < 1) return TTM_E_ARG;
+    if (!g_allreduce_cb) return TTM_E_UNSUPPORTED;
+    ++g_allreduce_calls;
+    g_allreduce_cb(buf, count, 1, op);
+    return TTM_OK;
+}
+int ttm_allreduce_i32(ttm_comm* c, int32_t* buf, int64_t count, int32_t op, void*) {
+    if (!c || !buf || count < 1) return TTM_E_ARG;
+    if (!g_allreduce_cb) return TTM_E_UNSUPPORTED;
+    ++g_allreduce_calls;
+    g_allreduce_cb(buf, count, 0, op);
+    return TTM_OK;
+}
 int64_t ttm_program_sizeof(void) { return (int64_t)sizeof(ttm_program); }
 int ttm_device_count(int* count) { if (count) *count = 0; return TTM_E_HIP; }
 

@@ -70,6 +70,7 @@ def _worker(rank, world, port, case, outdir):
             zlo, zhi = (0, M // 2) if rank == 0 else (M // 2, M)
             tm.alternate_root_finding = False                   # bisection: needs the all-reduced iteration caps
             out['Xinv'] = tm.inverse_map(Zin[zlo:zhi])
+            out['allreduce_calls'] = emu.lib().ttm_hostemu_allreduce_calls()
         np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
     finally:
         dist.destroy_process_group()
@@ -90,7 +91,7 @@ def _worker_components(rank, world, port, case, outdir):
             tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False,
                                shard_components=True, **ctor_kwargs(desc))
             tm.optimize()
-            out = {'J': tm.objective_total}
+            out = {'J': tm.objective_total, 'allreduce_calls': emu.lib().ttm_hostemu_allreduce_calls()}
             for k in range(tm.D):
                 out['mon_%d' % k] = tm.coeffs_mon[k]
                 out['non_%d' % k] = tm.coeffs_nonmon[k]
@@ -124,6 +125,8 @@ def test_sample_sharding_world2(case, tmp_path):
     mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     tm, npz, X, kw = _single(case)
+    # the data-path reductions went through the C ABI's ttm_allreduce_* (moments, sums / Gram matrix, iteration caps)
+    assert int(r0['allreduce_calls']) >= 4 and int(r0['allreduce_calls']) == int(r1['allreduce_calls'])
     with emu.install():
         assert rel(r0['X_mean'], tm.X_mean) < 1e-13 and rel(r0['X_std'], tm.X_std) < 1e-13
         assert np.array_equal(r0['X_mean'], r1['X_mean'])
@@ -159,6 +162,7 @@ def test_component_sharding_world2(tmp_path):
     mp.spawn(_worker_components, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
     tm, npz, X, kw = _single(case)
+    assert int(r0['allreduce_calls']) == 2           # coefficient exchange + the one scalar objective all-reduce
     with emu.install():
         tm.optimize()
         for k in range(tm.D):

@@ -31,6 +31,7 @@ RECT = {'exponential': 0, 'softplus': 1, 'squared': 2, 'expneg': 3, 'explinearun
 _SIGNATURES = {
     'ttm_last_error_string': (ctypes.c_char_p, []),
     'ttm_version': (ctypes.c_int, []),
+    'ttm_last_kernel': (ctypes.c_char_p, []),
     'ttm_program_sizeof': (c_i64, []),
     'ttm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'ttm_colstats_work_size': (c_i64, [c_i64, c_i32]),
@@ -58,6 +59,12 @@ _SIGNATURES = {
     'ttm_objective_host': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'ttm_comm_last_error': (ctypes.c_char_p, []),
+    'ttm_comm_unique_id': (ctypes.c_int, [c_vp]),
+    'ttm_comm_create': (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),
+    'ttm_comm_destroy': (ctypes.c_int, [c_vp]),
+    'ttm_allreduce_f64': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    'ttm_allreduce_i32': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
 }
 
 EXPORTED_SYMBOLS = sorted(_SIGNATURES)
@@ -76,11 +83,12 @@ def load():
     if _lib is None:
         path = library_path()
         if _build.is_stale():
+            # never run an out-of-date binary silently: a stale library whose rebuild fails is an error
             try:
                 _build.build_lib()
             except Exception as exc:          # no hipcc / compile error
-                if not os.path.exists(path):
-                    raise RuntimeError('libttm.so is not built (%s) and could not be built: %s' % (path, exc))
+                raise RuntimeError('libttm.so (%s) is %s and could not be (re)built: %s'
+                                   % (path, 'out of date' if os.path.exists(path) else 'not built', exc))
         # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  It has to be
         # loaded first so that libttm.so binds to that one runtime: two runtimes in a process
         # cannot share streams / allocations (and the second one finds no GPU).

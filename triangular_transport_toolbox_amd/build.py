@@ -1,15 +1,26 @@
-"""Build libttm.so (HIP kernels + C ABI) in-tree with hipcc for gfx950."""
+"""Build libttm.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+Staleness is decided from what the compiler itself reports: every build writes the dependency list of the
+translation unit (`hipcc -MD`, every header it really included) and a stamp of the command line next to the
+library; the library is rebuilt when any of those files is newer, when the flags differ, or when the stamp is
+missing.  A tuning build with extra flags (TTM_BUILD_FLAGS, TTM_BUILD_LIB) therefore never passes for the product
+library: a different flag set is a different stamp, and a different output path if TTM_BUILD_LIB says so."""
+import hashlib
 import os
+import shlex
 import shutil
 import subprocess
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
-LIB = os.path.join(PKG, 'libttm.so')
-SOURCES = ['ttm_kernels.hip']
-HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', os.path.join('..', '..', 'include', 'ttm.h')]
+LIB = os.environ.get('TTM_BUILD_LIB') or os.path.join(PKG, 'libttm.so')
+SOURCES = ['ttm_kernels.hip', 'ttm_optim.cpp', 'ttm_comm.cpp']
+# what the translation units include (the depfile of the last build supersedes this list)
+HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', 'ttm_uform.h', 'ttm_cheb_table.h',
+           os.path.join('..', '..', 'include', 'ttm.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
-         '-DNDEBUG']
+         '-DNDEBUG'] + shlex.split(os.environ.get('TTM_BUILD_FLAGS', ''))
+LINK = ['-ldl']                   # (RCCL is bound at run time, csrc/ttm_comm.cpp)
 
 
 def hipcc_path():
@@ -19,12 +30,44 @@ def hipcc_path():
     raise RuntimeError('hipcc not found: the MI355X engine needs the ROCm toolchain to build libttm.so')
 
 
+def _sources():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stamp():
+    return hashlib.sha256(' '.join(FLAGS + LINK + [os.path.basename(s) for s in _sources()]).encode()).hexdigest()
+
+
+def _deps():
+    """Files the library was built from: the compiler's depfiles of the last build when present, else the static list."""
+    deps = set(_sources()) | {os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS}
+    dpath = LIB + '.d'
+    if os.path.exists(dpath):
+        txt = open(dpath).read().replace('\\\n', ' ')
+        for tok in txt.split():
+            if tok.endswith(':'):
+                continue
+            if not tok.startswith(('/opt/', '/usr/')):
+                deps.add(os.path.normpath(tok))
+    return [d for d in deps if os.path.exists(d)]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
+    spath = LIB + '.stamp'
+    if not os.path.exists(spath) or open(spath).read().strip() != _stamp():
+        return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def can_build():
+    try:
+        hipcc_path()
+        return True
+    except RuntimeError:
+        return False
 
 
 def build_lib(force=False, verbose=False):
@@ -32,15 +75,36 @@ def build_lib(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     tmp = '%s.tmp.%d' % (LIB, os.getpid())        # atomic replace: several ranks may build at the same time
-    cmd = [hipcc_path()] + FLAGS + ['-o', tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(' '.join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
-    os.replace(tmp, LIB)
+    objs, deptxt = [], []
+    try:
+        for src in _sources():
+            obj = '%s.%s.o' % (tmp, os.path.basename(src))
+            cflags = [f for f in FLAGS if f != '-shared']
+            cmd = [hipcc_path()] + cflags + ['-x', 'hip', '-c', src, '-MD', '-MF', obj + '.d', '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+            objs.append(obj)
+            if os.path.exists(obj + '.d'):
+                deptxt.append(open(obj + '.d').read())
+        cmd = [hipcc_path(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs + LINK
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('hipcc (link) failed:\n' + res.stdout + res.stderr)
+        os.replace(tmp, LIB)
+        with open(LIB + '.d', 'w') as f:
+            f.write('\n'.join(deptxt))
+        with open(LIB + '.stamp', 'w') as f:
+            f.write(_stamp() + '\n')
+    finally:
+        for o in objs + [tmp]:
+            for path in (o, o + '.d'):
+                if os.path.exists(path):
+                    os.remove(path)
     return LIB
 
 

@@ -39,7 +39,10 @@ static int set_err(int code, const char* fmt, const char* a = "", long long b = 
     return code;
 }
 
+static thread_local const char* g_last_kernel = "";      // name of the kernel the last entry point launched
+
 static int check_launch(const char* what) {
+    g_last_kernel = what;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_err, sizeof(g_err), "launch of %s failed: %s", what, hipGetErrorString(e));
@@ -1837,6 +1840,8 @@ extern "C" {
 const char* ttm_last_error_string(void) { return g_err; }
 
 int ttm_version(void) { return TTM_VERSION; }
+
+const char* ttm_last_kernel(void) { return g_last_kernel; }
 
 int64_t ttm_program_sizeof(void) { return (int64_t)sizeof(ttm_program); }
 

@@ -36,7 +36,7 @@ import ctypes
 
 import numpy as np
 
-from . import _capi, lbfgsb, quantile, termtable
+from . import _capi, comm, lbfgsb, quantile, termtable
 
 __all__ = ['transport_map']
 
@@ -263,9 +263,24 @@ class transport_map():
         return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
     def _allreduce(self, t, op='sum'):
-        dist = self._dist()
-        if dist is not None:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
+        """In-place all-reduce of a short device vector over the ranks that share the SAMPLES (no-op otherwise)."""
+        if self._dist() is not None:
+            self._allreduce_world(t, op)
+        return t
+
+    def _allreduce_world(self, t, op='sum'):
+        """The collective itself: ttm_allreduce_f64 / _i32 of the C ABI (RCCL over xGMI) on the current stream; with
+        a process group that is not RCCL (gloo rehearsals sharing one GPU) the same reduction through torch.distributed."""
+        torch = _torch()
+        handle = comm.get(self._lib, force=self._dev.type != 'cuda')
+        if handle is not None and t.dtype in (torch.float64, torch.int32) and t.is_contiguous():
+            fn = self._lib.ttm_allreduce_f64 if t.dtype == torch.float64 else self._lib.ttm_allreduce_i32
+            rc = fn(handle, ctypes.c_void_p(t.data_ptr()), t.numel(), 0 if op == 'sum' else 1, self._stream())
+            if rc != 0:
+                raise _capi.TTMError('ttm_allreduce: %d: %s' % (rc, self._lib.ttm_comm_last_error().decode()))
+            return t
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
         return t
 
     def _refresh_uform(self):
@@ -1215,14 +1230,14 @@ class transport_map():
                 o = int(self._cm.coef_off[k])
                 ck = np.concatenate((self.coeffs_nonmon[k], self.coeffs_mon[k]))
                 buf[o:o + len(ck)] = torch.from_numpy(ck).to(self._dev)
-            tdist.all_reduce(buf)                      # disjoint supports: sum == gather
+            self._allreduce_world(buf)                 # disjoint supports: sum == gather
             allc = buf.cpu().numpy()
             for k in K:
                 o, nn, nm = int(self._cm.coef_off[k]), int(self._cm.n_nm[k]), int(self._cm.n_mon[k])
                 self.coeffs_nonmon[k] = allc[o:o + nn].copy()
                 self.coeffs_mon[k] = allc[o + nn:o + nn + nm].copy()
             jt = torch.tensor([J_local], dtype=torch.float64, device=self._dev)
-            tdist.all_reduce(jt)
+            self._allreduce_world(jt)                  # the one scalar all-reduce of the partitioned optimisation
             self.objective_total = float(jt.item())
         else:
             self.objective_total = J_local
