@@ -297,7 +297,14 @@ def spawn_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # exactly one JSON line on stdout: rank 0's; anything else it printed (gloo's connection banner) goes to stderr
+    lines = out0.splitlines()
+    js = [ln for ln in lines if ln.startswith('{"metric"')]
+    for ln in lines:
+        if ln not in js[-1:]:
+            print(ln, file=sys.stderr)
+    if js:
+        print(js[-1])
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit('bench.py: rank exit codes %s' % rcs)

@@ -272,6 +272,13 @@ int  ttm_version(void);
 /* name of the (last) kernel the most recent launching entry point of this thread dispatched, e.g. "k_inverse_hl":
  * lets a benchmark name the kernel its timings belong to (which variant runs is decided inside the library) */
 const char* ttm_last_kernel(void);
+/* Launch-planning options (tests and tuning runs): which kernel variant an entry point picks is normally decided from
+ * the program and the ensemble size; an option pins one aspect of that choice, e.g. ttm_set_option("no_uform", 1),
+ * ("forward_ns", 2), ("rt_off", 1) - the list is TTM_OPTIONS in csrc/ttm_kernels.hip.  Defaults come from the environment
+ * variables TTM_<NAME>, read once when the library is first used (never on the launch path); ttm_reset_options() goes
+ * back to them.  Options change speed and kernel choice only, never results beyond the documented tolerances.       */
+int ttm_set_option(const char* name, int32_t value);
+int ttm_reset_options(void);
 /* sizeof(ttm_program) as the library was compiled: bindings check their mirror of the struct against it */
 int64_t ttm_program_sizeof(void);
 /* number of visible HIP devices; 0 with an error string when there is none */
@@ -343,8 +350,11 @@ int ttm_basis(const ttm_program* p, int32_t k, int32_t which, const double* Xsoa
  *   abscissae, row k at tab_y + (k-k0)*ldy (ldy = 0: one shared row, e.g. the unpermuted linspace).
  *   h_y_affine (host, nullable): {y0, step, y_last} when ldy = 0 and tab_y[i] == i*step + y0 (i < T-1),
  *   tab_y[T-1] == y_last bit for bit (np.linspace): the abscissae are then computed instead of gathered.
- *   bkt (int32, (k1-k0) x (nb+1)): search accelerator, bkt[b] = searchsorted_left(tab_x, tmin + b (tmax-tmin)/nb);
- *   the kernel bisects only inside the buckets around the target - same index as the full search.
+ *   bkt (int32, (k1-k0) x (nb+1)): search accelerator as ttm_inverse_table_index writes it: bkt[b] = number of entries
+ *   whose bucket - clamp((int)fma(x, nb / (tmax - tmin), -tmin nb / (tmax - tmin)), 0, nb-1), monotone in x - is below b;
+ *   the kernels compare only the entries of the target's own bucket (k_inverse_rt) or bisect inside the buckets around
+ *   it (generic kernel, which also accepts bkt[b] = searchsorted_left(tab_x, tmin + b (tmax-tmin)/nb)) - same index as
+ *   the full search.
  *   Xsoa holds the conditioning columns on entry and receives column kc of every component.       */
 int ttm_inverse_table_build(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                             const double* pts, int32_t T, double* out, void* stream);

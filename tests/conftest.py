@@ -15,3 +15,33 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def repo_root():
     return ROOT
+
+
+@pytest.fixture
+def ttm_opt():
+    """Pin launch-planning options (include/ttm.h: ttm_set_option) for one test, on the device library and on the host
+    test double alike; everything goes back to the defaults afterwards."""
+    import ctypes
+    libs = []
+    try:
+        from triangular_transport_toolbox_amd import build as _b
+        if os.path.exists(_b.LIB) and not _b.is_stale():
+            import torch  # noqa: F401  (its HIP runtime first, as _capi.load() does)
+            dev = ctypes.CDLL(_b.LIB)               # (same dlopen handle, hence the same option table, as _capi's)
+            dev.ttm_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+            libs.append(dev)
+    except Exception:                                   # noqa: BLE001  (no device library here: the double alone)
+        pass
+    try:
+        from tests.hostemu import emu
+        libs.append(emu.lib())
+    except Exception:                                   # noqa: BLE001
+        pass
+
+    def opt(name, value):
+        for lib in libs:
+            rc = lib.ttm_set_option(name.encode(), int(value))
+            assert rc == 0, name
+    yield opt
+    for lib in libs:
+        lib.ttm_reset_options()

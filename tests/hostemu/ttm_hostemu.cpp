@@ -178,6 +178,15 @@ extern "C" {
 const char* ttm_last_error_string(void) { return "hostemu"; }
 int ttm_version(void) { return TTM_VERSION; }
 const char* ttm_last_kernel(void) { return "hostemu"; }
+// options of the test double: the three it knows live in its environment variables (read per call)
+int ttm_set_option(const char* name, int32_t value) {
+    if (!name) return TTM_E_ARG;
+    const char* env = !strcmp(name, "no_plan") ? "TTM_NO_PLAN" : !strcmp(name, "no_uform") ? "TTM_NO_UFORM" :
+                      !strcmp(name, "u_no_hot") ? "TTM_EMU_NO_HOT" : nullptr;
+    if (env) { if (value) setenv(env, "1", 1); else unsetenv(env); }
+    return TTM_OK;                                  // (the other options select device kernel variants: nothing to do)
+}
+int ttm_reset_options(void) { unsetenv("TTM_NO_PLAN"); unsetenv("TTM_NO_UFORM"); unsetenv("TTM_EMU_NO_HOT"); return TTM_OK; }
 
 // the collective of the path (include/ttm.h "C1"): the test double has no RCCL; the harness registers a callback that
 // performs the reduction on the host buffer (tests: torch.distributed over gloo), so the class under test goes

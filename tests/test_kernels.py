@@ -65,7 +65,7 @@ def test_import_export_and_moments(backend):
 
 
 @pytest.mark.parametrize('name,ns', [('c3_sep', '2'), ('c5_sep', '2'), ('c2a_int', '2'), ('misc_grid', '2'), ('c3_sep', '4')])
-def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
+def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch, ttm_opt):
     """The 2- and 4-samples-per-thread kernels (chosen automatically for large ensembles) give the same
     results as the one-sample kernels, including ragged tails."""
     from triangular_transport_toolbox_amd.transport_map import transport_map
@@ -73,35 +73,35 @@ def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch):
     X = case_X(name, npz)[:777]
     tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
     tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
-    monkeypatch.setenv('TTM_FORWARD_NS', '1')
-    monkeypatch.setenv('TTM_INVERSE_NS', '1')
-    monkeypatch.setenv('TTM_U_NS', '1')
-    monkeypatch.setenv('TTM_U_LOADER', '0')
+    ttm_opt('forward_ns', int('1'))
+    ttm_opt('inverse_ns', int('1'))
+    ttm_opt('u_ns', int('1'))
+    ttm_opt('u_loader', int('0'))
     Z1 = tm.map(X)
     sep = desc['kwargs']['monotonicity'] == 'separable monotonicity'
     if sep:
         p1 = tm.evaluate_pullback_density(X)
         I1 = tm.inverse_map(npz['inv_Z'])
-    monkeypatch.setenv('TTM_FORWARD_NS', ns)
-    monkeypatch.setenv('TTM_INVERSE_NS', '2')
-    monkeypatch.setenv('TTM_U_NS', ns)
+    ttm_opt('forward_ns', int(ns))
+    ttm_opt('inverse_ns', int('2'))
+    ttm_opt('u_ns', int(ns))
     assert np.array_equal(tm.map(X), Z1)
     if sep:
         assert np.array_equal(tm.evaluate_pullback_density(X), p1)
         assert np.array_equal(tm.inverse_map(npz['inv_Z']), I1)
         # the loader-wave kernels (U-form maps; chosen automatically for large ensembles) - odd N, ragged last tile
         # (hot-record kernels take exp(-x^2/4) from the 2^(j/32) table: same values to rounding, not bit for bit)
-        monkeypatch.setenv('TTM_U_LOADER', '1')
+        ttm_opt('u_loader', int('1'))
         ZL = tm.map(X)
         assert relerr(ZL, Z1) < 1e-12
         assert relerr(tm.evaluate_pullback_density(X), p1) < 1e-10
         assert np.array_equal(tm.map(X[:1]), ZL[:1])
         assert np.array_equal(tm.map(X[:513]), ZL[:513])
-        monkeypatch.setenv('TTM_HL_NS', '4')                       # four samples per evaluating thread (1024-row tiles)
+        ttm_opt('hl_ns', int('4'))                       # four samples per evaluating thread (1024-row tiles)
         assert np.array_equal(tm.map(X), ZL)
         assert np.array_equal(tm.map(X[:1025]), ZL[:1025])
         I4 = tm.inverse_map(npz['inv_Z'])
-        monkeypatch.setenv('TTM_HL_NS', '2')
+        ttm_opt('hl_ns', int('2'))
         assert np.array_equal(tm.inverse_map(npz['inv_Z']), I4)
         # (the loader-wave inverse evaluates the offsets in U-form: same values to rounding, not bit for bit)
         assert relerr(tm.inverse_map(npz['inv_Z']), I1) < 1e-12

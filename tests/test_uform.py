@@ -123,7 +123,7 @@ def test_falls_back_when_spline_would_be_too_fine(backend):
     assert tm2._cm.u_enabled
 
 
-def test_rejected_fit_disables_uform(backend, monkeypatch):
+def test_rejected_fit_disables_uform(backend, monkeypatch, ttm_opt):
     """A spline outside the host's tolerance is rejected when the coefficients are packed: the fold is redone
     without the U section and the direct kernels run (bit-identical to a map that never had a U-form)."""
     from triangular_transport_toolbox_amd.transport_map import transport_map
@@ -135,9 +135,9 @@ def test_rejected_fit_disables_uform(backend, monkeypatch):
     assert tm._cm.u_enabled
     Zu = tm.map(X)
     assert tm.uform_fit_error[:, 0].max() < 2e-14
-    monkeypatch.setenv('TTM_NO_UFORM', '1')
+    ttm_opt('no_uform', int('1'))
     Zd = tm.map(X)
-    monkeypatch.delenv('TTM_NO_UFORM')
+    ttm_opt('no_uform', 0)
     assert relerr(Zu, Zd) < 1e-12
     monkeypatch.setattr(termtable, 'U_TOL_VALUE', 0.0)          # nothing passes
     tm._refresh_uform()
@@ -168,7 +168,7 @@ def test_class_results_match_oracle_through_uform(backend, name):
 
 
 @pytest.mark.parametrize('name', ['c5_sep', 'c2b_sep'])
-def test_conditional_inverse_and_partial_sweeps_on_loader_kernels(backend, name, monkeypatch):
+def test_conditional_inverse_and_partial_sweeps_on_loader_kernels(backend, name, monkeypatch, ttm_opt):
     """Sweeps that start inside the map (conditional inverse with X_star on a map without skipped dimensions,
     s() of a single component): the hot-record kernels preload the planned cache from the entry state of that
     component.  Forced onto the loader-wave kernels (they are chosen by themselves only for large ensembles)."""
@@ -178,7 +178,7 @@ def test_conditional_inverse_and_partial_sweeps_on_loader_kernels(backend, name,
     tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
     tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D)
     om = make_oracle(name, npz, desc)
-    monkeypatch.setenv('TTM_U_LOADER', '1')
+    ttm_opt('u_loader', int('1'))
     Xq = X[:333]
     E = 1 if tm.D == 2 else 7
     Zq = om.map(Xq)
@@ -216,7 +216,7 @@ def _synthetic_separable(D, band, hf_order, plain_order, n_irbf, family='hermite
     (6, 3, 7, 6, 2, (3, 4)),       # class (7,7), four group records
     (5, 1, 4, 1, 0, (2, 2)),       # one group per component (padded records), LET + RET only
 ])
-def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band, hf_order, plain_order, n_irbf, expect):
+def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band, hf_order, plain_order, n_irbf, expect, ttm_opt):
     """Every degree class / record count of the hot-record kernels (k_forward_hl, k_inverse_hl), forced onto the
     loader-wave path at small N, against the oracle: map, pullback density, table inverse, conditional inverse."""
     from triangular_transport_toolbox_amd.transport_map import transport_map
@@ -235,9 +235,9 @@ def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
     assert tm._cm.u_enabled
     assert (tm._cm.u_h_cls, tm._cm.u_h_ng) == expect
-    monkeypatch.setenv('TTM_U_LOADER', '1')
+    ttm_opt('u_loader', int('1'))
     for ns in ('2', '4'):
-        monkeypatch.setenv('TTM_HL_NS', ns)
+        ttm_opt('hl_ns', int(ns))
         Z = tm.map(X)
         assert relerr(Z, om.map(X)) < 1e-11
         with np.errstate(all='ignore'):
@@ -254,7 +254,7 @@ def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band
 
 
 @pytest.mark.parametrize('case', ['dense', 'own_terms', 'skip_dims', 'other_family'])
-def test_generic_uform_kernels_against_the_oracle(backend, monkeypatch, case):
+def test_generic_uform_kernels_against_the_oracle(backend, monkeypatch, case, ttm_opt):
     """U-form maps WITHOUT hot records (cache misses of dense maps, polynomial / Hermite-function terms in the
     monotone list, skipped dimensions, another polynomial family): the generic U-form kernels (k_forward_u,
     loader-wave k_forward_ul) and the direct inverse, against the oracle."""
@@ -288,7 +288,7 @@ def test_generic_uform_kernels_against_the_oracle(backend, monkeypatch, case):
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
     assert tm._cm.u_enabled and tm._cm.u_h_cls == 0
     for loader in ('0', '1'):
-        monkeypatch.setenv('TTM_U_LOADER', loader)
+        ttm_opt('u_loader', int(loader))
         assert relerr(tm.map(X), om.map(X)) < 1e-11
         with np.errstate(all='ignore'):
             pref = om.evaluate_pullback_density(X[:200])

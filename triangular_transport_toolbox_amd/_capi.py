@@ -32,6 +32,8 @@ _SIGNATURES = {
     'ttm_last_error_string': (ctypes.c_char_p, []),
     'ttm_version': (ctypes.c_int, []),
     'ttm_last_kernel': (ctypes.c_char_p, []),
+    'ttm_set_option': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
+    'ttm_reset_options': (ctypes.c_int, []),
     'ttm_program_sizeof': (c_i64, []),
     'ttm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'ttm_colstats_work_size': (c_i64, [c_i64, c_i32]),
@@ -111,6 +113,15 @@ class TTMError(RuntimeError):
 def check(rc):
     if rc != 0:
         raise TTMError('libttm error %d: %s' % (rc, load().ttm_last_error_string().decode()))
+
+
+def set_option(name, value):
+    """Pin a launch-planning option of the loaded library (include/ttm.h: ttm_set_option)."""
+    check(load().ttm_set_option(name.encode(), int(value)))
+
+
+def reset_options():
+    check(load().ttm_reset_options())
 
 
 def device_count():

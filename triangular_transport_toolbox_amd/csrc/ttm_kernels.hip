@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "ttm_eval.h"
 #include "ttm_uform.h"
 
@@ -721,13 +723,6 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 #define TTM_FWD_ETAB(NS) false
 #endif
 #define TTM_UL_THREADS ((TTM_UL_CW + 2) * 64)
-#if defined(TTM_HL_MAXWAVES)  // tuning knob: tell the scheduler that no more than this many waves per SIMD will be resident
-#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS) __attribute__((amdgpu_waves_per_eu(1, TTM_HL_MAXWAVES)))
-#elif defined(TTM_HL_WAVES)   // tuning knob: register-allocate the hot kernels for this many waves per SIMD
-#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS, TTM_HL_WAVES)
-#else
-#define TTM_HL_BOUNDS __launch_bounds__(TTM_UL_THREADS)
-#endif
 #define TTM_UL_CT (TTM_UL_CW * 64)             // evaluating threads
 #define TTM_UL_ROWS (TTM_UL_CW * 128)          // rows per tile (evaluating waves x 64 lanes x 2 samples)
 // Evaluating waves per workgroup of the hot FORWARD kernel: two for the plain map (four workgroups per CU instead of
@@ -742,26 +737,16 @@ __global__ __launch_bounds__(256) void k_forward_u(const int* __restrict__ ucomp
 #define TTM_HL_CW_LD 4
 #endif
 #define TTM_HL_FWD_CW(WANT_LD) ((WANT_LD) ? TTM_HL_CW_LD : TTM_HL_CW_PLAIN)
-#if defined(TTM_HL_MAXWAVES)
-#define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64) __attribute__((amdgpu_waves_per_eu(1, TTM_HL_MAXWAVES)))
-#elif defined(TTM_HL_WAVES)
-#define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64, TTM_HL_WAVES)
-#else
 #define TTM_HL_FWD_BOUNDS(WANT_LD) __launch_bounds__((TTM_HL_FWD_CW(WANT_LD) + 2) * 64)
-#endif
 // xlead / tlead (kernel arguments): how many steps ahead of the evaluation the x / table loaders run; the rings have
 // xlead + 1 and tlead + 1 slots.  xlead <= 4 and tlead <= 2 (the vmcnt immediates).
 
-#ifdef TTM_EXPERIMENT_NO_BARRIER   // timing experiment only (results are wrong): what do the per-step barriers cost?
-#define TTM_RAW_BARRIER() asm volatile("" ::: "memory")
-#else
 #define TTM_RAW_BARRIER()                       \
     do {                                        \
         asm volatile("" ::: "memory");          \
         __builtin_amdgcn_s_barrier();           \
         asm volatile("" ::: "memory");          \
     } while (0)
-#endif
 
 __device__ __forceinline__ void ul_wait_vmcnt(int n) {      // all but the n youngest vector-memory operations are done
     switch (n) {
@@ -1011,12 +996,6 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
     double* tabs = ring + (size_t)XSLOTS * ROWS;
     double* cache = tabs + (size_t)TSLOTS * tab_slot;
 
-#ifdef TTM_EXPERIMENT_EVAL_ONLY        // timing experiments only (results are wrong; both need TTM_EXPERIMENT_NO_BARRIER)
-    if (wv >= CW) return;
-#endif
-#ifdef TTM_EXPERIMENT_LOADERS_ONLY
-    if (wv < CW) return;
-#endif
     if (wv == CW) {
         ul_column_loader<ROWS>([&](int kk) { return X + (int64_t)((cint_p)(H + (int64_t)kk * HS))[3] * ldx; }, k0, k1, S, N, ring,
                                XSLOTS, xlead, lane);
@@ -1053,10 +1032,8 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
     // sum_k log(dS_k / sigma_k) = sum_k log dS_k - sum_k log sigma_k: the second sum is one number per launch, taken once
     // here instead of a division per component evaluation (8 instructions of ~110)
     double lsig = 0.0;
-#ifndef TTM_EXPERIMENT_LD_DIV          // A/B timing switch
     if (WANT_LD && sigma)
         for (int kk = k0; kk < k1; ++kk) lsig += fast_log(((cdbl_p)sigma)[kk - k0]);
-#endif
     TTM_RAW_BARRIER();                                                   // A(0)
     for (int64_t s = 0; s < S; ++s) {
         cdbl_p rec = H + (int64_t)k * HS;
@@ -1066,9 +1043,7 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
                 const int64_t n = ctile * ROWS + q * (2 * CT) + 2 * tid;
                 act0[q] = n < N; act1[q] = n + 1 < N;
             }
-#ifndef TTM_EXPERIMENT_NO_FULL_TILE     // A/B timing switch
             full = (ctile + 1) * ROWS <= N;
-#endif
             ld = R(0.0); ss = R(0.0);
             if (k0 > 0) {                                                // (rare: sweeps that start inside the map)
                 XOffN<NS> cx;
@@ -1094,11 +1069,7 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
         ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
         R Sv, dS;
         h_component<NG, DB, DA, GS, WANT_LD, TTM_FWD_ETAB(NS)>(rec, tab, xk, cst, WANT_LD ? want_val : true, Sv, dS);
-#ifdef TTM_EXPERIMENT_LD_DIV
-        if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - k0]) : dS);
-#else
         if (WANT_LD) ld += fast_log(dS);
-#endif
         if (Z) {
             double* zt = Z + (int64_t)(k - k0) * ldz + ctile * ROWS + 2 * tid;
             if (full) {                                                  // all but the last tile: no per-lane masks
@@ -1139,215 +1110,372 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
     }
 }
 
-// Table inverse from hot records with loader waves (same workgroup anatomy and barrier protocol as k_forward_hl):
-// wave 4 streams the z_k columns, wave 5 the 1001-point table and its bucket index of the component, both by
-// LDS-DMA; the evaluating waves (two adjacent samples per thread) compute the nonmonotone offset from the planned
-// column cache, search the staged table (np.searchsorted left: bucket start + forward scan, four entries at a
-// time), interpolate with interp1d's slope form, put x_k into the cache and store it.  The abscissae are the
-// computed np.linspace (yreg semantics of k_inverse_table).  Requires (nb + 1) % 4 == 0.
-// LDS (doubles): [z ring: (xlead+1) x 512 | table ring: (tlead+1) x tab_slot | column cache: 2 x ways x 2 x 256]
-// table slot: [xs: T rounded up to even | bucket index: nb + 1 int32]
-template <int NG, int CLS, int NS>
-__global__ TTM_HL_BOUNDS void k_inverse_hl(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
-                                                    int D, int k0, int k1,
-                                                    const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
-                                                    const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
-                                                    const double* __restrict__ tmin, const double* __restrict__ tmax,
-                                                    const int* __restrict__ bkt, int nb, int truncate,
-                                                    int tab_slot, int xlead, int tlead, int ways) {
-    typedef VecD<NS> R;
-    constexpr int ROWS = TTM_UL_CT * NS;
+// ---------------------------------------------------------------------------
+// Table inverse with RESIDENT tables (the kernel the large-ensemble path runs).
+//
+// k_inverse_hl streams the 12 KB table + bucket index of a component into LDS for every 512-row step: 945 MB of
+// L2 -> LDS traffic per launch at C5 (1.5 x the algorithmic bytes), two loader waves per workgroup and one barrier
+// per step.  Here a workgroup owns a contiguous chunk of rows and walks the components in BLOCKS of B: the tables of
+// a block (xs row + 16-bit bucket index, 10 KB per component) are loaded into LDS once per workgroup and launch, then
+// every tile of the chunk runs the B components against them.  Inside a block there are no barriers, no loader waves
+// and no rings: a thread carries its NS rows through the B components, reads z_k with one 16-byte global load per row
+// pair (issued one step ahead) and stores x_k the same way (one step behind).
+//
+// What a later component reads of the earlier ones (x_j and exp(-x_j^2/4) of the columns its nonmonotone groups use)
+// lives in the planned column cache (termtable.py:_plan_column_cache) in per-thread 16-byte LDS words, 32 B per row
+// and way: one workgroup of 16 waves per CU, 8 components per block at C5.  (Measured and dropped: carrying the last
+// two columns of a banded map in registers instead - no cache traffic, 15 components per block, or two workgroups
+// = 32 waves per CU under a 64-register cap: 0.215 / 0.234 ms against 0.215 ms)
+// At a block boundary the state of a tile is re-loaded from the x columns the SAME thread stored in the previous block.
+// With ETAB, exp(-x_k^2/4) comes from the located table interval instead of a full exp: x_k = y_lo + delta with
+// 0 <= delta <= step, exp(-x_k^2/4) = E[i-1] exp(w), w = -delta (y_lo + x_k) / 4, |w| <= 0.1, E[i] = exp(-y_i^2/4)
+// tabulated once per workgroup (the abscissae are the same for every component), exp(w) by its degree-9 Taylor
+// polynomial (truncation 2.8e-17).  The host enables it when the targets are clipped to the table
+// (root_search_truncation) and step * max|y| / 2 <= 0.1.
+// Search: the bucket function of k_table_index, bit for bit (table_bucket) -> a = number of entries in lower buckets; only
+// the entries of the target's own bucket are compared (at most `per` = 2-3 with nb ~ T): exact without verification.
+// LDS (doubles): [tables: B x tab_slot | E: Teven (ETAB) | column cache, 2 x ways x NS x blockDim]
+// table slot: [lo, hi, bucket scale, bucket bias, int32 {entries per bucket at most, 0}, 0 | xs: T entries + 4 sentinels
+//              (+inf), rounded up to even | bucket index: nb + 1 uint16]
+// ---------------------------------------------------------------------------
+// The bucket function of the table search, shared bit for bit by the index kernel and the lookup kernels (IEEE
+// division, one fma): bucket(x) = clamp((int)fma(x, scale, bias), 0, nb - 1), scale = nb / (hi - lo), bias = -lo scale.
+// It is monotone in x, so entries in a lower bucket than the target's are < target and entries in a higher one are
+// > target: only the entries of the target's own bucket have to be compared.  A degenerate table (hi == lo, NaN) has
+// scale 0: everything is bucket 0.
+__device__ __forceinline__ void table_bucket_params(double lo, double hi, int nb, double& scale, double& bias) {
+    scale = (double)nb / (hi - lo);
+    if (!(scale > 0.0 && scale < 1.0e300)) scale = 0.0;
+    bias = -lo * scale;
+}
+__device__ __forceinline__ int table_bucket(double x, double scale, double bias, int nb) {
+    int q = (int)fma(x, scale, bias);
+    q = max(q, 0);
+    return min(q, nb - 1);
+}
+
+#define TTM_RT_HDR 6
+
+// The planned column cache of k_inverse_rt: value i (x of way w at 2w, exp(-x^2/4) at 2w+1) of row pair q of a thread
+// is ONE 16-byte LDS word {first row, second row} at cache[((i NP + q) CT + tid) 2]: consecutive lanes read consecutive
+// words (ds_read_b128 / ds_write_b128 at full rate, no bank conflicts), half the LDS instructions of per-row columns.
+template <int NP>
+struct RtCache {
+    double* base;                // cache + 2 tid
+    int stride;                  // doubles between consecutive (value, pair) words: 2 CT
+    __device__ __forceinline__ D2 get(int i, int q) const { return *(const D2*)(base + (size_t)(i * NP + q) * stride); }
+    __device__ __forceinline__ void set(int i, int q, D2 v) const { *(D2*)(base + (size_t)(i * NP + q) * stride) = v; }
+};
+
+__device__ __forceinline__ D2 rt_expq(D2 x) {
+    VecD<2> v;
+    v.v[0] = x.x; v.v[1] = x.y;
+    const VecD<2> e = exp_q_fast(v);
+    D2 r = {e.v[0], e.v[1]};
+    return r;
+}
+
+// entry state of the planned cache at a component from the columns already in X (block boundaries, conditional
+// inverse): out of line, so that its exp() constants and addresses do not live in the registers of the step loop
+template <int NP>
+__device__ __attribute__((noinline)) void rt_warm(const int* state_, const char* X, int64_t ldb, unsigned int n0,
+                                                  unsigned int last_pair, int CT, double* cache_base) {
+    cint_p state = (cint_p)state_;
+    RtCache<NP> cc{cache_base, 2 * CT};
+    for (int w = 0; w < TTM_PLAN_WAYS; ++w) {
+        const int v = state[w];
+        if (v >= 0) {
+            const char* col = X + (int64_t)(v & ~TTM_PLAN_E) * ldb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                unsigned int n = n0 + (unsigned int)(q * 2 * CT);
+                n = n < last_pair ? n : last_pair;
+                const D2 x = *(const D2*)(col + (size_t)(n * 8u));
+                cc.set(2 * w, q, x);
+                if (v & TTM_PLAN_E) cc.set(2 * w + 1, q, rt_expq(x));
+            }
+        }
+    }
+}
+
+template <int NG, int CLS, int NS, bool ETAB>
+__global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+                                                     int D, int k0, int k1,
+                                                     const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
+                                                     const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
+                                                     const double* __restrict__ tmin, const double* __restrict__ tmax,
+                                                     const int* __restrict__ bkt, int nb, int truncate,
+                                                     int tab_slot, int B, int ways, int64_t rows_per_wg) {
     constexpr int NP = NS / 2;
-    const int XSLOTS = xlead + 1, TSLOTS = tlead + 1;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
     constexpr int HS = TTM_H_HDR + NG * GS;
-    cdbl_p H = (cdbl_p)(U_ + h_off);
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int ncomp = k1 - k0;
-    const int64_t ntiles = (N + ROWS - 1) / ROWS;
-    if ((int64_t)blockIdx.x >= ntiles) return;
-    const int64_t my_tiles = (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
-    const int64_t S = my_tiles * ncomp;
-    double* ring = g_smem;
-    double* tabs = ring + (size_t)XSLOTS * ROWS;
-    double* cache = tabs + (size_t)TSLOTS * tab_slot;
-    const int Teven = (T + 4 + 1) & ~1;          // table entries + 4 sentinels (+inf), rounded up to even
-    double* etab = cache + (size_t)2 * ways * NS * TTM_UL_CT;                   // 2^(j/32), behind the column cache
-
-#ifdef TTM_EXPERIMENT_EVAL_ONLY        // timing experiments only (results are wrong; both need TTM_EXPERIMENT_NO_BARRIER)
-    if (wv >= TTM_UL_CW) return;
-#endif
-#ifdef TTM_EXPERIMENT_LOADERS_ONLY
-    if (wv < TTM_UL_CW) return;
-#endif
-    if (wv == TTM_UL_CW) {
-        ul_column_loader<ROWS>([&](int kk) { return Z + (int64_t)(kk - k0) * ldz; }, k0, k1, S, N, ring, XSLOTS, xlead, lane);
-        return;
+    const int tid = threadIdx.x, CT = blockDim.x, ROWS = CT * NS;
+    const int64_t c0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
+    const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
+    const int Teven = (T + 4 + 1) & ~1;
+    double* tabs = g_smem;
+    double* etab = tabs + (size_t)B * tab_slot;
+    double* cache = etab + (ETAB ? Teven : 0);
+    const RtCache<NP> cc{cache + 2 * tid, 2 * CT};
+    // (row numbers are 32-bit - N < 2^28 - and every access is `uniform column base + 32-bit byte offset`)
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);        // first row of the last readable pair
+    const unsigned int row0 = (unsigned int)c0 + 2u * (unsigned int)tid, c1_32 = (unsigned int)c1;
+    if (ETAB)
+        for (int i = tid; i < T; i += CT) etab[i] = exp_q_fast(i == T - 1 ? ylast : (double)i * ystep + y0);
+    // Taylor coefficients 1/9! .. 1/2! of the ETAB put, kept in VGPRs (as scalars they would push the kernel over the
+    // SGPR budget and be spilled to VGPR lanes: v_readlane + hazard nops in the middle of every step)
+    double kc[8];
+    {
+        const __attribute__((address_space(4))) double* kg = (const __attribute__((address_space(4))) double*)g_exp_coef;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kc[j] = kg[4 + j];
+            if (ETAB) asm volatile("" : "+v"(kc[j]));
+        }
     }
-    if (wv == TTM_UL_CW + 1) {
-        // xs row (T doubles: whole 16-byte units, then the odd double as two dwords) + bucket row (nb + 1 int32)
-        const int bytes1 = (T * 8) & ~15, tail4 = (T * 8 - bytes1) / 4;
-        ul_table_loader([&](int kk, double* slot) {
-            const char* src1 = (const char*)(tab_x + (int64_t)(kk - k0) * T);
-            int n = ul_dma_block(src1, bytes1, slot, lane);
-            if (lane < tail4) ul_dma4(src1 + bytes1 + lane * 4, (char*)slot + bytes1);
-            n += tail4 ? 1 : 0;
-            return n + ul_dma_block((const char*)(bkt + (int64_t)(kk - k0) * (nb + 1)), (nb + 1) * 4, slot + Teven, lane);
-        }, k0, k1, S, tabs, tab_slot, TSLOTS, tlead);
-        return;
-    }
+    const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
 
-    // ---- evaluating waves -------------------------------------------------------------------------------------------
-    // (the paired 16-byte layout of the forward kernel is slower here, 0.265 against 0.253 ms at C5: every step
-    // ends with a put, and ds_write_b128 costs more than the two ds_write_b64 it replaces)
-    typedef CacheStore<R, false> Store;
-    Store cst;
-    cst.base = cache + tid;
-    cst.stride = TTM_UL_CT;
-#ifdef TTM_INV_ETAB                 // exp(-x^2/4) of the put from the 2^(j/32) table: 0.2353 ms against 0.2322 ms with
-    if (tid < TTM_EXPQ_TABLE_LEN) etab[tid] = g_expq_table[tid];           // the series (exp_q_fast) at C5, steady clock
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    cst.etab = etab;
-#else
-    (void)etab;
-#endif
-    bool act0[NP], act1[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) { act0[q] = false; act1[q] = false; }
-    int64_t ctile = blockIdx.x;
-    int k = k0;
-    int xs = 0, ts = 0;
-#ifndef TTM_INV_EXACT_LERP
-    const double dy_last = ylast - ((double)(T - 2) * ystep + y0);
-#endif
-    // sentinels behind the table entries of every slot (the DMAs only ever write the first T doubles)
-    if (tid < TSLOTS * (Teven - T)) tabs[(size_t)(tid / (Teven - T)) * tab_slot + T + tid % (Teven - T)] = INFINITY;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    TTM_RAW_BARRIER();                                                   // A(0)
-    for (int64_t s = 0; s < S; ++s) {
-        cdbl_p rec = H + (int64_t)k * HS;
-        if (k == k0) {
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
-                act0[q] = n < N; act1[q] = n + 1 < N;
+    for (int kb = k0; kb < k1; kb += B) {
+        const int ke = kb + B < k1 ? kb + B : k1;
+        const int nk = ke - kb;
+        __syncthreads();                                                 // every wave is done with the previous block's tables
+        if (tid < nk) {
+            // header of the slot: search parameters (the index kernel's bucket function, bit for bit) and the largest
+            // number of entries any bucket holds (filled in below)
+            const int c = kb + tid;
+            double* slot = tabs + (size_t)tid * tab_slot;
+            const double lo = tmin[c - k0], hi = tmax[c - k0];
+            double scale, bias;
+            table_bucket_params(lo, hi, nb, scale, bias);
+            slot[0] = lo; slot[1] = hi; slot[2] = scale; slot[3] = bias;
+            ((int*)slot)[8] = 0;                                         // entries per bucket, at most
+            ((int*)slot)[9] = 0;
+            slot[5] = 0.0;
+        }
+        __syncthreads();
+        for (int c = kb; c < ke; ++c) {
+            double* slot = tabs + (size_t)(c - kb) * tab_slot;
+            double* xs = slot + TTM_RT_HDR;
+            const double* src = tab_x + (int64_t)(c - k0) * T;
+            for (int i = tid; i < Teven; i += CT) xs[i] = i < T ? src[i] : INFINITY;
+            unsigned short* bs = (unsigned short*)(xs + Teven);
+            const int* bsrc = bkt + (int64_t)(c - k0) * (nb + 1);
+            int per = 0;
+            for (int i = tid; i <= nb; i += CT) {
+                const int v = bsrc[i];
+                bs[i] = (unsigned short)v;
+                if (i < nb) per = max(per, bsrc[i + 1] - v);
             }
-            if (k0 > 0) {                                                // (conditional inverse: columns given in X)
-                XOffN<NS> cx;
-                cx.X = (const char*)X; cx.ldb = ldx * 8;
-#pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const int64_t n = ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
-                    cx.off[2 * q] = (unsigned int)(act0[q] ? n : N - 1) * 8u;
-                    cx.off[2 * q + 1] = (unsigned int)(act1[q] ? n + 1 : N - 1) * 8u;
-                }
-                PlanCache<XOffN<NS>, R, Store> x(cx, cst);
-                x.warm((cint_p)ucomp_ + TTM_UC_STATE(D, k0));
-            }
+            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+            if ((tid & 63) == 0) atomicMax((int*)slot + 8, per);         // (one LDS atomic per wave, not per thread)
         }
-        double zv[NS];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const D2 zp = *(const D2*)(ring + (size_t)xs * ROWS + q * (2 * TTM_UL_CT) + 2 * tid);
-            zv[2 * q] = zp.x; zv[2 * q + 1] = zp.y;
-        }
-        const double* xsl = tabs + (size_t)ts * tab_slot;
-        const int* bkl = (const int*)(xsl + Teven);
-        xs = (xs + 1 == XSLOTS) ? 0 : xs + 1;
-        ts = (ts + 1 == TSLOTS) ? 0 : ts + 1;
-        const double lo = ((cdbl_p)tmin)[k - k0], hi = ((cdbl_p)tmax)[k - k0];
-        // bucket number of a target: (target - lo) nb / (hi - lo); the search starts one bucket lower, so the
-        // last-bit difference between this reciprocal and the division of the index kernel does not matter
-        const double scale = (double)nb * approx_rcp(hi - lo);           // (2^-23 of a bucket: the search starts a bucket early)
-        const bool use_bkt = scale > 0.0 && scale < 1.0e300;
-#ifdef TTM_EXPERIMENT_INV_NO_OFFSET      // timing experiments only (results are wrong): marginal cost of the parts
-        R off(rec[7]);
-#else
-        const R off = h_offset<NG, DB, DA, GS, R, Store>(rec, cst);
-#endif
-        double tg[NS];
-        int a[NS];
-#pragma unroll
-        for (int e = 0; e < NS; ++e) {
-            double target = -off.v[e] + zv[e];
-            if (truncate) {                          // TM:4074-4076 (comparisons keep NaN untouched)
-                if (target < lo) target = lo;
-                if (target > hi) target = hi;
-            }
-            tg[e] = target;
-            int q = (int)((target - lo) * scale) - 1;
-            q = q < 0 ? 0 : (q > nb - 1 ? nb - 1 : q);
-#ifdef TTM_INV_ALIGNED_SCAN
-            a[e] = (use_bkt ? bkl[q] : 0) & ~1;      // even start: the scan reads 16-byte aligned pairs (entries before
-                                                     // a bucket start are < target, so the count is unchanged)
-#else
-            a[e] = use_bkt ? bkl[q] : 0;
-#endif
-        }
-        // np.searchsorted(xs, target) (left) = a + #{entries from a on that are < target}: both samples scan four
-        // entries per round together (a finished sample re-reads its last group); the table is followed by +inf sentinels
-        int pos[NS];
-#ifdef TTM_EXPERIMENT_INV_NO_SCAN
-#pragma unroll
-        for (int e = 0; e < NS; ++e) pos[e] = a[e] + 1;
-#endif
-#ifdef TTM_EXPERIMENT_INV_NO_SCAN
-        for (int round = 0; round < 0; ++round) {
-#else
-        for (int round = 0; round < 4096; ++round) {
-#endif
-            int cmax = 0;
-#pragma unroll
-            for (int e = 0; e < NS; ++e) {
-#ifdef TTM_INV_ALIGNED_SCAN
-                double q0, q1, q2, q3;
-                load_pair(xsl + a[e], q0, q1);
-                load_pair(xsl + a[e] + 2, q2, q3);
-#else
-                const double* q4 = xsl + a[e];
-                const double q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
-#endif
-                const int c = (q0 < tg[e] ? 1 : 0) + (q1 < tg[e] ? 1 : 0) + (q2 < tg[e] ? 1 : 0) + (q3 < tg[e] ? 1 : 0);
-                pos[e] = a[e] + c;
-                a[e] += c & 4;                                           // (a finished sample stays where it is)
-                cmax = c > cmax ? c : cmax;
-            }
-            if (cmax < 4) break;
-        }
-        R r;
-#pragma unroll
-        for (int e = 0; e < NS; ++e) {
-            const int i = pos[e] < 1 ? 1 : (pos[e] > T - 1 ? T - 1 : pos[e]);
-            const double x_lo = xsl[i - 1], x_hi = xsl[i];
-            const double y_lo = (double)(i - 1) * ystep + y0;
-#ifndef TTM_INV_EXACT_LERP
-            // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-15 of the step; the last interval,
-            // whose end point np.linspace forces, keeps its own difference): no second abscissa, no compare
-            const double dy = (i == T - 1) ? dy_last : ystep;
-            const double slope = fast_div1(dy, fmax(x_hi - x_lo, 1e-300));         // (tie at a flat start: table_lookup)
-#else
-            const double y_hi = (i == T - 1) ? ylast : (double)i * ystep + y0;
-            const double slope = fast_div(y_hi - y_lo, fmax(x_hi - x_lo, 1e-300));          // interp1d slope form (TM:4062-4065)
-#endif
-            r.v[e] = slope * (tg[e] - x_lo) + y_lo;
-        }
-#ifdef TTM_EXPERIMENT_INV_NO_PUTEXP
-        { const int put2 = ((cint_p)rec)[0]; if (put2 >= 0) { cst.set(put2, r); cst.set(put2 + 1, r * rec[7]); } }
-#else
-        h_put(rec, cst, r);
-#endif
+        __syncthreads();
+
+        // Memory operations of a step, in issue order: [wait for z_s] -> store of x_{s-1} (deferred by one step) ->
+        // load of z_{s+1} -> arithmetic.  The wait therefore only ever covers operations issued a whole step earlier
+        // (the load of z_s and the store of x_{s-2}); a store issued at the END of its own step would sit between the
+        // load and the next wait and stall every step for a full write latency (vmcnt counts in order).
+        D2 zn[NP], rprev[NP];
+        const char* xprev_col = nullptr;                                 // column of the deferred store (uniform)
+        unsigned int xprev_off = 0;                                      // byte offset of this thread's first row in it
+        bool xprev_full = true;
         {
-            const int kc = ((cint_p)rec)[3];
+            const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                double* xc = X + (int64_t)kc * ldx + ctile * ROWS + q * (2 * TTM_UL_CT) + 2 * tid;
-                if (act1[q]) { D2 o = {r.v[2 * q], r.v[2 * q + 1]}; *(D2*)xc = o; }
-                else if (act0[q]) *xc = r.v[2 * q];
+                unsigned int n = row0 + (unsigned int)(q * 2 * CT);
+                n = n < last_pair ? n : last_pair;
+                zn[q] = *(const D2*)(zcol + (size_t)(n * 8u));
             }
         }
-        if (k + 1 == k1) { ctile += gridDim.x; k = k0; }
-        else ++k;
-        TTM_RAW_BARRIER();                                               // A(s + 1)
+        for (int tile = 0; tile < ntile; ++tile) {
+            const unsigned int tbase = row0 + (unsigned int)tile * (unsigned int)ROWS;     // this thread's first row of the tile
+            const bool full = c0 + (int64_t)(tile + 1) * ROWS <= c1;     // (uniform) every row of the tile exists
+            if (kb > 0)                                                  // columns the earlier blocks (or the caller) left in X
+                rt_warm<NP>(ucomp_ + TTM_UC_STATE(D, kb), (const char*)X, ldxb, tbase, last_pair, CT, cache + 2 * tid);
+            cdbl_p rec = (cdbl_p)(U_ + h_off) + (int64_t)kb * HS;
+            const double* slot = tabs;
+            const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;   // column of THIS step's z
+            for (int j = 0; j < nk; ++j, rec += HS, slot += tab_slot, zcol += ldzb) {
+                // ---- uniform data of the step: the whole record by scalar loads issued together --------------------
+                cint_p ri = (cint_p)rec;
+                const int put2 = ri[0], flg = ri[1], kcol = ri[3], n_grp = ri[13];
+                const double nm0 = rec[7];
+                int gslot[NG];
+                double gB[NG][DB + 1], gA[NG][DA + 1];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    cdbl_p gr = rec + TTM_H_HDR + g * GS;
+                    gslot[g] = ((cint_p)gr)[0];
+#pragma unroll
+                    for (int i = 0; i <= DB; ++i) gB[g][i] = gr[1 + i];
+#pragma unroll
+                    for (int i = 0; i <= DA; ++i) gA[g][i] = gr[2 + DB + i];
+                }
+                // ---- memory: z of this step has landed; x of the step before goes out; z of the step after comes in ----
+                D2 zc[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { zc[q] = zn[q]; asm volatile("" : "+v"(zc[q])); }
+                if (xprev_col) {
+                    if (xprev_full) {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q)
+                            *(D2*)(const_cast<char*>(xprev_col) + (size_t)(xprev_off + (unsigned int)(q * 2 * CT) * 8u)) = rprev[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const unsigned int n = xprev_off / 8u + (unsigned int)(q * 2 * CT);
+                            char* xp = const_cast<char*>(xprev_col) + (size_t)(n * 8u);
+                            if (n + 1 < c1_32) *(D2*)xp = rprev[q];
+                            else if (n < c1_32) *(double*)xp = rprev[q].x;
+                        }
+                    }
+                }
+                {
+                    const bool wrap = j + 1 == nk;                       // next: first component of the next tile
+                    const char* zc_next = wrap ? (const char*)Z + (int64_t)(kb - k0) * ldzb : zcol + ldzb;
+                    const unsigned int tb = (wrap && tile + 1 < ntile) ? tbase + (unsigned int)ROWS : tbase;   // (past the last tile: a harmless re-read)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        unsigned int n = tb + (unsigned int)(q * 2 * CT);
+                        n = n < last_pair ? n : last_pair;
+                        zn[q] = *(const D2*)(zc_next + (size_t)(n * 8u));
+                    }
+                }
+                // ---- the table's search parameters (LDS broadcast reads) ---------------------------------------------
+                double lo, hi, scale, bias;
+                load_pair(slot, lo, hi);
+                load_pair(slot + 2, scale, bias);
+                const double* xsl = slot + TTM_RT_HDR;
+                const unsigned short* bkl = (const unsigned short*)(xsl + Teven);
+                // ---- nonmonotone offset (h_offset's arithmetic, operand for operand) ------------------------------------
+                double off[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) off[e] = nm0;
+                auto group = [&](int g, const D2 (&xv)[NP], const D2 (&ev)[NP]) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const double x = h ? xv[q].y : xv[q].x, ee = h ? ev[q].y : ev[q].x;
+                            double bq = gB[g][DB], aq = gA[g][DA];
+#pragma unroll
+                            for (int i = DB - 1; i >= 0; --i) bq = fma(bq, x, gB[g][i]);
+#pragma unroll
+                            for (int i = DA - 1; i >= 0; --i) aq = fma(aq, x, gA[g][i]);
+                            off[2 * q + h] = fma(ee, bq, off[2 * q + h]) + aq;
+                        }
+                    }
+                };
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g < n_grp) {
+                        D2 xv[NP], ev[NP];
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) { xv[q] = cc.get(gslot[g], q); ev[q] = cc.get(gslot[g] + 1, q); }
+                        group(g, xv, ev);
+                    }
+                }
+                // ---- target, bucket, position ---------------------------------------------------------------------------
+                // np.searchsorted(xs, target) (left) = a + #{entries of the target's own bucket that are < target}, a =
+                // number of entries in lower buckets: the bucket function is monotone, so those are all < target and the
+                // entries of higher buckets are all > target (k_table_index).  `per` entries are compared - the most any
+                // bucket of this table holds (2-3 with nb ~ T) - what lies behind the bucket compares as not smaller, and
+                // behind the table stand +inf sentinels: no verification, no second pass.
+                const int per = __builtin_amdgcn_readfirstlane(((const int*)slot)[8]);
+                double tg[NS];
+                int pos[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const double z = (e & 1) ? zc[e >> 1].y : zc[e >> 1].x;
+                    double target = -off[e] + z;
+                    if (truncate) {                          // TM:4074-4076: clip; a NaN target stays NaN (fmin / fmax drop it)
+                        const double cl = fmin(fmax(target, lo), hi);
+                        target = target != target ? target : cl;
+                    }
+                    tg[e] = target;
+                    pos[e] = (int)bkl[table_bucket(target, scale, bias, nb)];
+                }
+                if (per <= 2) {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const double* q4 = xsl + pos[e];
+                        const double q0 = q4[0], q1 = q4[1];
+                        pos[e] += (q0 < tg[e] ? 1 : 0) + (q1 < tg[e] ? 1 : 0);
+                    }
+                } else if (per <= 4) {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const double* q4 = xsl + pos[e];
+                        const double q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
+                        pos[e] += (q0 < tg[e] ? 1 : 0) + (q1 < tg[e] ? 1 : 0) + (q2 < tg[e] ? 1 : 0) + (q3 < tg[e] ? 1 : 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        int ae = pos[e];
+                        for (int done = 0; done < per; done += 4) {      // (uniform trip count; a finished lane re-reads sentinels or larger entries)
+                            const double* q4 = xsl + ae;
+                            const double q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];
+                            const int c = (q0 < tg[e] ? 1 : 0) + (q1 < tg[e] ? 1 : 0) + (q2 < tg[e] ? 1 : 0) + (q3 < tg[e] ? 1 : 0);
+                            ae += c;
+                            if (__builtin_amdgcn_ballot_w64(c == 4) == 0) break;
+                        }
+                        pos[e] = ae;
+                    }
+                }
+                // ---- interp1d slope form (TM:4062-4065) and, with ETAB, exp(-x^2/4) from the located interval -------------
+                double r[NS], ev[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    int i = max(pos[e], 1);
+                    i = min(i, T - 1);
+                    const double x_lo = xsl[i - 1], x_hi = xsl[i];
+                    const double y_lo = (double)(i - 1) * ystep + y0;
+                    // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-13 of the step, also in the last
+                    // interval, whose end point np.linspace forces: 2e-15 of x at most)
+                    const double slope = fast_div1(ystep, fmax(x_hi - x_lo, 1e-300));   // (tie at a flat start: table_lookup)
+                    const double delta = slope * (tg[e] - x_lo);
+                    r[e] = delta + y_lo;
+                    if (ETAB) {
+                        const double w = (delta * -0.25) * (y_lo + r[e]);
+                        double p = kc[0];
+#pragma unroll
+                        for (int i2 = 1; i2 < 8; ++i2) p = fma(p, w, kc[i2]);
+                        p = fma(p, w, 1.0);
+                        p = fma(p, w, 1.0);
+                        ev[e] = etab[i - 1] * p;
+                    }
+                }
+                // ---- keep x_k (and exp(-x_k^2/4)) for the components behind; the store is deferred to the next step -----
+#pragma unroll
+                for (int q = 0; q < NP; ++q) { D2 o = {r[2 * q], r[2 * q + 1]}; rprev[q] = o; }
+                if (put2 >= 0) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        cc.set(put2, q, rprev[q]);
+                        if (flg & 1) {
+                            D2 eo = {ev[2 * q], ev[2 * q + 1]};
+                            cc.set(put2 + 1, q, ETAB ? eo : rt_expq(rprev[q]));
+                        }
+                    }
+                }
+                xprev_col = (const char*)X + (int64_t)kcol * ldxb;
+                xprev_off = tbase * 8u;
+                xprev_full = full;
+            }
+        }
+        if (xprev_col) {                                                 // the last step's x
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const unsigned int n = xprev_off / 8u + (unsigned int)(q * 2 * CT);
+                char* xp = const_cast<char*>(xprev_col) + (size_t)(n * 8u);
+                if (n + 1 < c1_32) *(D2*)xp = rprev[q];
+                else if (n < c1_32) *(double*)xp = rprev[q].x;
+            }
+        }
     }
 }
 
@@ -1400,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
                                                      double* __restrict__ tmin, double* __restrict__ tmax,
                                                      int* __restrict__ bkt, int* __restrict__ unsorted) {
     __shared__ double xs[2048];
+    __shared__ int bq[2048];
     __shared__ int bad;
     const double* row = tab_x + (int64_t)blockIdx.x * T;
     if (threadIdx.x == 0) bad = 0;
@@ -1408,18 +1537,20 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
     int mybad = 0;
     for (int i = threadIdx.x + 1; i < T; i += blockDim.x) mybad |= !(xs[i - 1] <= xs[i]);   // also flags NaN
     if (mybad) atomicOr(&bad, 1);
-    __syncthreads();
     const double lo = xs[0], hi = xs[T - 1];
+    double scale, bias;
+    table_bucket_params(lo, hi, nb, scale, bias);
+    for (int i = threadIdx.x; i < T; i += blockDim.x) bq[i] = table_bucket(xs[i], scale, bias, nb);
+    __syncthreads();
     if (threadIdx.x == 0) { tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad; }
-    const double step = (hi - lo) / (double)nb;
+    // bkt[q] = number of entries in buckets below q (the entries are sorted, so their bucket numbers are too)
     for (int q = threadIdx.x; q <= nb; q += blockDim.x) {
         int a = 0, b = T;
         if (q == nb) a = T;
         else if (q > 0) {
-            const double u = lo + (double)q * step;
             while (a < b) {
                 const int mid = (a + b) >> 1;
-                if (xs[mid] < u) a = mid + 1; else b = mid;
+                if (bq[mid] < q) a = mid + 1; else b = mid;
             }
         }
         bkt[(int64_t)blockIdx.x * (nb + 1) + q] = a;
@@ -1772,9 +1903,74 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, int k, const double* __
 
 static const int kLdsBudget = 64 * 1024;      // bytes per workgroup
 
+// What the launch planning needs to know about the device (queried once per process) and the tuning knobs of the
+// environment (read once, at the first launch - never on the launch path again).
+struct DeviceInfo {
+    int cus = 256;                 // compute units
+    size_t lds_per_cu = 160 * 1024;   // bytes of LDS a workgroup may be granted (gfx950: 160 KB per CU)
+};
+static const DeviceInfo& device_info() {
+    static DeviceInfo di = [] {
+        DeviceInfo d;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            if (prop.multiProcessorCount > 0) d.cus = prop.multiProcessorCount;
+            if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024) d.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+        }
+        (void)hipGetLastError();
+        return d;
+    }();
+    return di;
+}
+// Options: what a test or a tuning run may override (ttm_set_option).  The defaults come from the environment
+// (TTM_<NAME IN UPPER CASE>), which is read ONCE, when the library is first used - never on the launch path.
+// -1 = "let the launch planning decide".
+#define TTM_OPTIONS(X)                                                                                                   \
+    X(no_plan, 0)        /* 1: generic kernels instead of the planned-cache ones                                     */ \
+    X(no_uform, 0)       /* 1: direct kernels instead of the U-form ones                                             */ \
+    X(u_no_hot, 0)       /* 1: U-form kernels without hot records                                                    */ \
+    X(u_loader, -1)      /* 0 / 1: loader-wave forward kernels off / on whatever the ensemble size                   */ \
+    X(forward_ns, -1)    /* samples per thread of the generic forward kernels (1, 2, 4)                              */ \
+    X(inverse_ns, -1)    /* samples per thread of the generic table inverse (1, 2)                                   */ \
+    X(u_ns, -1)          /* samples per thread of k_forward_u (1, 2, 4)                                              */ \
+    X(hl_ns, -1)         /* samples per evaluating thread of k_forward_hl (2, 4)                                     */ \
+    X(u_xlead, -1)       /* ring depths of the loader-wave forward kernels                                           */ \
+    X(u_tlead, -1)                                                                                                       \
+    X(u_wgs, -1)         /* workgroups per CU of the U-form forward kernels                                          */ \
+    X(rt_off, 0)         /* 1: table inverse through the generic kernel instead of k_inverse_rt                      */ \
+    X(rt_threads, -1)    /* threads per workgroup of k_inverse_rt (multiple of 64, <= 1024)                          */ \
+    X(rt_ns, -1)         /* rows per thread of k_inverse_rt (2, 4)                                                   */ \
+    X(rt_block, -1)      /* components per block of k_inverse_rt                                                     */ \
+    X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */
+struct Tuning {
+#define X(name, dflt) int name = dflt;
+    TTM_OPTIONS(X)
+#undef X
+};
+static Tuning tuning_from_env() {
+    Tuning u;
+    auto geti = [](const char* name, int dflt) {
+        char env[64] = "TTM_";
+        size_t n = 4;
+        for (const char* c = name; *c && n < sizeof(env) - 1; ++c) env[n++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+        env[n] = 0;
+        const char* e = getenv(env);
+        return e ? atoi(e) : dflt;
+    };
+#define X(name, dflt) u.name = geti(#name, dflt);
+    TTM_OPTIONS(X)
+#undef X
+    return u;
+}
+static Tuning& tuning() {
+    static Tuning t = tuning_from_env();
+    return t;
+}
+
 static int grid_for(int64_t N, int per_block) {
     int64_t tiles = (N + per_block - 1) / per_block;
-    const int64_t cap = 256 * 8;              // 256 CUs x up to 8 resident workgroups
+    const int64_t cap = (int64_t)device_info().cus * 8;       // up to 8 resident workgroups per CU
     if (tiles > cap) tiles = cap;
     if (tiles < 1) tiles = 1;
     return (int)tiles;
@@ -1800,7 +1996,7 @@ static int validate(const ttm_program* p, int k0, int k1) {
 
 // do all components of [ka,kb) take the fast path (planned-cache kernels)?
 static bool all_fast(const ttm_program* p, int ka, int kb) {
-    if (getenv("TTM_NO_PLAN")) return false;                              // tuning / test knob: generic kernels
+    if (tuning().no_plan) return false;                                   // (option: generic kernels)
     for (int k = ka; k < kb; ++k)
         if (p->h_complex[k]) return false;
     return true;
@@ -1842,6 +2038,20 @@ const char* ttm_last_error_string(void) { return g_err; }
 int ttm_version(void) { return TTM_VERSION; }
 
 const char* ttm_last_kernel(void) { return g_last_kernel; }
+
+int ttm_set_option(const char* name, int32_t value) {
+    if (!name) return set_err(TTM_E_ARG, "ttm_set_option: null name%s");
+    Tuning& t = tuning();
+#define X(field, dflt) if (!strcmp(name, #field)) { t.field = (int)value; return TTM_OK; }
+    TTM_OPTIONS(X)
+#undef X
+    return set_err(TTM_E_ARG, "ttm_set_option: unknown option '%s'", name);
+}
+
+int ttm_reset_options(void) {
+    tuning() = tuning_from_env();
+    return TTM_OK;
+}
 
 int64_t ttm_program_sizeof(void) { return (int64_t)sizeof(ttm_program); }
 
@@ -1930,7 +2140,7 @@ static int plan_ways_of(const ttm_program* p) {
 }
 
 static bool u_on(const ttm_program* p) {
-    return p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo && p->h_ucomp && p->h_ugrp && !getenv("TTM_NO_UFORM");
+    return p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo && p->h_ucomp && p->h_ugrp && !tuning().no_uform;
 }
 
 int64_t ttm_fold_size(const ttm_program* p) {
@@ -1966,7 +2176,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const int nsl = map_slots(p, k0, k1);
     // several samples per thread: the scalar (table-interpreter) work is paid once per NS*64 samples
     int NS = N >= 4 * 256 * 256 ? 2 : 1;
-    if (const char* e = getenv("TTM_FORWARD_NS")) NS = atoi(e);           // tuning knob
+    if (tuning().forward_ns > 0) NS = tuning().forward_ns;
     if (NS != 1 && NS != 2 && NS != 4) NS = 1;
     while (NS > 1 && !pick_block(nsl, 0, NS)) NS >>= 1;
     const int bd = pick_block(nsl, 0, NS);
@@ -1991,26 +2201,27 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             nchmax = (nimax * TTM_U_TSTRIDE * 8 + 1023) >> 10;
             const int tab_slot = TTM_U_TSTRIDE * nimax;                   // doubles (nI is even: 16-byte multiple)
             int xlead = 3, tlead = 2;
-            if (const char* e = getenv("TTM_U_XLEAD")) xlead = atoi(e);
-            if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
+            const Tuning& tn = tuning();
+            if (tn.u_xlead > 0) xlead = tn.u_xlead;
+            if (tn.u_tlead > 0) tlead = tn.u_tlead;
             xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
             tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
             // samples per evaluating thread of the hot kernels: four (a wave issues at most one fp64 instruction every
             // ~8 cycles and a dependent one only after ~30, tools/micro/fp64_peak.hip: the Horner chains of four
             // samples interleave to that rate; with two the chains wait on themselves)
             int hNS = 4;
-            if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
-            const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !getenv("TTM_U_NO_HOT");
+            if (tn.hl_ns > 0) hNS = tn.hl_ns == 4 ? 4 : 2;
+            const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !tn.u_no_hot;
             const int hcw = TTM_HL_FWD_CW(logdet != nullptr);            // evaluating waves per workgroup of the hot kernel
             const int rows = hot ? hcw * 64 * hNS : TTM_UL_ROWS;
             auto lds_for = [&](int xl, int tl) { return ((size_t)(xl + 1) * rows + (size_t)(tl + 1) * tab_slot + (size_t)2 * ways * rows + TTM_EXPQ_TABLE_LEN) * 8; };
-            if (hot && !getenv("TTM_U_XLEAD") && !getenv("TTM_U_TLEAD")) {
+            if (hot && tn.u_xlead <= 0 && tn.u_tlead <= 0) {
                 // shallower rings when they buy a workgroup per CU (more independent phases per CU outweigh the look-ahead:
                 // 0.155 -> 0.152 ms at C5 with five workgroups and one-step rings)
                 static const int cand[4][2] = {{3, 2}, {2, 2}, {2, 1}, {1, 1}};
                 size_t best = 0;
                 for (int c = 0; c < 4; ++c) {
-                    size_t w = (size_t)(160 * 1024) / lds_for(cand[c][0], cand[c][1]);
+                    size_t w = device_info().lds_per_cu / lds_for(cand[c][0], cand[c][1]);
                     if (w > (size_t)(32 / (hcw + 2))) w = 32 / (hcw + 2);
                     if (w > best) { best = w; xlead = cand[c][0]; tlead = cand[c][1]; }
                 }
@@ -2020,8 +2231,8 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                                  (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) &&
                                  (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0) &&
                                  ((uintptr_t)(fold + fold_base_size(p)) % 16 == 0);
-            bool use_ul = aligned && N >= 64 * 1024 && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 / 2;
-            if (const char* e = getenv("TTM_U_LOADER")) use_ul = aligned && nchmax <= 15 && lds_ul <= (size_t)160 * 1024 && atoi(e) != 0;
+            bool use_ul = aligned && N >= 64 * 1024 && nchmax <= 15 && lds_ul <= device_info().lds_per_cu / 2;
+            if (tn.u_loader >= 0) use_ul = aligned && nchmax <= 15 && lds_ul <= device_info().lds_per_cu && tn.u_loader != 0;
             if (use_ul && hot) {
                 typedef void (*hkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*,
                                         int64_t, double*, const double*, double*, int, int, int, int);
@@ -2035,12 +2246,12 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                     else hk = logdet ? TTM_HK(true, 4, 4) : TTM_HK(false, 4, 4);
                 }
 #undef TTM_HK
-                int wgs = (int)((size_t)(160 * 1024) / lds_ul);
+                int wgs = (int)(device_info().lds_per_cu / lds_ul);
                 if (wgs > 32 / (hcw + 2)) wgs = 32 / (hcw + 2);
                 if (wgs < 1) wgs = 1;
-                if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+                if (tn.u_wgs > 0) wgs = tn.u_wgs;
                 const int64_t tiles = (N + rows - 1) / rows;
-                const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
+                const int64_t grid = tiles < (int64_t)device_info().cus * wgs ? tiles : (int64_t)device_info().cus * wgs;
                 allow_big_lds((const void*)hk, lds_ul);
                 hipLaunchKernelGGL(hk, dim3((unsigned)grid), dim3((hcw + 2) * 64), lds_ul, (hipStream_t)stream, p->ucomp,
                                    fold + fold_base_size(p), (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz,
@@ -2062,12 +2273,12 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
                 lkern_t lk = logdet ? (cls == 0 ? k_forward_ul<true, 3, 1> : cls == 1 ? k_forward_ul<true, 5, 5> : k_forward_ul<true, 7, 7>)
                                     : (cls == 0 ? k_forward_ul<false, 3, 1> : cls == 1 ? k_forward_ul<false, 5, 5> : k_forward_ul<false, 7, 7>);
-                int wgs = (int)((size_t)(160 * 1024) / lds_ul);
+                int wgs = (int)(device_info().lds_per_cu / lds_ul);
                 if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);                                    // 6 waves per workgroup, 32 per CU
                 if (wgs < 1) wgs = 1;
-                if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
+                if (tn.u_wgs > 0) wgs = tn.u_wgs;
                 const int64_t tiles = (N + TTM_UL_ROWS - 1) / TTM_UL_ROWS;
-                const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
+                const int64_t grid = tiles < (int64_t)device_info().cus * wgs ? tiles : (int64_t)device_info().cus * wgs;
                 allow_big_lds((const void*)lk, lds_ul);
                 hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds_ul, (hipStream_t)stream, p->ucomp, p->ugrp,
                                    fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq,
@@ -2076,7 +2287,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             }
         }
         int uNS = N >= 2 * 256 * 256 ? 2 : 1;
-        if (const char* e = getenv("TTM_U_NS")) uNS = atoi(e);
+        if (tuning().u_ns > 0) uNS = tuning().u_ns;
         if (uNS != 1 && uNS != 2 && uNS != 4) uNS = 2;
         const int ubd = 256;
         const size_t lds = ((size_t)2 * tab_cap + (size_t)2 * ways * uNS * ubd) * 8;
@@ -2094,17 +2305,16 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 }
             }
             const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
-            if (getenv("TTM_U_GENERIC_DEG")) { /* tuning knob: per-group degrees */ }
 #define TTM_UK(L, NSV) (cls == 0 ? k_forward_u<L, NSV, 3, 1> : cls == 1 ? k_forward_u<L, NSV, 5, 5> : k_forward_u<L, NSV, 7, 7>)
             ukern_t uk = logdet ? (uNS == 4 ? TTM_UK(true, 4) : uNS == 2 ? TTM_UK(true, 2) : TTM_UK(true, 1))
                                 : (uNS == 4 ? TTM_UK(false, 4) : uNS == 2 ? TTM_UK(false, 2) : TTM_UK(false, 1));
 #undef TTM_UK
-            int wgs_per_cu = (int)((size_t)(160 * 1024) / (lds ? lds : 1));
+            int wgs_per_cu = (int)(device_info().lds_per_cu / (lds ? lds : 1));
             if (wgs_per_cu > 8) wgs_per_cu = 8;
             if (wgs_per_cu < 1) wgs_per_cu = 1;
-            if (const char* e = getenv("TTM_U_WGS")) wgs_per_cu = atoi(e) > 0 ? atoi(e) : wgs_per_cu;
+            if (tuning().u_wgs > 0) wgs_per_cu = tuning().u_wgs;
             int64_t tiles = (N + (int64_t)uNS * ubd - 1) / ((int64_t)uNS * ubd);
-            int64_t grid = tiles < (int64_t)256 * wgs_per_cu ? tiles : (int64_t)256 * wgs_per_cu;
+            int64_t grid = tiles < (int64_t)device_info().cus * wgs_per_cu ? tiles : (int64_t)device_info().cus * wgs_per_cu;
             hipLaunchKernelGGL(uk, dim3((unsigned)grid), dim3(ubd), lds, (hipStream_t)stream, p->ucomp, p->ugrp,
                                fold + fold_base_size(p), (int)p->D, (int)k0, (int)k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, tab_cap);
             return check_launch("k_forward_u");
@@ -2184,51 +2394,64 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         T < 8 || T > 65536 || nb < 4 || nb > 65536 || (ldy != 0 && ldy < T) || (h_y_affine && ldy != 0))
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
-    // large ensembles of maps with hot records: loader-wave kernel
+    // large ensembles of maps with hot records: resident-table kernel (components in blocks, tables resident in LDS)
     if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
-        h_y_affine && ldy == 0 && (nb + 1) % 4 == 0 && T <= 4096 && !getenv("TTM_U_NO_HOT")) {
+        h_y_affine && ldy == 0 && T <= 4096 && nb <= 65535 && N >= 64 * 1024 && N < ((int64_t)1 << 28) && !tuning().rt_off && !tuning().u_no_hot) {
+        const DeviceInfo& di = device_info();
+        const Tuning& tn = tuning();
         const int ways = plan_ways_of(p);
-        int xlead = 2, tlead = 1;          // (three workgroups per CU with the 12 KB table slots)
-        if (const char* e = getenv("TTM_U_XLEAD")) xlead = atoi(e);
-        if (const char* e = getenv("TTM_U_TLEAD")) tlead = atoi(e);
-        xlead = xlead < 1 ? 1 : (xlead > 4 ? 4 : xlead);
-        tlead = tlead < 1 ? 1 : (tlead > 2 ? 2 : tlead);
-        const int Teven = (T + 4 + 1) & ~1;                              // entries + 4 sentinels, even
-        const int tab_slot = Teven + (nb + 1 + 1) / 2;                   // doubles
-        const int nops = ((((T * 8) & ~15) + 1023) >> 10) + ((T & 1) ? 1 : 0) + (((nb + 1) * 4 + 1023) >> 10);
-        int hNS = 2;
-        if (const char* e = getenv("TTM_HL_NS")) hNS = atoi(e) == 4 ? 4 : 2;
-        const int rows = TTM_UL_CT * hNS;
-        const size_t lds = ((size_t)(xlead + 1) * rows + (size_t)(tlead + 1) * tab_slot + (size_t)2 * ways * hNS * TTM_UL_CT + TTM_EXPQ_TABLE_LEN) * 8;
+        const int ncomp = k1 - k0;
+        const int NS = tn.rt_ns == 4 ? 4 : 2;
+        const int Teven = (T + 4 + 1) & ~1;
+        const int tab_slot = TTM_RT_HDR + Teven + (((nb + 1 + 3) / 4 + 1) & ~1);   // doubles: header + xs row + uint16 bucket index (even)
+        const double ymax = fabs(h_y_affine[0]) > fabs(h_y_affine[2]) ? fabs(h_y_affine[0]) : fabs(h_y_affine[2]);
+        bool etab = truncate && h_y_affine[1] > 0.0 && h_y_affine[1] * ymax * 0.5 <= 0.1;
+        if (tn.rt_etab == 0) etab = false;
         const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
-                             ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ((uintptr_t)bkt % 16 == 0) && ((uintptr_t)tab_x % 8 == 0);
-        bool use = aligned && N >= 64 * 1024 && nops <= 15 && lds <= (size_t)160 * 1024 / 2;
-        if (const char* e = getenv("TTM_U_LOADER")) use = aligned && nops <= 15 && lds <= (size_t)160 * 1024 && atoi(e) != 0;
-        if (use) {
-            typedef void (*ikern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t,
-                                    const double*, int, double, double, double, const double*, const double*, const int*, int, int,
-                                    int, int, int, int);
-            ikern_t ik;
-#define TTM_IK(NGV, NSV) (p->u_h_cls == 1 ? k_inverse_hl<NGV, 1, NSV> : p->u_h_cls == 2 ? k_inverse_hl<NGV, 2, NSV> : k_inverse_hl<NGV, 3, NSV>)
-            if (hNS == 2) { if (p->u_h_ng == 2) ik = TTM_IK(2, 2); else ik = TTM_IK(4, 2); }
-            else { if (p->u_h_ng == 2) ik = TTM_IK(2, 4); else ik = TTM_IK(4, 4); }
-#undef TTM_IK
-            int wgs = (int)((size_t)(160 * 1024) / lds);
-            if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);
-            if (wgs < 1) wgs = 1;
-            if (const char* e = getenv("TTM_U_WGS")) wgs = atoi(e) > 0 ? atoi(e) : wgs;
-            const int64_t tiles = (N + rows - 1) / rows;
-            const int64_t grid = tiles < (int64_t)256 * wgs ? tiles : (int64_t)256 * wgs;
-            allow_big_lds((const void*)ik, lds);
-            hipLaunchKernelGGL(ik, dim3((unsigned)grid), dim3(TTM_UL_THREADS), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
+                             ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1);
+        const int wgs = 1;                                               // the tables + the column cache fill the LDS of a CU
+        int CT = tn.rt_threads >= 64 && tn.rt_threads <= 1024 ? (tn.rt_threads & ~63) : 1024;
+        const size_t budget = di.lds_per_cu / wgs;
+        int Bc = 0;
+        size_t lds = 0;
+        for (; CT >= 256; CT -= 256) {                                   // fewer rows in flight if the tables would not fit
+            const size_t fixed = ((size_t)(etab ? Teven : 0) + (size_t)2 * ways * NS * CT) * 8;
+            if (fixed + (size_t)tab_slot * 8 > budget) continue;
+            Bc = (int)((budget - fixed) / ((size_t)tab_slot * 8));
+            if (Bc > ncomp) Bc = ncomp;
+            if (tn.rt_block > 0 && tn.rt_block < Bc) Bc = tn.rt_block;
+            const int nblk = (ncomp + Bc - 1) / Bc;
+            Bc = (ncomp + nblk - 1) / nblk;                              // even out the blocks
+            lds = fixed + (size_t)Bc * tab_slot * 8;
+            if (Bc >= 4 || Bc == ncomp) break;
+            Bc = 0;
+        }
+        if (aligned && Bc > 0) {
+            typedef void (*rkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t,
+                                    int64_t, const double*, int, double, double, double, const double*, const double*, const int*, int,
+                                    int, int, int, int, int64_t);
+            rkern_t rk;
+#define TTM_RK3(NGV, CLSV, NSV) (etab ? k_inverse_rt<NGV, CLSV, NSV, true> : k_inverse_rt<NGV, CLSV, NSV, false>)
+#define TTM_RK(NGV, NSV) (p->u_h_cls == 1 ? TTM_RK3(NGV, 1, NSV) : p->u_h_cls == 2 ? TTM_RK3(NGV, 2, NSV) : TTM_RK3(NGV, 3, NSV))
+            if (NS == 2) { if (p->u_h_ng == 2) rk = TTM_RK(2, 2); else rk = TTM_RK(4, 2); }
+            else { if (p->u_h_ng == 2) rk = TTM_RK(2, 4); else rk = TTM_RK(4, 4); }
+#undef TTM_RK
+#undef TTM_RK3
+            // every workgroup gets the same (even) number of rows
+            const int nwg = di.cus * wgs;
+            int64_t rows = (N + nwg - 1) / nwg;
+            rows = (rows + 1) & ~(int64_t)1;
+            const int64_t grid = (N + rows - 1) / rows;
+            allow_big_lds((const void*)rk, lds);
+            hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(CT), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
                                (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine[0],
-                               h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, xlead, tlead, ways);
-            return check_launch("k_inverse_hl");
+                               h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, Bc, ways, rows);
+            return check_launch("k_inverse_rt");
         }
     }
     const int bd = 256;
     int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)
-    if (const char* e = getenv("TTM_INVERSE_NS")) NS = atoi(e) == 2 ? 2 : 1;      // tuning knob
+    if (tuning().inverse_ns > 0) NS = tuning().inverse_ns == 2 ? 2 : 1;
     const bool planned = all_fast(p, k0, k1);
     auto kern = NS == 2 ? k_inverse_table<2, false, -1> : k_inverse_table<1, false, -1>;
     if (planned) {

@@ -108,9 +108,6 @@ TTM_HD R exp_q_fast(const R& x) {
 #else
     const double* kc = g_exp_coef;
 #endif
-#ifdef TTM_EXPERIMENT_OLD_EXP      // A/B timing switch
-    return fast_exp(-0.25 * (x * x));
-#endif
     const R y = vmax(-0.25 * (x * x), -800.0);
     const R k = vrint(y * 1.4426950408889634);
     R r = vfma(-k, 6.93147180369123816490e-01, y);

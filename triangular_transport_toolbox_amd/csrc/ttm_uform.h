@@ -493,11 +493,7 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const ST& st
         u_spline_gather<0, H>(tab, ix, q);
         TTM_SCHED_FENCE();
         // phase 2: arithmetic that needs none of them (the exp of the column cache) behind their latency
-#ifdef TTM_EXPERIMENT_NO_EXP
-        const R ek = xk * rec[3];
-#else
         const R ek = (ETAB ? exp_q_tab(st.etab, xk) : exp_q_fast(xk));
-#endif
         TTM_SCHED_FENCE();
         // phase 3: spline of the first half; then the second half's gather behind the groups
         R m, dm(0.0);
