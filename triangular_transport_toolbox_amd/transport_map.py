@@ -953,92 +953,106 @@ class transport_map():
 
     def adapt_map(self, coeffs={}, maxorder_mon=10, maxorder_nonmon=10, threshold_sw=0.1, threshold_prec=0.1,
                   sequential_updates=False, map_finished=None):
-        """TM:373-636, adaptation_map_type = 'separable': (1) marginal phase - every component starts as [[k]] and gets
-        one more 'iRBF k' per round until its pushforward marginal passes a Shapiro-Wilk test (p >= threshold_sw) or
-        maxorder_mon is reached; (2) off-diagonal phase - for every pair (k, j < k) whose standardised precision
-        (first round) / correlation (later rounds) of the pushforward exceeds threshold_prec, one more nonmonotone
-        term [j]*order (+ 'HF' from order 2 on) per round, until all pairs are finished or maxorder_nonmon rounds.
-        Every round re-specifies the map (coefficients back to coeffs_init, special terms re-placed), optimises all
-        components and maps the training ensemble - the hot path; the statistics on the N x D pushforward are the
-        reference's NumPy / SciPy calls on the host."""
+        """Greedy growth of the term lists (reference behaviour: TM:373-636 for adaptation_map_type = 'separable',
+        TM:4575-4950 for 'cross-terms').
+
+        'separable' runs two phases on the resident ensemble, each round = re-specify (coefficients back to
+        coeffs_init, special terms re-placed) -> optimize -> map, i.e. the hot path; only the statistics on the N x D
+        pushforward are host NumPy / SciPy:
+          1. marginals: every component starts as the linear term [[k]]; while its pushforward marginal fails a
+             Shapiro-Wilk test (p < threshold_sw) it gets one more 'iRBF k' per round, up to maxorder_mon;
+          2. dependence: a pair (k, j < k) whose dependence statistic exceeds threshold_prec gets one more nonmonotone
+             term in x_j per round ([j], then [j, j, 'HF'], [j, j, j, 'HF'], ...); a pair that falls below the threshold
+             once is closed for good.  The statistic is the standardised precision of the pushforward in the first
+             round and its correlation afterwards."""
         if self.adaptation_map_type == 'cross-terms':
             return self.adaptation_cross_terms(*coeffs)                                                  # (TM:642)
         if self.adaptation_map_type != 'separable':
             raise Exception("Currently, only adaptation_map_type = 'cross-terms' is implemented.")      # (TM:648, sic)
+        D = self.D
+        spec = {'monotone': [[[k]] for k in range(D)], 'nonmonotone': [[[]] for _ in range(D)]}
+        orders = np.zeros((D, D), dtype=int)
+        orders[np.arange(D), np.arange(D)] = 1
+        Z = self._adapt_marginals(spec, orders, maxorder_mon, threshold_sw)
+        # the reference keeps both dependence matrices of the marginal fit (absolute correlation, absolute standardised
+        # precision) as attributes; the second phase recomputes what it uses
+        self.covmat = self._unit_diagonal(np.abs(np.cov(Z.T)))
+        self.precmat = self._unit_diagonal(np.abs(np.linalg.inv(np.cov(Z.T))))
+        closed = np.zeros((D, D), dtype=bool) if map_finished is None else map_finished
+        self._adapt_dependence(spec, orders, closed, maxorder_nonmon, threshold_prec)
+        self._respecify(spec['monotone'], spec['nonmonotone'])
+        self.optimize()
+        self.maporders = orders
+
+    @staticmethod
+    def _unit_diagonal(M):
+        """M scaled to unit diagonal: M_ij / sqrt(M_ii M_jj) (columns first, then rows, as the reference divides)."""
+        M = np.array(M, dtype=float, copy=True)
+        root = np.sqrt(np.diag(M))
+        M /= root[np.newaxis, :]
+        M /= root[:, np.newaxis]
+        return M
+
+    def _fit_and_push(self, spec):
+        """One adaptation round on the device: new term lists, optimisation of every component, pushforward of the
+        training ensemble."""
+        self._respecify(spec['monotone'], spec['nonmonotone'])
+        self.optimize()
+        return self.map()
+
+    def _adapt_marginals(self, spec, orders, max_terms, p_accept):
+        """Phase 1 of the separable adaptation (marginal Gaussianisation).  `orders[k, k + skip]` counts the monotone
+        terms of component k; self.pvals_mat is not kept by the reference either (a local there)."""
         import scipy.stats
         D = self.D
-        nonmonotone = [[[]] for x in np.arange(D)]
-        monotone = [[[x]] for x in np.arange(D)]
-        Gaussianized = np.zeros(D, dtype=bool)
-        iterate, iteration = True, 0
-        maporders = np.zeros((D, D), dtype=int)
-        np.fill_diagonal(maporders, 1)
-        pvals_mat = np.zeros((maxorder_mon, D))
-        while iterate:
-            iteration += 1
-            self._respecify(monotone, nonmonotone)
-            self.optimize()
-            Z = self.map()
-            pval = np.zeros(D)
-            for k in range(D):
-                pval[k] = scipy.stats.shapiro(Z[:, k]).pvalue
-            pvals_mat[iteration - 1, :] = copy.copy(pval)
-            for idx in np.where(pval >= threshold_sw)[0]:
-                Gaussianized[np.arange(D)[idx]] = True
-            for k in np.where(~Gaussianized)[0]:
-                if maporders[k, k + self.skip_dimensions] < maxorder_mon:
-                    maporders[k, k + self.skip_dimensions] += 1
-                    monotone[k] += ['iRBF ' + str(k)]
-            if np.sum(Gaussianized) == D:
-                iterate = False
-            if iteration >= maxorder_mon - 1:
-                iterate = False
-        covmat = np.abs(np.cov(Z.T))
-        diagval = np.sqrt(np.diag(covmat))
-        covmat /= diagval[np.newaxis, :]
-        covmat /= diagval[:, np.newaxis]
-        precmat = np.abs(np.linalg.inv(np.cov(Z.T)))
-        diagval = np.sqrt(np.diag(precmat))
-        precmat /= diagval[np.newaxis, :]
-        precmat /= diagval[:, np.newaxis]
-        self.covmat, self.precmat = copy.copy(covmat), copy.copy(precmat)
-        iterate, iteration = True, 0
-        if map_finished is None:
-            map_finished = np.zeros((D, D), dtype=bool)
-        while iterate:
-            iteration += 1
-            self._respecify(monotone, nonmonotone)
-            self.optimize()
-            Z = self.map()
+        accepted = np.zeros(D, dtype=bool)
+        rounds = 0
+        while True:
+            rounds += 1
+            Z = self._fit_and_push(spec)
+            p = np.array([scipy.stats.shapiro(Z[:, k]).pvalue for k in range(D)])
+            accepted |= p >= p_accept                      # a component that passed once stays accepted
+            for k in np.flatnonzero(~accepted):
+                col = k + self.skip_dimensions
+                if orders[k, col] < max_terms:
+                    orders[k, col] += 1
+                    spec['monotone'][k] += ['iRBF ' + str(k)]
+            if accepted.all() or rounds >= max_terms - 1:
+                return Z
+
+    def _adapt_dependence(self, spec, orders, closed, max_rounds, threshold):
+        """Phase 2 of the separable adaptation.  Any exception while the lists are being extended ends the phase, as
+        in the reference (TM:614) - notably the list sort, which cannot order a term with the 'HF' marker against a
+        longer all-integer prefix; what was appended before the exception stays."""
+        D = self.D
+        rounds = 0
+        while True:
+            rounds += 1
+            Z = self._fit_and_push(spec)
+            stop = False
             try:
-                if iteration == 1:
-                    precmat = np.abs(np.linalg.inv(np.cov(Z.T)))
-                    diagval = np.sqrt(np.diag(precmat))
-                    precmat /= diagval[np.newaxis, :]
-                    precmat /= diagval[:, np.newaxis]
+                if rounds == 1:
+                    stat = self._unit_diagonal(np.abs(np.linalg.inv(np.cov(Z.T))))
                 else:
-                    precmat = np.corrcoef(Z.T)
+                    stat = np.corrcoef(Z.T)
                 for k in range(D):
                     for j in range(k):
-                        if precmat[k, j] > threshold_prec and not map_finished[k, j]:
-                            maporders[k, j] += 1
-                            if maporders[k, j] == 1:
-                                nonmonotone[k].append([j] * maporders[k, j])
-                            else:
-                                nonmonotone[k].append([j] * maporders[k, j] + ['HF'])
+                        if stat[k, j] > threshold and not closed[k, j]:
+                            orders[k, j] += 1
+                            term = [j] * orders[k, j]
+                            spec['nonmonotone'][k].append(term if orders[k, j] == 1 else term + ['HF'])
                         else:
-                            map_finished[k, j] = True
-                    nonmonotone[k].sort()
-            except Exception:                  # noqa: BLE001  (TM:614: anything that fails here ends the iteration)
-                iterate = False
-            if np.sum(map_finished) >= D * (D - 1) / 2:
-                iterate = False
-            if iteration >= maxorder_nonmon:
+                            closed[k, j] = True
+                    spec['nonmonotone'][k].sort()
+            except Exception:                      # noqa: BLE001
+                stop = True
+            if np.sum(closed) >= D * (D - 1) / 2:
+                stop = True
+            if rounds >= max_rounds:
                 print("WARNING: Map adaptation stopped at maximum number of iterations.")
-                iterate = False
-        self._respecify(monotone, nonmonotone)
-        self.optimize()
-        self.maporders = maporders
+                stop = True
+            if stop:
+                return
 
     def _respecify_component(self, k, monotone_k, nonmonotone_k):
         """New term lists for component k only (the reference's function_constructor_alternative(k = k), TM:1304-1310):
@@ -1083,12 +1097,12 @@ class transport_map():
             M[tuple([0] * nvar)] = 1
             M[tuple([0] * (nvar - 1) + [1])] = 1
             self.multi_index_matrix = M
-            coeffs = np.asarray(list(copy.copy(self.coeffs_nonmon[k])) + list(copy.copy(self.coeffs_mon[k])))
+            coeffs = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float), np.asarray(self.coeffs_mon[k], dtype=float)))
             div = len(self.coeffs_nonmon[k])
             opt = minimize(method='BFGS', fun=self.objective_function, jac=self.objective_function_jacobian, x0=coeffs,
                            args=(k, div))
-            coeffs = copy.copy(opt.x)
-            self.coeffs_nonmon[k], self.coeffs_mon[k] = copy.copy(coeffs[:div]), copy.copy(coeffs[div:])
+            coeffs = np.array(opt.x, copy=True)
+            self.coeffs_nonmon[k], self.coeffs_mon[k] = coeffs[:div].copy(), coeffs[div:].copy()
             rounds = 0
             history[k] = {}
             while True:
@@ -1110,7 +1124,7 @@ class transport_map():
                 candidates = np.asarray(np.where(M <= -nvar)).T
                 if self.verbose:
                     print(M)
-                coeffs = copy.copy(np.asarray(list(copy.copy(self.coeffs_nonmon[k])) + list(copy.copy(self.coeffs_mon[k]))))
+                coeffs = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float), np.asarray(self.coeffs_mon[k], dtype=float)))
                 obj_ref = self.objective_function(coeffs=coeffs, k=k, div=div)
                 grads = np.zeros(len(candidates))
                 for ci, cell in enumerate(candidates):
@@ -1133,8 +1147,8 @@ class transport_map():
                 div = len(nonmono)
                 self._respecify_component(k, mono, nonmono)
                 opt = minimize(method='L-BFGS-B', fun=self.objective_function, x0=start, args=(k, div))
-                coeffs = copy.copy(opt.x)
-                self.coeffs_nonmon[k], self.coeffs_mon[k] = copy.copy(coeffs[:div]), copy.copy(coeffs[div:])
+                coeffs = np.array(opt.x, copy=True)
+                self.coeffs_nonmon[k], self.coeffs_mon[k] = coeffs[:div].copy(), coeffs[div:].copy()
                 history[k][rounds] = dict(monotone=copy.deepcopy(self.monotone[k]), nonmonotone=copy.deepcopy(self.nonmonotone[k]),
                                           coeffs_nonmon=copy.copy(self.coeffs_nonmon[k]), coeffs_mon=copy.copy(self.coeffs_mon[k]),
                                           multi_index_matrix=copy.copy(M))
