@@ -226,11 +226,17 @@ def other_configs(torch, names, steps=40):
         for k in range(tm.D):
             tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
             tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tm.optimize()
-        torch.cuda.synchronize()
-        r['optimize_s'], r['optimize_N'] = time.perf_counter() - t0, Nopt
+        def timed_optimize():
+            for k in range(tm.D):
+                tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
+                tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tm.optimize()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        r['optimize_first_call_s'] = timed_optimize()
+        r['optimize_s'], r['optimize_N'] = timed_optimize(), Nopt
         out[name] = r
         del tm
     return out
@@ -488,11 +494,18 @@ def main():
         for k in range(D):
             tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
             tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
-        torch.cuda.synchronize()
-        t0o = time.perf_counter()
-        tm.optimize()
-        torch.cuda.synchronize()
-        extra['optimize_s'] = time.perf_counter() - t0o
+        def timed_optimize():
+            for k in range(D):
+                tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
+                tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
+            torch.cuda.synchronize()
+            t0o = time.perf_counter()
+            tm.optimize()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0o
+        # the first call of a process also loads the code objects of the reduction kernels (~0.15 s, once)
+        extra['optimize_first_call_s'] = timed_optimize()
+        extra['optimize_s'] = timed_optimize()
         tm.coeffs_mon, tm.coeffs_nonmon = saved
     if world == 1 and not args.no_other_configs and args.workload == 'C5':
         try:

@@ -409,7 +409,7 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
 /* The same reduction for an optimiser that lives on the host (TM:3108-3114, 3252-3257 drive SciPy with one
  * objective / gradient evaluation per call, so the per-call latency is what optimize() costs):
  * h_coef_k is a HOST vector (<= 64 coefficients) that travels as kernel arguments - no host-to-device copy; the
- * finishing sum runs in the workgroup that draws the last ticket of `counter` (device uint32, zero before the first
+ * finishing sum runs in the workgroup that draws the last ticket of `counter` (device uint32[16], zero before the first
  * call; left zero) in the order of the three-launch path, so both give the same bits; `out` may be pinned host
  * memory (device-accessible), which also saves the device-to-host copy.  Two launches instead of three + two copies. */
 int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa,
@@ -430,6 +430,29 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
  * work: >= ttm_reduce_work_size(m*m) doubles.                                                      */
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N,
              double* work, double* out, void* stream);
+
+/* ---- optimisers -----------------------------------------------------------------------------------------
+ * TM:3108-3114 (scipy.optimize.minimize, method 'L-BFGS-B': maxcor 10, ftol 2.22e-9, gtol 1e-5, maxls 20) as a host
+ * C++ loop (csrc/ttm_lbfgsb.h: L-BFGS-B 3.0 restated, dense for the few dozen variables of a map component).
+ * ttm_lbfgsb_minimize: generic front end - fun(n, x, &f, g, user) returns 0 or an error code; lb / ub may be NULL or
+ *   hold -inf / +inf for missing bounds; result (nullable, 5 doubles): {f, projected-gradient norm, iterations,
+ *   evaluations, status: 0 = projected gradient <= gtol, 1 = relative reduction <= ftol, 2 = iteration limit,
+ *   3 = abnormal termination in the line search}.
+ * ttm_optimize_separable: the reduced separable problem of one component (TM:2978-3018) minimised without leaving the
+ *   library: J(c) = c'Ac/2 - sum_n log dS_n / Ntotal + c.b with dS = dPsi.c + delta rowsum(dPsi) from the cached
+ *   derivative basis (ttm_objective_sep_cached).  A (m x m, row-major), b, lb, ub, x (start / result): host.
+ *   sums_host: >= 1 + m doubles, pinned host memory the device can write; sums_dev (device, >= 1 + m doubles) and
+ *   comm: non-NULL when the samples are sharded over ranks - the local sums are then combined by ONE
+ *   ttm_allreduce_f64 of the fused [objective | gradient] buffer per evaluation; Ntotal = samples of all ranks.
+ *   One stream synchronisation per evaluation, nothing else crosses the host boundary.                             */
+typedef int32_t (*ttm_objective_cb)(int32_t n, const double* x, double* f, double* g, void* user);
+int ttm_lbfgsb_minimize(int32_t n, double* x, const double* lb, const double* ub, ttm_objective_cb fun, void* user,
+                        int32_t maxiter, double* result);
+struct ttm_comm;
+int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* A, const double* b,
+                           double Ntotal, double delta, const double* lb, const double* ub, double* x, double* work,
+                           uint32_t* counter, double* sums_dev, double* sums_host, struct ttm_comm* comm, void* stream,
+                           int32_t maxiter, double* result);
 
 /* ---- C1: the one collective of the path (RCCL over xGMI) ---------------------------------------------
  * Replaces nothing in the reference (its only parallelism is the fork pool of TM:2789-2845, whose "collective" is

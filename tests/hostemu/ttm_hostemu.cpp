@@ -729,3 +729,7 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
 }
 
 }  // extern "C"
+
+// the optimiser loops of the product, compiled for the host (no streams)
+#define TTM_HOST_ONLY
+#include "../../triangular_transport_toolbox_amd/csrc/ttm_optim.cpp"

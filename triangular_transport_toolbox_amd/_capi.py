@@ -15,6 +15,9 @@ from . import build as _build
 c_i32, c_i64, c_dbl, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
 
+OBJECTIVE_CB = ctypes.CFUNCTYPE(c_i32, c_i32, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_vp)
+
+
 class ttm_program(ctypes.Structure):
     """Mirror of `struct ttm_program` (include/ttm.h)."""
     _fields_ = [('itab', c_vp), ('ftab', c_vp), ('fdesc', c_vp), ('fints', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
@@ -61,6 +64,9 @@ _SIGNATURES = {
     'ttm_objective_host': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'ttm_lbfgsb_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_optimize_separable': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_comm_last_error': (ctypes.c_char_p, []),
     'ttm_comm_unique_id': (ctypes.c_int, [c_vp]),
     'ttm_comm_create': (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),

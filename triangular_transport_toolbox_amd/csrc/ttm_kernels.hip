@@ -1711,6 +1711,33 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k
 #define TTM_RED_BLOCKS 1024
 #define TTM_HOSTCOEF_MAX 64
 
+// "Which workgroup is the last one?" without a thousand atomics on one address (they serialise in the L2: ~75 ns each,
+// 77 us for the 977 workgroups of an N = 1e6 reduction): workgroups draw a ticket from one of 8 group counters
+// (counter[1 + (blockIdx & 7)], different addresses proceed in parallel), the last of a group draws one from
+// counter[0], and the last of those is the last workgroup of the grid.  Every workgroup has made its partial sums
+// visible (__threadfence) before it draws.  counter: 16 uint32, zero before the first launch; left zero.
+__device__ __forceinline__ bool last_workgroup(unsigned int* counter) {
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int g = blockIdx.x & 7u, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned int in_group = (gridDim.x - g + 7u) / 8u;
+        int last = 0;
+        if (atomicAdd(counter + 1 + g, 1u) == in_group - 1u) {
+            __threadfence();
+            last = atomicAdd(counter, 1u) == ngroups - 1u ? 1 : 0;
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        if (threadIdx.x < 9) counter[threadIdx.x] = 0u;
+    }
+    return is_last != 0;
+}
+
 // LDS: erf table | per-thread columns [scratch (nscr) | acc (nacc)]
 __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const double* __restrict__ coef_k,
                                                    const double* __restrict__ fold_k,
@@ -1747,20 +1774,13 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
     if (out) {
         // single-launch variant: the workgroup that draws the last ticket adds the partials up, in the very order
         // k_reduce_partials uses (bit-identical sums), and writes the result - `out` may be pinned host memory
-        __shared__ int is_last;
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) is_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
-        __syncthreads();
-        if (is_last) {
-            __threadfence();
+        if (last_workgroup(counter)) {
             for (int i = wv; i < nacc; i += nw) {
                 double v = 0.0;
                 for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
                 v = wave_sum(v);
                 if (lane == 0) out[i] = v;
             }
-            if (tid == 0) *counter = 0u;
         }
     }
 }
@@ -1788,21 +1808,23 @@ __global__ __launch_bounds__(64) void k_fold_host(DevProg P, int k, HostCoef hc,
 #define TTM_SEPC_MAXM 16
 struct SepCoef { double c[TTM_SEPC_MAXM]; };
 
-__global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __restrict__ dPsi, int64_t ldp, int64_t N, int m,
+template <int M>
+__global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __restrict__ dPsi, int64_t ldp, int64_t N,
                                                               SepCoef hc, double delta, double* __restrict__ partial,
                                                               unsigned int* __restrict__ counter, double* __restrict__ out) {
-    __shared__ double red[4][TTM_SEPC_MAXM + 1];
-    __shared__ int is_last;
+    // M is a template parameter: the M column loads of a row are issued together (a run-time `i < m` guard per load
+    // made every load wait for the one before it: 77 us per launch at N = 1e6, m = 4 - 0.4 TB/s), two rows per
+    // pass of the loop are independent chains
+    __shared__ double red[4][M + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    double acc[TTM_SEPC_MAXM + 1];
+    double acc[M + 1];
 #pragma unroll
-    for (int i = 0; i <= TTM_SEPC_MAXM; ++i) acc[i] = 0.0;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + tid; n < N; n += (int64_t)gridDim.x * blockDim.x) {
-        double d[TTM_SEPC_MAXM];
+    for (int i = 0; i <= M; ++i) acc[i] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto row = [&](const double (&d)[M]) {
         double dS = 0.0, rowsum = 0.0;
 #pragma unroll
-        for (int i = 0; i < TTM_SEPC_MAXM; ++i) {
-            d[i] = i < m ? dPsi[(int64_t)i * ldp + n] : 0.0;
+        for (int i = 0; i < M; ++i) {
             dS = fma(hc.c[i], d[i], dS);
             rowsum += d[i];
         }
@@ -1810,31 +1832,39 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
         acc[0] += fast_log(dS);
         const double inv = fast_rcp(dS);
 #pragma unroll
-        for (int i = 0; i < TTM_SEPC_MAXM; ++i) acc[1 + i] += d[i] * inv;
-    }
-    const int nacc = 1 + m;
+        for (int i = 0; i < M; ++i) acc[1 + i] += d[i] * inv;
+    };
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + tid;
+    for (; n + stride < N; n += 2 * stride) {
+        double d0[M], d1[M];
 #pragma unroll
-    for (int i = 0; i <= TTM_SEPC_MAXM; ++i) {
-        if (i < nacc) {
-            const double v = wave_sum(acc[i]);
-            if (lane == 0) red[wv][i] = v;
-        }
+        for (int i = 0; i < M; ++i) { d0[i] = dPsi[(int64_t)i * ldp + n]; d1[i] = dPsi[(int64_t)i * ldp + n + stride]; }
+        row(d0);
+        row(d1);
+    }
+    if (n < N) {
+        double d0[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) d0[i] = dPsi[(int64_t)i * ldp + n];
+        row(d0);
+    }
+#pragma unroll
+    for (int i = 0; i <= M; ++i) {
+        const double v = wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = v;
     }
     __syncthreads();
+    const int nacc = 1 + M;
     if (tid < nacc) partial[(int64_t)blockIdx.x * nacc + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) is_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
-    __syncthreads();
-    if (is_last) {
-        __threadfence();
+    // counter == nullptr: the finishing sum is a second launch (large grids: a device-scope fence per workgroup - an L2
+    // write-back + invalidate on gfx950 - costs ~60 ns each and they serialise: 64 us for the 977 workgroups of N = 1e6)
+    if (counter && last_workgroup(counter)) {
         for (int i = wv; i < nacc; i += 4) {
             double v = 0.0;
             for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
             v = wave_sum(v);
             if (lane == 0) out[i] = v;
         }
-        if (tid == 0) *counter = 0u;
     }
 }
 
@@ -2554,8 +2584,12 @@ int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, 
     HostCoef hc;
     for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = i < ncoef ? h_coef_k[i] : 0.0;
     hipLaunchKernelGGL(k_fold_host, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, hc, ncoef, coef_dev, fold_k);
+    const bool ticket = nb <= 64;                    // (see ttm_objective_sep_cached)
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k,
-                       (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)counter, out);
+                       (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial,
+                       ticket ? (unsigned int*)counter : (unsigned int*)nullptr, ticket ? out : (double*)nullptr);
+    if (!ticket)
+        hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
     return check_launch("k_objective");
 }
 
@@ -2568,8 +2602,18 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
     for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
     int nb = grid_for(N, 256 * 4);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
-    hipLaunchKernelGGL(k_objective_sep_cached, dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, (int)m, hc, delta,
-                       work + TTM_OBJ_FOLD_MAX, (unsigned int*)counter, out);
+    typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*);
+    static const skern_t kerns[TTM_SEPC_MAXM] = {
+        k_objective_sep_cached<1>, k_objective_sep_cached<2>, k_objective_sep_cached<3>, k_objective_sep_cached<4>,
+        k_objective_sep_cached<5>, k_objective_sep_cached<6>, k_objective_sep_cached<7>, k_objective_sep_cached<8>,
+        k_objective_sep_cached<9>, k_objective_sep_cached<10>, k_objective_sep_cached<11>, k_objective_sep_cached<12>,
+        k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
+    const bool ticket = nb <= 64;                    // small grids: one launch, the last workgroup finishes
+    hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta,
+                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out);
+    if (!ticket)
+        hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
     return check_launch("k_objective_sep_cached");
 }
 

@@ -801,7 +801,7 @@ class transport_map():
             if getattr(self, '_obj_out', None) is None:
                 pin = self._dev.type == 'cuda'
                 self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
-                self._obj_cnt = self._zeros(1, dtype=torch.int32)
+                self._obj_cnt = self._zeros(16, dtype=torch.int32)
             _capi.check(self._lib.ttm_objective_host(self._pp, int(k), ctypes.c_void_p(coef_k.ctypes.data), self._ptr(self._Xs),
                                                      self._Xs.shape[1], self._N, self._ptr(work),
                                                      ctypes.c_void_p(self._obj_cnt.data_ptr()),
@@ -905,7 +905,7 @@ class transport_map():
         precalculate() keeps as der_Psi_mon): every L-BFGS-B evaluation is then one streaming launch."""
         self._sep_cache = None
         m = int(self._cm.n_mon[k])
-        if self._dist() is not None or m < 1 or m > 16:
+        if m < 1 or m > 16:
             return
         torch = _torch()
         dpsi = self._cols(m, self._N)
@@ -914,7 +914,7 @@ class transport_map():
         if getattr(self, '_obj_out', None) is None:
             pin = self._dev.type == 'cuda'
             self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
-            self._obj_cnt = self._zeros(1, dtype=torch.int32)
+            self._obj_cnt = self._zeros(16, dtype=torch.int32)
         self._sep_cache = (int(k), dpsi)
 
     def _sep_cache_end(self):
@@ -924,7 +924,7 @@ class transport_map():
         """TM:2978-3018: (objective, gradient) of the reduced problem."""
         c = np.ascontiguousarray(coeffs_mon, dtype=float)
         cache = getattr(self, '_sep_cache', None)
-        if cache is not None and cache[0] == int(k):
+        if cache is not None and cache[0] == int(k) and self._dist() is None:
             m = len(c)
             work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
             _capi.check(self._lib.ttm_objective_sep_cached(self._ptr(cache[1]), cache[1].shape[1], self._N, m,
@@ -1164,7 +1164,7 @@ class transport_map():
         one evaluation = one ctypes call, one stream synchronisation and O(m^2) host arithmetic.  Same operations on
         the same values as separable_objective (which stays the public method)."""
         cache = getattr(self, '_sep_cache', None)
-        if cache is None or cache[0] != int(k) or self._dev.type != 'cuda':
+        if cache is None or cache[0] != int(k) or self._dev.type != 'cuda' or self._dist() is not None:
             return None
         torch = _torch()
         dpsi = cache[1]
@@ -1190,9 +1190,46 @@ class transport_map():
             return c @ Ax / 2 - sums[0] / N + np.inner(c, b), Ax - sums[1:] / N + b
         return fun
 
+    # separable components are minimised by the library's own L-BFGS-B loop (ttm_optimize_separable: no Python per
+    # evaluation); False = scipy.optimize's loop driven from Python with the same device reductions
+    native_optimizer = True
+
+    def _optimize_separable_native(self, A, k, x0, bounds):
+        """TM:3108-3114 for one component without leaving the library; None when the native loop does not apply
+        (no cached derivative basis, or ranks that share samples without an RCCL / test-double communicator)."""
+        cache = getattr(self, '_sep_cache', None)
+        if not self.native_optimizer or cache is None or cache[0] != int(k):
+            return None
+        handle = None
+        if self._dist() is not None:
+            handle = comm.get(self._lib, force=self._dev.type != 'cuda')
+            if handle is None:
+                return None
+        dpsi = cache[1]
+        m = int(self._cm.n_mon[k])
+        A = np.ascontiguousarray(A, dtype=float)
+        b = np.ascontiguousarray(self.delta * np.sum(A, axis=-1))
+        x = np.array(x0, dtype=float, copy=True)
+        lb = np.array([-np.inf if lo is None else lo for lo, _ in bounds], dtype=float)
+        ub = np.array([np.inf if hi is None else hi for _, hi in bounds], dtype=float)
+        work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
+        sums_dev = self._empty(1 + m) if handle is not None else None
+        res = np.zeros(5)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)                   # noqa: E731
+        _capi.check(self._lib.ttm_optimize_separable(
+            self._ptr(dpsi), dpsi.shape[1], self._N, m, p(A), p(b), float(self._Nglobal), float(self.delta), p(lb), p(ub), p(x),
+            self._ptr(work), ctypes.c_void_p(self._obj_cnt.data_ptr()), self._ptr(sums_dev),
+            ctypes.c_void_p(self._obj_out.data_ptr()), handle, self._stream(), 0, p(res)))
+
+        class _Result:
+            pass
+        out = _Result()
+        out.x, out.fun, out.nit, out.nfev, out.status = x, float(res[0]), int(res[2]), int(res[3]), int(res[4])
+        return out
+
     def optimize(self, K=None):
-        """TM:2714-2901: per-component SciPy minimisation (BFGS / L-BFGS-B as
-        TM:3252-3257 / TM:3108-3114) driven by the device reductions."""
+        """TM:2714-2901: per-component minimisation (BFGS / L-BFGS-B as TM:3252-3257 / TM:3108-3114) on the device
+        reductions: separable components by the library's own L-BFGS-B loop, integrated ones by SciPy's BFGS."""
         from scipy.optimize import minimize
         if K is None:
             K = np.arange(self.D)
@@ -1221,9 +1258,11 @@ class transport_map():
                 self._sep_cache_begin(k)
                 try:
                     # (scipy.optimize.minimize(method='L-BFGS-B') as TM:3108-3114, minus its per-evaluation wrappers)
-                    fast = self._sep_objective_fast(A, k)
-                    opt = lbfgsb.minimize_lbfgsb(fast if fast is not None else self.separable_objective,
-                                                 np.asarray(self.coeffs_mon[k], dtype=float), bounds, (A, k))
+                    opt = self._optimize_separable_native(A, k, np.asarray(self.coeffs_mon[k], dtype=float), bounds)
+                    if opt is None:
+                        fast = self._sep_objective_fast(A, k)
+                        opt = lbfgsb.minimize_lbfgsb(fast if fast is not None else self.separable_objective,
+                                                     np.asarray(self.coeffs_mon[k], dtype=float), bounds, (A, k))
                 finally:
                     self._sep_cache_end()
                 self.coeffs_mon[k] = copy.deepcopy(opt.x)
