@@ -431,6 +431,20 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N,
              double* work, double* out, void* stream);
 
+/* ---- column utilities of the device-resident ensemble filter -----------------------------------------------
+ * example_06.py:252-328 (the caller of the hot path in Examples C) keeps the ensemble in host NumPy; entf.Filter keeps
+ * it column-major on the device and needs three small kernels around the map calls:
+ * ttm_lorenz63_rk4: nt RK4 steps of length dt of the Lorenz-63 system (example_06.py:28-76) on the 3 x N ensemble E;
+ * ttm_perturb: out[n] = in[n] + sd * noise[n]; noise NULL: standard normal deviates of a counter-based generator
+ *   (Philox-4x32-10 + Box-Muller, a function of (seed, stream_id, row0 + n) only);
+ * ttm_map_columns: out[j][n] = in[src[j]][n] * scale[j] + shift[j] for j < ncols <= 16 (src[j] < 0: the constant
+ *   shift[j]; scale / shift NULL: 1 / 0; src, scale, shift: host) - column gather, (de)standardisation, permutation. */
+int ttm_lorenz63_rk4(double* E, int64_t ld, int64_t N, double dt, int32_t nt, void* stream);
+int ttm_perturb(const double* in, const double* noise, double sd, uint64_t seed, uint32_t stream_id, int64_t row0, int64_t N,
+                double* out, void* stream);
+int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const double* scale, const double* shift,
+                    int32_t ncols, int64_t N, double* out, int64_t ldo, void* stream);
+
 /* ---- optimisers -----------------------------------------------------------------------------------------
  * TM:3108-3114 (scipy.optimize.minimize, method 'L-BFGS-B': maxcor 10, ftol 2.22e-9, gtol 1e-5, maxls 20) as a host
  * C++ loop (csrc/ttm_lbfgsb.h: L-BFGS-B 3.0 restated, dense for the few dozen variables of a map component).

@@ -17,6 +17,7 @@
 
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_eval.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_uform.h"
+#include "../../triangular_transport_toolbox_amd/csrc/ttm_rng.h"
 
 using namespace ttm;
 
@@ -729,6 +730,35 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
 }
 
 }  // extern "C"
+
+// column utilities of the device-resident ensemble filter (same per-row bodies)
+extern "C" {
+int ttm_lorenz63_rk4(double* E, int64_t ld, int64_t N, double dt, int32_t nt, void*) {
+    if (!E || N < 1 || ld < N || nt < 0) return TTM_E_ARG;
+    for (int64_t n = 0; n < N; ++n) {
+        double x = E[n], y = E[ld + n], z = E[2 * ld + n];
+        for (int i = 0; i < nt; ++i) ttm::lorenz63_rk4_step(x, y, z, dt);
+        E[n] = x; E[ld + n] = y; E[2 * ld + n] = z;
+    }
+    return TTM_OK;
+}
+int ttm_perturb(const double* in, const double* noise, double sd, uint64_t seed, uint32_t stream_id, int64_t row0, int64_t N,
+                double* out, void*) {
+    if (!in || !out || N < 1) return TTM_E_ARG;
+    for (int64_t n = 0; n < N; ++n) out[n] = in[n] + sd * (noise ? noise[n] : ttm::normal_deviate(seed, stream_id, (uint64_t)(row0 + n)));
+    return TTM_OK;
+}
+int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const double* scale, const double* shift, int32_t ncols,
+                    int64_t N, double* out, int64_t ldo, void*) {
+    if (!out || !src || N < 1 || ncols < 1 || ncols > 16 || ldo < N) return TTM_E_ARG;
+    for (int j = 0; j < ncols; ++j)
+        for (int64_t n = 0; n < N; ++n) {
+            const double v = src[j] >= 0 ? in[(int64_t)src[j] * ldi + n] : 0.0;
+            out[(int64_t)j * ldo + n] = v * (scale ? scale[j] : 1.0) + (shift ? shift[j] : 0.0);
+        }
+    return TTM_OK;
+}
+}
 
 // the optimiser loops of the product, compiled for the host (no streams)
 #define TTM_HOST_ONLY

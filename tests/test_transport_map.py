@@ -271,6 +271,38 @@ def test_entf_cycles_match_reference(backend):
         assert relerr(ens, npz['forecast_%d' % t]) < 1e-6
 
 
+def test_device_resident_filter_matches_reference_and_host_loop(backend):
+    """entf.Filter - forecast, observation noise, map input, reset, optimisation, pushforward, conditional inverse all on
+    the device, no host copy of the ensemble - replays the reference's three cycles (its own noise draws added on the
+    device) within 1e-6, and agrees with the host-loop harness `assimilate` to rounding."""
+    from triangular_transport_toolbox_amd import entf
+    npz, desc = load_case('entf')
+    ens = npz['ens0']
+    flt = entf.Filter(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
+    flt.set_ensemble(ens)
+    tm_host = entf.make_filter_map(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
+    host = ens
+    for t in range(3):
+        noises = np.stack([npz['noise_%d_%d' % (t, i)] for i in range(3)])
+        flt.assimilate(npz['obs'][t], noises=noises)
+        Xa = flt.ensemble()
+        assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
+        host = entf.assimilate(tm_host, host, npz['obs'][t], list(noises))
+        assert relerr(Xa, host) < 1e-9
+        flt.forecast(0.05, 2)
+        host = entf.rk4(host, 0.05, 2)
+        assert relerr(flt.ensemble(), npz['forecast_%d' % t]) < 1e-6
+    # own noise generator: reproducible, N(0, sd^2)
+    a = entf.Filter(4000, seed=5)
+    b = entf.Filter(4000, seed=5)
+    for f in (a, b):
+        f.set_ensemble(np.zeros((4000, 3)))
+        f.tm.map_columns([-1] * 4, 4, f.N, out=f._inp)
+        entf._check(f.tm._lib.ttm_perturb(f.tm._ptr(f.ens), None, 2.0, f.seed, 1, 0, f.N, f.tm._ptr(f._inp), f.tm._stream()))
+    ya, yb = a._inp[0, :4000].cpu().numpy(), b._inp[0, :4000].cpu().numpy()
+    assert np.array_equal(ya, yb) and abs(ya.mean()) < 0.15 and abs(ya.std() - 2.0) < 0.1
+
+
 def test_ents_backward_smoother_matches_reference(backend):
     """Ensemble Transport Smoother (example_07.py:368-465): the 6-column block map (skip_dimensions = 3, probabilist's
     Hermite polynomials with 'HF' terms, L2), three backward steps of reset -> optimize -> map -> inverse_map with

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "ttm_eval.h"
+#include "ttm_rng.h"
 #include "ttm_uform.h"
 
 using namespace ttm;
@@ -1928,6 +1929,38 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, int k, const double* __
 }
 
 // ---------------------------------------------------------------------------
+// Column utilities of the device-resident ensemble filter (entf.Filter: example_06.py:252-328 without a host copy of
+// the ensemble): everything is column-major, one thread per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lorenz63(double* __restrict__ E, int64_t ld, int64_t N, double dt, int nt) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double x = E[n], y = E[ld + n], z = E[2 * ld + n];
+    for (int i = 0; i < nt; ++i) lorenz63_rk4_step(x, y, z, dt);
+    E[n] = x; E[ld + n] = y; E[2 * ld + n] = z;
+}
+
+// out = in + sd * noise, noise = the given column or (noise == nullptr) standard normal deviates (seed, stream, row)
+__global__ __launch_bounds__(256) void k_perturb(const double* __restrict__ in, const double* __restrict__ noise, double sd,
+                                                 uint64_t seed, uint32_t stream_id, int64_t row0, int64_t N, double* __restrict__ out) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    out[n] = in[n] + sd * (noise ? noise[n] : normal_deviate(seed, stream_id, (uint64_t)(row0 + n)));
+}
+
+// out[j][n] = in[src[j]][n] * scale[j] + shift[j]  (column gather + affine map; scale / shift nullable)
+struct ColMap { int src[16]; double scale[16]; double shift[16]; };
+__global__ __launch_bounds__(256) void k_map_columns(const double* __restrict__ in, int64_t ldi, ColMap cmap, int ncols, int64_t N,
+                                                     double* __restrict__ out, int64_t ldo) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    for (int j = 0; j < ncols; ++j) {
+        const double v = cmap.src[j] >= 0 ? in[(int64_t)cmap.src[j] * ldi + n] : 0.0;
+        out[(int64_t)j * ldo + n] = v * cmap.scale[j] + cmap.shift[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side: launch planning
 // ---------------------------------------------------------------------------
 
@@ -2632,6 +2665,34 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     hipLaunchKernelGGL(k_gram, dim3(nb), dim3(bd), lds_bytes(m, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
     hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
     return check_launch("k_gram");
+}
+
+int ttm_lorenz63_rk4(double* E, int64_t ld, int64_t N, double dt, int32_t nt, void* stream) {
+    if (!E || N < 1 || ld < N || nt < 0) return set_err(TTM_E_ARG, "ttm_lorenz63_rk4: bad arguments%s");
+    hipLaunchKernelGGL(k_lorenz63, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E, ld, N, dt, (int)nt);
+    return check_launch("k_lorenz63");
+}
+
+int ttm_perturb(const double* in, const double* noise, double sd, uint64_t seed, uint32_t stream_id, int64_t row0, int64_t N,
+                double* out, void* stream) {
+    if (!in || !out || N < 1) return set_err(TTM_E_ARG, "ttm_perturb: bad arguments%s");
+    hipLaunchKernelGGL(k_perturb, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, noise, sd, seed, stream_id,
+                       row0, N, out);
+    return check_launch("k_perturb");
+}
+
+int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const double* scale, const double* shift, int32_t ncols,
+                    int64_t N, double* out, int64_t ldo, void* stream) {
+    if (!out || !src || N < 1 || ncols < 1 || ncols > 16 || ldo < N || (in && ldi < N)) return set_err(TTM_E_ARG, "ttm_map_columns: bad arguments%s");
+    ColMap cm;
+    for (int j = 0; j < 16; ++j) {
+        cm.src[j] = j < ncols ? (int)src[j] : -1;
+        cm.scale[j] = (j < ncols && scale) ? scale[j] : 1.0;
+        cm.shift[j] = (j < ncols && shift) ? shift[j] : 0.0;
+        if (j < ncols && src[j] >= 0 && !in) return set_err(TTM_E_ARG, "ttm_map_columns: source column without an input matrix%s");
+    }
+    hipLaunchKernelGGL(k_map_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, cm, (int)ncols, N, out, ldo);
+    return check_launch("k_map_columns");
 }
 
 }  // extern "C"

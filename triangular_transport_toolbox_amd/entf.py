@@ -4,11 +4,14 @@ example_06.py:252-328 and the backward smoother of example_07.py:424-465).
 
 One assimilation cycle = three one-observation-at-a-time composite-map updates
 (`reset -> optimize -> map -> inverse_map` with the observed value as X_star) followed by an RK4
-Lorenz-63 forecast.  The transport-map work runs on the GPU through the drop-in class; the forecast and the
-observation-noise draws are O(N) host NumPy as in the reference (a device-resident forecast is listed as next
-in DESIGN.md).
+Lorenz-63 forecast.  `assimilate` / `smooth` take and return host NumPy ensembles like the reference's loops (the
+transport-map work runs on the GPU through the drop-in class).  `Filter` is the same filter with the ensemble resident
+on the device: forecast, observation noise, assembly of the map input, reset, optimisation, pushforward and conditional
+inverse all run there; per update only a few dozen scalars (column moments, order statistics, coefficients) visit the
+host.
 """
 import copy
+import ctypes
 
 import numpy as np
 
@@ -88,3 +91,99 @@ def smooth(tm, forecasts, analyses):
         Z_pushforward = tm.map(map_input)
         Xs[t] = tm.inverse_map(X_star=copy.copy(Xs[t + 1]), Z=Z_pushforward)
     return Xs
+
+
+class Filter:
+    """Device-resident Ensemble Transport Filter for Lorenz-63 (example_06.py:252-328).
+
+    The ensemble is a column-major 3 x ld device matrix for its whole life.  One cycle = `forecast` (RK4,
+    ttm_lorenz63_rk4) + `assimilate` (three one-observation-at-a-time updates).  An update: y_t = x_idx + noise
+    (ttm_perturb) -> map input [y_t | x_perm] (ttm_map_columns) -> reset_device -> optimize (native L-BFGS-B) ->
+    pushforward of the resident samples (ttm_forward) -> conditional inverse with the observed value in the first
+    column (ttm_inverse_table) -> back to physical units and ensemble order (ttm_map_columns)."""
+
+    def __init__(self, N, maxorder=3, lmbda=0.05, seed=0, obs_sd=2.0, **kwargs):
+        self.N = int(N)
+        self.tm = make_filter_map(self.N, maxorder, lmbda, **kwargs)
+        self.seed = int(seed)
+        self.obs_sd = float(obs_sd)
+        self.ens = self.tm._cols(3, self.N, zero=True)           # the ensemble (device)
+        self._inp = self.tm._cols(4, self.N, zero=True)          # map input [y | x_perm]
+        self._draws = 0                                          # stream counter of the noise generator
+
+    # -- host <-> device, only at the boundaries of a run
+    def set_ensemble(self, ensemble):
+        import torch
+        E = np.ascontiguousarray(np.asarray(ensemble, dtype=float).T)
+        self.ens[:, :self.N].copy_(torch.from_numpy(E))
+
+    def ensemble(self):
+        return self.ens[:, :self.N].cpu().numpy().T.copy()
+
+    def forecast(self, dt=0.05, nt=2):
+        tm = self.tm
+        _check(tm._lib.ttm_lorenz63_rk4(tm._ptr(self.ens), self.ens.shape[1], self.N, float(dt), int(nt), tm._stream()))
+
+    def assimilate(self, observation, noises=None):
+        """The three updates of one cycle.  noises: optional 3 x N device tensor (or host array) of observation-noise
+        draws to ADD to the observed component (the parity tests pass the reference's own draws); default: fresh
+        N(0, obs_sd^2) deviates of the counter-based generator."""
+        import torch
+        tm, N, ens, inp = self.tm, self.N, self.ens, self._inp
+        ld = ens.shape[1]
+        if noises is not None and not isinstance(noises, torch.Tensor):
+            noises = tm._to_dev(np.ascontiguousarray(np.asarray(noises, dtype=float)))
+        for idx, perm in enumerate(PERMUTATIONS):
+            # y_t = x_idx + noise into column 0 of the map input; columns 1..3 = the ensemble in `perm` order
+            tm.map_columns([-1] + list(perm), 4, N, source=ens, out=inp)
+            col = ctypes.c_void_p(ens.data_ptr() + 8 * idx * ld)
+            if noises is not None:
+                _check(tm._lib.ttm_perturb(col, tm._ptr(noises, idx * noises.shape[1]), 1.0, 0, 0, 0, N, tm._ptr(inp), tm._stream()))
+            else:
+                self._draws += 1
+                _check(tm._lib.ttm_perturb(col, None, self.obs_sd, self.seed, self._draws, 0, N, tm._ptr(inp), tm._stream()))
+            tm.reset_device(inp, N)
+            tm.optimize()
+            Z = tm.forward_device(tm._Xs, N)
+            # conditioning column: the observed value, standardised like the first column of the training samples
+            ystar = (float(observation[idx]) - tm.X_mean[0]) / tm.X_std[0] if tm.standardize_samples else float(observation[idx])
+            Xc = tm.map_columns([-1, -1, -1, -1], 4, N, shift=[ystar, 0.0, 0.0, 0.0])
+            tm.inverse_device(Z, N, X=Xc)
+            # back to physical units; ensemble column j is the map's column 1 + perm[j]  (Xa = ret[:, perm])
+            src = [1 + p for p in perm]
+            scale = [tm.X_std[c] for c in src] if tm.standardize_samples else None
+            shift = [tm.X_mean[c] for c in src] if tm.standardize_samples else None
+            tm.map_columns(src, 3, N, source=Xc, scale=scale, shift=shift, out=ens)
+
+    def benchmark(self, ensemble, truth, cycles, warmup=3):
+        """`cycles` full cycles (truth forecast and observation on the host: 3 numbers; everything of size N on the
+        device), timed end to end."""
+        import time
+        import torch
+        rng = np.random.default_rng(self.seed)
+        self.set_ensemble(ensemble)
+        truth = np.array(truth, dtype=float)
+
+        def cycle(truth):
+            truth = rk4(truth[None, :], 0.05, 2)[0]
+            obs = truth + self.obs_sd * rng.standard_normal(3)
+            self.forecast(0.05, 2)
+            self.assimilate(obs)
+            return truth
+        for _ in range(warmup):
+            truth = cycle(truth)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(cycles):
+            truth = cycle(truth)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        mean = self.ens[:, :self.N].mean(dim=1).cpu().numpy()
+        return dict(workload='C4: Lorenz-63 EnTF, Example-06 map (4 columns, D = 3, order 3, L2 0.05), ensemble resident on the device',
+                    N=self.N, cycles=cycles, ms_per_cycle=1e3 * el / cycles, updates_per_cycle=3,
+                    rmse_last=float(np.sqrt(np.mean((mean - truth) ** 2))))
+
+
+def _check(rc):
+    from . import _capi
+    _capi.check(rc)

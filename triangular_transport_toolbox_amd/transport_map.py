@@ -327,9 +327,12 @@ class transport_map():
 
     def _import(self, X, standardize):
         """Row-major host array -> standardised column-major device matrix (d x N)."""
-        X = np.ascontiguousarray(X, dtype=np.float64)
-        N, d = X.shape
-        Xrow = self._to_dev(X)
+        if isinstance(X, _torch().Tensor):
+            Xrow = X.contiguous()
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            Xrow = self._to_dev(X)
+        N, d = Xrow.shape
         Xs = self._cols(d, N, zero=True)
         mean = self._mean_d if standardize else None
         sd = self._std_d if standardize else None
@@ -337,13 +340,13 @@ class transport_map():
                                          self._stream()))
         return Xs
 
-    def _export(self, Xs, N, j0, dout, destandardize):
+    def _export(self, Xs, N, j0, dout, destandardize, to_host=True):
         out = self._empty(N, dout)
         mean = self._mean_d if destandardize else None
         sd = self._std_d if destandardize else None
         _capi.check(self._lib.ttm_export(self._ptr(Xs), Xs.shape[1], N, j0, dout, self._ptr(mean), self._ptr(sd),
                                          self._ptr(out), self._stream()))
-        return out.cpu().numpy()
+        return out.cpu().numpy() if to_host else out
 
     def _load_samples(self, X):
         torch = _torch()
@@ -377,8 +380,9 @@ class transport_map():
         if X is None:
             raise ValueError('standardize() needs the raw samples')
         N, d = X.shape
+        on_device = isinstance(X, torch.Tensor)          # (reset_device: the raw samples are already there, row-major)
         if self.standardization.lower() == 'standard':
-            Xrow = self._to_dev(X)
+            Xrow = X if on_device else self._to_dev(X)
             mean, sd = self._empty(d), self._empty(d)
             work = self._workspace(self._lib.ttm_colstats_work_size(N, d))
             _capi.check(self._lib.ttm_colstats(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(work),
@@ -397,7 +401,7 @@ class transport_map():
             # median / quantile spread per column (TM:775-778) from device order statistics; the
             # quantiles of X - median are the quantiles of X minus the median (monotone shift)
             Xraw = self._cols(d, N, zero=True)
-            Xrow = self._to_dev(X)
+            Xrow = X if on_device else self._to_dev(X)
             _capi.check(self._lib.ttm_import(self._ptr(Xrow), N, d, None, None, self._ptr(Xraw), Xraw.shape[1], self._stream()))
             med, spread = np.empty(d), np.empty(d)
             for j in range(d):
@@ -497,6 +501,45 @@ class transport_map():
             self.coeffs_mon[k] = np.asarray(self.coeffs_mon[k], dtype=float) * 0 + self.coeffs_init
             self.coeffs_nonmon[k] = np.asarray(self.coeffs_nonmon[k], dtype=float) * 0 + self.coeffs_init
         self._load_samples(X)
+
+    def reset_device(self, Xcols, N):
+        """reset() (TM:710-748) for samples that are already on the device: Xcols is a raw (un-standardised)
+        column-major matrix (d x ld tensor, column j = sample column j); nothing of size N crosses the host boundary -
+        only the 2 d column moments and the few order statistics the special-term placement interpolates.
+        Same kernels, hence the same numbers, as reset() of the same samples."""
+        torch = _torch()
+        d = self._cm.d_cols
+        if Xcols.shape[0] != d or Xcols.shape[1] < N:
+            raise Exception('Xcols has shape ' + str(tuple(Xcols.shape)) + ', the map was built for ' + str(d) + ' columns')
+        for k in range(self.D):
+            self.coeffs_mon[k] = np.asarray(self.coeffs_mon[k], dtype=float) * 0 + self.coeffs_init
+            self.coeffs_nonmon[k] = np.asarray(self.coeffs_nonmon[k], dtype=float) * 0 + self.coeffs_init
+        Xrow = self._export(Xcols, N, 0, d, False, to_host=False)          # row-major copy for the moment / layout kernels
+        self._N = N
+        self._Nglobal = N
+        dist = self._dist()
+        if dist is not None:
+            n = torch.tensor([N], dtype=torch.int64, device=self._dev)
+            dist.all_reduce(n)
+            self._Nglobal = int(n.item())
+        self._X_host = None
+        if self.standardize_samples:
+            self.standardize(Xrow)
+        self._Xs = self._import(Xrow, self.standardize_samples)
+        self._obj_cache = None
+        self.determine_special_term_locations()
+
+    def map_columns(self, src, ncols_out, N, source=None, scale=None, shift=None, out=None):
+        """out[j] = source[src[j]] * scale[j] + shift[j] on column-major device matrices (ttm_map_columns): column
+        gather / permutation, constants (src[j] < 0) and (de)standardisation in one pass."""
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        scale = None if scale is None else np.ascontiguousarray(scale, dtype=float)
+        shift = None if shift is None else np.ascontiguousarray(shift, dtype=float)
+        out = self._cols(ncols_out, N) if out is None else out
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)      # noqa: E731
+        _capi.check(self._lib.ttm_map_columns(self._ptr(source), 0 if source is None else source.shape[1], p(src), p(scale), p(shift),
+                                              len(src), N, self._ptr(out), out.shape[1], self._stream()))
+        return out
 
     # ------------------------------------------------------------------------
     # coefficients
