@@ -320,3 +320,54 @@ def test_ents_backward_smoother_matches_reference(backend):
     for k in range(tm.D):                     # (coefficients of the last update, t = 0)
         assert relerr(tm.coeffs_mon[k], npz['last_coeffs_mon_%d' % k]) < 1e-4
         assert relerr(tm.coeffs_nonmon[k], npz['last_coeffs_nonmon_%d' % k]) < 1e-4
+
+
+def test_packed_coefficients_held_across_reset_are_refolded(backend):
+    """forward_device / inverse_device callers may keep a packed coefficient vector; the folded coefficients, U-form
+    splines and inverse tables cached with it belong to one special-term placement.  After reset() the vector is folded
+    again on its next use instead of evaluating with stale splines."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case('c3_sep')
+    X = case_X('c3_sep', npz)
+    tm = transport_map(X=X[:1000], monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
+    mon, non = coeff_lists(npz, tm.D)
+    tm.coeffs_mon, tm.coeffs_nonmon = [c.copy() for c in mon], [c.copy() for c in non]
+    coef = tm._pack_coeffs()
+    Z0 = tm.forward_device(tm._Xs, tm._N, coef=coef)[:, :tm._N].cpu().numpy()
+    tm.reset(X[1000:2000] * 1.7 + 0.3)                   # other samples: other special-term centres / scales
+    tm.coeffs_mon, tm.coeffs_nonmon = [c.copy() for c in mon], [c.copy() for c in non]
+    epoch = coef._ttm_epoch
+    Z1 = tm.forward_device(tm._Xs, tm._N, coef=coef)[:, :tm._N].cpu().numpy()
+    assert coef._ttm_epoch != epoch
+    assert np.array_equal(Z1, tm.forward_device(tm._Xs, tm._N)[:, :tm._N].cpu().numpy())      # == a fresh pack
+    assert Z0.shape == Z1.shape and not np.allclose(Z0, Z1)
+    Xi = tm.inverse_device(tm.forward_device(tm._Xs, tm._N), tm._N, coef=coef)
+    assert np.array_equal(Xi[:, :tm._N].cpu().numpy(), tm.inverse_device(tm.forward_device(tm._Xs, tm._N), tm._N)[:, :tm._N].cpu().numpy())
+
+
+def test_nearly_collinear_nonmonotone_basis_takes_the_qr_path(backend):
+    """The reduced separable problem is formed from the Gram matrix (one device pass) when that is safe and by the
+    reference's Householder QR otherwise: two nonmonotone terms that differ by 1e-7 of a third make the equilibrated
+    Gram matrix singular to working precision; A and the nonmonotone coefficients still match the oracle's."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    rng = np.random.default_rng(2)
+    x0 = rng.standard_normal(3000)
+    X = np.column_stack((x0, x0 * (1 + 1e-7 * rng.standard_normal(3000)), 0.5 * x0 + rng.standard_normal(3000)))
+    monotone = [['LET 0', 'RET 0'], ['LET 1', 'RET 1'], ['LET 2', 'iRBF 2', 'RET 2']]
+    nonmonotone = [[[]], [[], [0]], [[], [0], [1], [0, 0, 'HF']]]
+    kw = dict(polynomial_type='hermite function', monotonicity='separable monotonicity', standardize_samples=True)
+    tm = transport_map(X=X, monotone=monotone, nonmonotone=nonmonotone, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=monotone, nonmonotone=nonmonotone, **kw)
+    k = 2
+    G = tm._gram(k)
+    n_nm = int(tm._cm.n_nm[k])
+    assert tm._normal_solve(G[:n_nm, :n_nm], G[:n_nm, n_nm:], 0.0) is None          # the normal equations are refused ...
+    A, solve = tm.separable_setup(k)                                                  # ... and the QR path runs
+    Ao, aux = om.separable_setup(k)
+    assert relerr(A, Ao) < 1e-8
+    c = np.array([0.7, 0.2, 0.9])
+    assert relerr(tm.separable_objective(c, A, k)[0], om.separable_objective(c, Ao, k)[0]) < 1e-9
+    # a well-conditioned component of the same map keeps the Gram path and agrees as before
+    A1, _ = tm.separable_setup(1)
+    assert relerr(A1, om.separable_setup(1)[0]) < 1e-9

@@ -202,6 +202,7 @@ class transport_map():
         self._pp = ctypes.byref(self._prog)
         self._u_checked = None
         self._u_rejected = False
+        self._epoch = getattr(self, '_epoch', 0) + 1      # packed coefficient vectors of an older program are stale
         self._ugrp_d = None                      # (static U-form tables belong to the specification just compiled)
         self._refresh_uform()
         self._work = None
@@ -301,6 +302,7 @@ class transport_map():
         _capi.set_uform(self._prog, cm, self._ucomp_d.data_ptr(), self._ugrp_d.data_ptr(), self._umono_d.data_ptr(),
                         self._ugeo_d.data_ptr())
         self._u_checked = None
+        self._epoch = getattr(self, '_epoch', 0) + 1      # new spline geometry: folds / tables kept with a vector are stale
 
     def _check_uform(self, fold):
         """The special-term splines are verified when they are built (fit error against the direct evaluation,
@@ -319,6 +321,7 @@ class transport_map():
             self._u_rejected = True
             cm.u_enabled = False
             self._prog.u_enabled = 0
+            self._epoch += 1
         return ok
 
     # ------------------------------------------------------------------------
@@ -468,6 +471,7 @@ class transport_map():
         termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
         self._cm.fill_special_terms(self.special_terms)
         self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
+        self._epoch += 1                         # (the folded special-term records depend on centres and scales)
         self._u_rejected = False
         self._refresh_uform()
 
@@ -556,13 +560,30 @@ class transport_map():
                                  % (k, self._cm.n_nm[k], self._cm.n_mon[k], len(cn), len(cm)))
             parts += [cn, cm]
         coef = self._to_dev(np.concatenate(parts))
-        # folded coefficients (device pre-pass, include/ttm.h "Folded coefficients"); kept with the vector
+        return self._fold(coef)
+
+    def _fold(self, coef):
+        """Folded coefficients of a packed coefficient vector (device pre-pass, include/ttm.h "Folded coefficients"),
+        kept with the vector together with the state of the map they were made for: special-term placement, U-form
+        geometry and its accept / reject decision (`_epoch`).  A vector that outlived that state - a caller of
+        forward_device / inverse_device holding it across reset() - is folded again on its next use (`_current`)."""
         fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
         _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
         if not self._check_uform(fold):
             fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
             _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
         coef._ttm_fold = fold
+        coef._ttm_tables = {}
+        coef._ttm_epoch = self._epoch
+        return coef
+
+    def _current(self, coef):
+        if coef is None:
+            return self._pack_coeffs()
+        if getattr(coef, '_ttm_epoch', None) != self._epoch:
+            if coef.numel() != int(self._cm.coef_off[-1]):
+                raise ValueError('packed coefficient vector belongs to a different specification of the map')
+            self._fold(coef)
         return coef
 
     # ------------------------------------------------------------------------
@@ -590,7 +611,7 @@ class transport_map():
     # device-resident entry points (column-major tensors in, column-major tensors out; no PCIe traffic)
     def forward_device(self, Xs, N, coef=None, Z=None, logdet=None, sigma=None, sumsq=None):
         """S(x) for a standardised column-major device matrix Xs (d x N) -> Z (D x N)."""
-        coef = self._pack_coeffs() if coef is None else coef
+        coef = self._current(coef)
         Z = self._cols(self.D, N) if Z is None else Z
         _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
                                           self._ptr(Z), Z.shape[1], self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq),
@@ -600,7 +621,7 @@ class transport_map():
     def inverse_device(self, Zs, N, coef=None, X=None, table=None):
         """S^{-1}(z) for a column-major device matrix Zs (D x N) -> standardised X (d x N);
         conditioning columns (if any) must already be in X."""
-        coef = self._pack_coeffs() if coef is None else coef
+        coef = self._current(coef)
         X = self._cols(self._cm.d_cols, N, zero=True) if X is None else X
         if table is None:
             table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
@@ -929,19 +950,63 @@ class transport_map():
         Gnn, Gnm, Gmm = G[:n_nm, :n_nm], G[:n_nm, n_nm:], G[n_nm:, n_nm:]
         N = self._Nglobal
         if self.regularization is None:
-            sol = np.linalg.solve(Gnn, Gnm)
+            sol = self._normal_solve(Gnn, Gnm, 0.0)
+            if sol is None:
+                return self._separable_setup_qr(k)                   # nearly collinear nonmonotone basis: the reference's QR
             A = (Gmm - Gnm.T @ sol) / N
             A = (A + A.T) / 2
             return A, (lambda c: -(sol @ c))
         if self.regularization.lower() == 'l2':
             lam = self.regularization_lambda
-            Gm = np.linalg.solve(Gnn + lam * np.identity(n_nm), Gnm)
+            Gm = self._normal_solve(Gnn, Gnm, lam)
             dd = Gmm - Gnm.T @ Gm - Gm.T @ Gnm + Gm.T @ Gnn @ Gm
             A = dd / 2 + lam * (Gm.T @ Gm + np.identity(Gm.shape[-1]))      # no 1/N: as TM:3040-3050
             A = (A + A.T) / 2
-            sol2 = np.linalg.solve(Gnn + 2 * lam * np.identity(n_nm), Gnm)
+            sol2 = self._normal_solve(Gnn, Gnm, 2 * lam)
             return A, (lambda c: -(sol2 @ c))
         raise ValueError("separable monotonicity supports regularization None or 'l2' (TM:2959, 3021)")
+
+    # condition number (of the diagonally equilibrated Gram matrix) above which the normal equations are not trusted:
+    # they square the condition number of Psi_nonmon, the reference's Householder QR (TM:2966-2975) does not
+    GRAM_COND_MAX = 1e11
+
+    @classmethod
+    def _normal_solve(cls, Gnn, Gnm, ridge):
+        """(Gnn + ridge I)^-1 Gnm by Cholesky on the diagonally equilibrated matrix with one step of iterative
+        refinement; None when the equilibrated matrix is too ill-conditioned for the normal equations (ridge == 0
+        only: a ridge bounds the condition number by itself)."""
+        import scipy.linalg
+        M = Gnn + ridge * np.identity(Gnn.shape[0])
+        d = np.sqrt(np.diag(M))
+        if not np.all(d > 0) or not np.all(np.isfinite(d)):
+            return None if ridge == 0.0 else np.linalg.solve(M, Gnm)
+        Ms = M / d[:, None] / d[None, :]
+        if ridge == 0.0:
+            w = np.linalg.eigvalsh(Ms)
+            if not (w[0] > 0) or w[-1] / w[0] > cls.GRAM_COND_MAX:
+                return None
+        try:
+            cf = scipy.linalg.cho_factor(Ms)
+        except np.linalg.LinAlgError:
+            return None if ridge == 0.0 else np.linalg.solve(M, Gnm)
+        rhs = Gnm / d[:, None]
+        y = scipy.linalg.cho_solve(cf, rhs)
+        y += scipy.linalg.cho_solve(cf, rhs - Ms @ y)                 # one refinement step
+        return y / d[:, None]
+
+    def _separable_setup_qr(self, k):
+        """The reduced problem exactly as the reference forms it (TM:2966-2975, 3152-3157): Householder QR of Psi_nonmon
+        on the host.  Fallback for nonmonotone bases whose Gram matrix is too ill-conditioned (the basis matrices come
+        off the device once: N x m doubles)."""
+        if self._dist() is not None:
+            raise np.linalg.LinAlgError('component %d: the nonmonotone basis is numerically rank deficient (equilibrated Gram '
+                                        'matrix beyond cond %.0e) and samples are sharded over ranks' % (k, self.GRAM_COND_MAX))
+        Pn, Pm = self.basis(k, 'nonmon'), self.basis(k, 'mon')
+        Q, R = np.linalg.qr(Pn, mode='reduced')
+        A = (Pm.T @ Pm - (Q.T @ Pm).T @ (Q.T @ Pm)) / self._Nglobal
+        A = (A + A.T) / 2
+        QtPm = Q.T @ Pm
+        return A, (lambda c: -np.linalg.solve(R, QtPm @ c))
 
     def _sep_cache_begin(self, k):
         """Cache dPsi_mon of component k on the device for the duration of its optimisation (what the reference's
