@@ -1199,8 +1199,9 @@ __device__ __attribute__((noinline)) void rt_warm(const int* state_, const char*
     }
 }
 
-template <int NG, int CLS, int NS, bool ETAB>
-__global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ ucomp_, const double* __restrict__ U_, int64_t h_off,
+template <int NG, int CLS, int NS, bool ETAB, bool BAND>
+__global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ ucomp_, const int* __restrict__ ugrp_,
+                                                     const double* __restrict__ U_, int64_t h_off,
                                                      int D, int k0, int k1,
                                                      const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
                                                      const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
@@ -1237,6 +1238,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
         }
     }
     const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
+    const int kc_first = ((cint_p)ucomp_)[k0 * TTM_UC_LEN + TTM_UC_KC];    // BAND: column of component k is kc_first + k - k0
 
     for (int kb = k0; kb < k1; kb += B) {
         const int ke = kb + B < k1 ? kb + B : k1;
@@ -1251,26 +1253,70 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
             double scale, bias;
             table_bucket_params(lo, hi, nb, scale, bias);
             slot[0] = lo; slot[1] = hi; slot[2] = scale; slot[3] = bias;
+            int code = 0;
+            if (BAND) {                                                  // n_grp | lag of group 0 << 4 | lag of group 1 << 8
+                const int* uc = ucomp_ + c * TTM_UC_LEN;
+                const int n_grp = uc[TTM_UC_N_GRP];
+                code = n_grp;
+                for (int g = 0; g < n_grp && g < 2; ++g)
+                    code |= (uc[TTM_UC_KC] - ugrp_[(uc[TTM_UC_GRP_OFF] + g) * TTM_UG_LEN + TTM_UG_VAR]) << (4 + 4 * g);
+            }
             ((int*)slot)[8] = 0;                                         // entries per bucket, at most
-            ((int*)slot)[9] = 0;
+            ((int*)slot)[9] = code;
             slot[5] = 0.0;
         }
         __syncthreads();
-        for (int c = kb; c < ke; ++c) {
-            double* slot = tabs + (size_t)(c - kb) * tab_slot;
-            double* xs = slot + TTM_RT_HDR;
-            const double* src = tab_x + (int64_t)(c - k0) * T;
-            for (int i = tid; i < Teven; i += CT) xs[i] = i < T ? src[i] : INFINITY;
-            unsigned short* bs = (unsigned short*)(xs + Teven);
-            const int* bsrc = bkt + (int64_t)(c - k0) * (nb + 1);
-            int per = 0;
-            for (int i = tid; i <= nb; i += CT) {
-                const int v = bsrc[i];
-                bs[i] = (unsigned short)v;
-                if (i < nb) per = max(per, bsrc[i + 1] - v);
+        // The tables of the block, as ONE flat element loop per kind with eight loads in flight per thread: a loop over
+        // the components with one load -> wait -> LDS store per pass costs a memory latency per component and kind -
+        // 80 latencies per workgroup and launch at C5, a quarter of the kernel, while every wave waits at the barrier.
+        {
+            const int total_x = nk * Teven;
+            for (int e0 = tid; e0 < total_x; e0 += 8 * CT) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * CT, total_x - 1);
+                    const int c = e / Teven, i = e - c * Teven;
+                    const double t = tab_x[(int64_t)(kb - k0 + c) * T + min(i, T - 1)];
+                    v[u] = i < T ? t : INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * CT;
+                    const int c = e / Teven, i = e - c * Teven;
+                    if (e < total_x) tabs[(size_t)c * tab_slot + TTM_RT_HDR + i] = v[u];
+                }
             }
-            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
-            if ((tid & 63) == 0) atomicMax((int*)slot + 8, per);         // (one LDS atomic per wave, not per thread)
+            const int nb1 = nb + 1, total_b = nk * nb1;
+            for (int e0 = tid; e0 < total_b; e0 += 8 * CT) {
+                int v[8], w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = min(e0 + u * CT, total_b - 1);         // (clamped, unconditional: all sixteen loads in flight)
+                    const int c = e / nb1, i = e - c * nb1;
+                    const int* bsrc = bkt + (int64_t)(kb - k0 + c) * nb1;
+                    v[u] = bsrc[i];
+                    w[u] = bsrc[min(i + 1, nb)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * CT;
+                    const int c = e / nb1, i = e - c * nb1;
+                    if (e < total_b) {
+                        double* slot = tabs + (size_t)c * tab_slot;
+                        ((unsigned short*)(slot + TTM_RT_HDR + Teven))[i] = (unsigned short)v[u];
+                        // entries per bucket, at most: one LDS atomic per wave and component run
+                        int per = w[u] - v[u];
+                        const int c_first = __builtin_amdgcn_readfirstlane(c);
+                        if (__builtin_amdgcn_ballot_w64(c != c_first) == 0) {
+                            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+                            if ((tid & 63) == 0) atomicMax((int*)slot + 8, per);
+                        } else {
+                            atomicMax((int*)slot + 8, per);              // (a wave that straddles two components: rare)
+                        }
+                    }
+                }
+            }
         }
         __syncthreads();
 
@@ -1279,6 +1325,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
         // (the load of z_s and the store of x_{s-2}); a store issued at the END of its own step would sit between the
         // load and the next wait and stall every step for a full write latency (vmcnt counts in order).
         D2 zn[NP], rprev[NP];
+        D2 bx1[NP], be1[NP], bx2[NP], be2[NP];                           // BAND: x and exp(-x^2/4) of columns kc-1 and kc-2
         const char* xprev_col = nullptr;                                 // column of the deferred store (uniform)
         unsigned int xprev_off = 0;                                      // byte offset of this thread's first row in it
         bool xprev_full = true;
@@ -1294,8 +1341,26 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
         for (int tile = 0; tile < ntile; ++tile) {
             const unsigned int tbase = row0 + (unsigned int)tile * (unsigned int)ROWS;     // this thread's first row of the tile
             const bool full = c0 + (int64_t)(tile + 1) * ROWS <= c1;     // (uniform) every row of the tile exists
-            if (kb > 0)                                                  // columns the earlier blocks (or the caller) left in X
+            if (BAND) {                                                  // the two columns in front of the block, if they exist
+                const int kcb = kc_first + (kb - k0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    unsigned int n = tbase + (unsigned int)(q * 2 * CT);
+                    n = n < last_pair ? n : last_pair;
+                    D2 zero = {0.0, 0.0};
+                    bx1[q] = be1[q] = bx2[q] = be2[q] = zero;
+                    if (kcb >= 1) {
+                        bx1[q] = *(const D2*)((const char*)X + (int64_t)(kcb - 1) * ldxb + (size_t)(n * 8u));
+                        be1[q] = rt_expq(bx1[q]);
+                    }
+                    if (kcb >= 2) {
+                        bx2[q] = *(const D2*)((const char*)X + (int64_t)(kcb - 2) * ldxb + (size_t)(n * 8u));
+                        be2[q] = rt_expq(bx2[q]);
+                    }
+                }
+            } else if (kb > 0) {                                         // columns the earlier blocks (or the caller) left in X
                 rt_warm<NP>(ucomp_ + TTM_UC_STATE(D, kb), (const char*)X, ldxb, tbase, last_pair, CT, cache + 2 * tid);
+            }
             cdbl_p rec = (cdbl_p)(U_ + h_off) + (int64_t)kb * HS;
             const double* slot = tabs;
             const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;   // column of THIS step's z
@@ -1370,13 +1435,24 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                         }
                     }
                 };
+                if (BAND) {
+                    const int code = __builtin_amdgcn_readfirstlane(((const int*)slot)[9]);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (g < n_grp) {
-                        D2 xv[NP], ev[NP];
+                    for (int g = 0; g < (NG < 2 ? NG : 2); ++g) {
+                        if (g < (code & 15)) {
+                            if (((code >> (4 + 4 * g)) & 15) == 1) group(g, bx1, be1);
+                            else group(g, bx2, be2);
+                        }
+                    }
+                } else {
 #pragma unroll
-                        for (int q = 0; q < NP; ++q) { xv[q] = cc.get(gslot[g], q); ev[q] = cc.get(gslot[g] + 1, q); }
-                        group(g, xv, ev);
+                    for (int g = 0; g < NG; ++g) {
+                        if (g < n_grp) {
+                            D2 xv[NP], ev[NP];
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) { xv[q] = cc.get(gslot[g], q); ev[q] = cc.get(gslot[g] + 1, q); }
+                            group(g, xv, ev);
+                        }
                     }
                 }
                 // ---- target, bucket, position ---------------------------------------------------------------------------
@@ -1453,7 +1529,14 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 // ---- keep x_k (and exp(-x_k^2/4)) for the components behind; the store is deferred to the next step -----
 #pragma unroll
                 for (int q = 0; q < NP; ++q) { D2 o = {r[2 * q], r[2 * q + 1]}; rprev[q] = o; }
-                if (put2 >= 0) {
+                if (BAND) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        D2 eo = {ev[2 * q], ev[2 * q + 1]};
+                        bx2[q] = bx1[q]; be2[q] = be1[q];
+                        bx1[q] = rprev[q]; be1[q] = ETAB ? eo : rt_expq(rprev[q]);
+                    }
+                } else if (put2 >= 0) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
                         cc.set(put2, q, rprev[q]);
@@ -2005,7 +2088,8 @@ static const DeviceInfo& device_info() {
     X(rt_threads, -1)    /* threads per workgroup of k_inverse_rt (multiple of 64, <= 1024)                          */ \
     X(rt_ns, -1)         /* rows per thread of k_inverse_rt (2, 4)                                                   */ \
     X(rt_block, -1)      /* components per block of k_inverse_rt                                                     */ \
-    X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */
+    X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */ \
+    X(rt_band, -1)       /* 0: banded maps through the LDS column cache instead of the register shift                */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2464,7 +2548,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         const Tuning& tn = tuning();
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
-        const int NS = tn.rt_ns == 4 ? 4 : 2;
+        int NS = tn.rt_ns == 4 ? 4 : 2;
         const int Teven = (T + 4 + 1) & ~1;
         const int tab_slot = TTM_RT_HDR + Teven + (((nb + 1 + 3) / 4 + 1) & ~1);   // doubles: header + xs row + uint16 bucket index (even)
         const double ymax = fabs(h_y_affine[0]) > fabs(h_y_affine[2]) ? fabs(h_y_affine[0]) : fabs(h_y_affine[2]);
@@ -2472,13 +2556,24 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         if (tn.rt_etab == 0) etab = false;
         const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) &&
                              ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1);
-        const int wgs = 1;                                               // the tables + the column cache fill the LDS of a CU
+        // banded map: every nonmonotone group of component k reads column kc-1 or kc-2, columns consecutive -> the last
+        // two columns are carried in registers (no LDS cache, four rows per thread)
+        bool band = p->u_h_ng == 2 && tn.rt_band != 0;
+        for (int k = k0; k < k1 && band; ++k) {
+            const int* uc = p->h_ucomp + k * TTM_UC_LEN;
+            if (uc[TTM_UC_KC] != p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC] + (k - k0) || uc[TTM_UC_N_GRP] > 2) band = false;
+            for (int g = 0; g < uc[TTM_UC_N_GRP] && band; ++g) {
+                const int lag = uc[TTM_UC_KC] - p->h_ugrp[(uc[TTM_UC_GRP_OFF] + g) * TTM_UG_LEN + TTM_UG_VAR];
+                if (lag != 1 && lag != 2) band = false;
+            }
+        }
+        const int wgs = 1;                                               // the tables (+ the column cache) fill the LDS of a CU
         int CT = tn.rt_threads >= 64 && tn.rt_threads <= 1024 ? (tn.rt_threads & ~63) : 1024;
         const size_t budget = di.lds_per_cu / wgs;
         int Bc = 0;
         size_t lds = 0;
         for (; CT >= 256; CT -= 256) {                                   // fewer rows in flight if the tables would not fit
-            const size_t fixed = ((size_t)(etab ? Teven : 0) + (size_t)2 * ways * NS * CT) * 8;
+            const size_t fixed = ((size_t)(etab ? Teven : 0) + (band ? 0 : (size_t)2 * ways * NS * CT)) * 8;
             if (fixed + (size_t)tab_slot * 8 > budget) continue;
             Bc = (int)((budget - fixed) / ((size_t)tab_slot * 8));
             if (Bc > ncomp) Bc = ncomp;
@@ -2490,26 +2585,28 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
             Bc = 0;
         }
         if (aligned && Bc > 0) {
-            typedef void (*rkern_t)(const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t,
+            typedef void (*rkern_t)(const int*, const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t,
                                     int64_t, const double*, int, double, double, double, const double*, const double*, const int*, int,
                                     int, int, int, int, int64_t);
             rkern_t rk;
-#define TTM_RK3(NGV, CLSV, NSV) (etab ? k_inverse_rt<NGV, CLSV, NSV, true> : k_inverse_rt<NGV, CLSV, NSV, false>)
+#define TTM_RK4(NGV, CLSV, NSV, E) (band ? k_inverse_rt<NGV, CLSV, NSV, E, true> : k_inverse_rt<NGV, CLSV, NSV, E, false>)
+#define TTM_RK3(NGV, CLSV, NSV) (etab ? TTM_RK4(NGV, CLSV, NSV, true) : TTM_RK4(NGV, CLSV, NSV, false))
 #define TTM_RK(NGV, NSV) (p->u_h_cls == 1 ? TTM_RK3(NGV, 1, NSV) : p->u_h_cls == 2 ? TTM_RK3(NGV, 2, NSV) : TTM_RK3(NGV, 3, NSV))
             if (NS == 2) { if (p->u_h_ng == 2) rk = TTM_RK(2, 2); else rk = TTM_RK(4, 2); }
             else { if (p->u_h_ng == 2) rk = TTM_RK(2, 4); else rk = TTM_RK(4, 4); }
 #undef TTM_RK
 #undef TTM_RK3
+#undef TTM_RK4
             // every workgroup gets the same (even) number of rows
             const int nwg = di.cus * wgs;
             int64_t rows = (N + nwg - 1) / nwg;
             rows = (rows + 1) & ~(int64_t)1;
             const int64_t grid = (N + rows - 1) / rows;
             allow_big_lds((const void*)rk, lds);
-            hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(CT), lds, (hipStream_t)stream, p->ucomp, fold + fold_base_size(p),
+            hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(CT), lds, (hipStream_t)stream, p->ucomp, p->ugrp, fold + fold_base_size(p),
                                (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine[0],
                                h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, Bc, ways, rows);
-            return check_launch("k_inverse_rt");
+            return check_launch(band ? "k_inverse_rt<band>" : "k_inverse_rt");
         }
     }
     const int bd = 256;
