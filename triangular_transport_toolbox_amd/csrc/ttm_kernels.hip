@@ -1269,57 +1269,35 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
             slot[5] = 0.0;
         }
         __syncthreads();
-        // The tables of the block, as ONE flat element loop per kind with eight loads in flight per thread: a loop over
-        // the components with one load -> wait -> LDS store per pass costs a memory latency per component and kind -
-        // 80 latencies per workgroup and launch at C5, a quarter of the kernel, while every wave waits at the barrier.
-        {
-            const int total_x = nk * Teven;
-            for (int e0 = tid; e0 < total_x; e0 += 8 * CT) {
-                double v[8];
+        // The tables of the block, sixteen components' loads in flight per thread: a loop over the components with one
+        // load -> wait -> LDS store per pass costs a memory latency per component and kind - 80 latencies per workgroup
+        // and launch at C5, a quarter of the kernel, while every wave waits at the barrier.
+        for (int cg = 0; cg < nk; cg += 16) {
+            for (int i = tid; i < Teven; i += CT) {
+                double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = min(e0 + u * CT, total_x - 1);
-                    const int c = e / Teven, i = e - c * Teven;
-                    const double t = tab_x[(int64_t)(kb - k0 + c) * T + min(i, T - 1)];
-                    v[u] = i < T ? t : INFINITY;
-                }
+                for (int u = 0; u < 16; ++u) v[u] = tab_x[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * T + min(i, T - 1)];   // (clamped, unconditional)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * CT;
-                    const int c = e / Teven, i = e - c * Teven;
-                    if (e < total_x) tabs[(size_t)c * tab_slot + TTM_RT_HDR + i] = v[u];
-                }
+                for (int u = 0; u < 16; ++u)
+                    if (cg + u < nk) tabs[(size_t)(cg + u) * tab_slot + TTM_RT_HDR + i] = i < T ? v[u] : INFINITY;
             }
-            const int nb1 = nb + 1, total_b = nk * nb1;
-            for (int e0 = tid; e0 < total_b; e0 += 8 * CT) {
-                int v[8], w[8];
+            for (int i = tid; i <= nb; i += CT) {
+                int v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = min(e0 + u * CT, total_b - 1);         // (clamped, unconditional: all sixteen loads in flight)
-                    const int c = e / nb1, i = e - c * nb1;
-                    const int* bsrc = bkt + (int64_t)(kb - k0 + c) * nb1;
-                    v[u] = bsrc[i];
-                    w[u] = bsrc[min(i + 1, nb)];
-                }
+                for (int u = 0; u < 16; ++u) v[u] = bkt[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * (nb + 1) + i];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = e0 + u * CT;
-                    const int c = e / nb1, i = e - c * nb1;
-                    if (e < total_b) {
-                        double* slot = tabs + (size_t)c * tab_slot;
-                        ((unsigned short*)(slot + TTM_RT_HDR + Teven))[i] = (unsigned short)v[u];
-                        // entries per bucket, at most: one LDS atomic per wave and component run
-                        int per = w[u] - v[u];
-                        const int c_first = __builtin_amdgcn_readfirstlane(c);
-                        if (__builtin_amdgcn_ballot_w64(c != c_first) == 0) {
-                            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
-                            if ((tid & 63) == 0) atomicMax((int*)slot + 8, per);
-                        } else {
-                            atomicMax((int*)slot + 8, per);              // (a wave that straddles two components: rare)
-                        }
-                    }
-                }
+                for (int u = 0; u < 16; ++u)
+                    if (cg + u < nk) ((unsigned short*)(tabs + (size_t)(cg + u) * tab_slot + TTM_RT_HDR + Teven))[i] = (unsigned short)v[u];
             }
+        }
+        __syncthreads();
+        // entries per bucket, at most: one wave per component scans its bucket index in LDS
+        for (int c = tid >> 6; c < nk; c += CT >> 6) {
+            const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + TTM_RT_HDR + Teven);
+            int per = 0;
+            for (int i = tid & 63; i < nb; i += 64) per = max(per, (int)bs[i + 1] - (int)bs[i]);
+            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+            if ((tid & 63) == 0) ((int*)(tabs + (size_t)c * tab_slot))[8] = per;
         }
         __syncthreads();
 
@@ -2551,7 +2529,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         const Tuning& tn = tuning();
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
-        const int NS = tn.rt_ns == 4 ? 4 : 2;
+        int NS = tn.rt_ns == 4 ? 4 : 2;
         const int Teven = (T + 4 + 1) & ~1;
         const int tab_slot = TTM_RT_HDR + Teven + (((nb + 1 + 3) / 4 + 1) & ~1);   // doubles: header + xs row + uint16 bucket index (even)
         const double ymax = fabs(h_y_affine[0]) > fabs(h_y_affine[2]) ? fabs(h_y_affine[0]) : fabs(h_y_affine[2]);
@@ -2571,8 +2549,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
             }
         }
         const int wgs = 1;                                               // the tables (+ the column cache) fill the LDS of a CU
-        // (banded maps with four rows per thread - option rt_ns = 4 - make the chunk of a workgroup ONE tile at C5, so the
-        // register columns survive the block boundaries and nothing is re-read; measured 0.209 against 0.202 ms with two)
+        // banded maps: four rows per thread when the chunk of a workgroup then is ONE tile - the register columns survive
+        // the block boundaries and nothing is re-read (0.1755 against 0.1781 ms with two at C5)
+        if (band && tn.rt_ns <= 0 && (N + di.cus - 1) / di.cus <= 4 * 1024) NS = 4;
         int CT = tn.rt_threads >= 64 && tn.rt_threads <= 1024 ? (tn.rt_threads & ~63) : 1024;
         const size_t budget = di.lds_per_cu / wgs;
         int Bc = 0;
