@@ -571,7 +571,7 @@ def main():
             # the dominant kernel = the one with the longer measured launch
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': traffic.get('%s_hbm_bytes_per_launch' % dom_kernel.split('<')[0]),
+                         'traffic': traffic.get("%s_hbm_bytes_per_launch" % dom_kernel.split("<")[0]),
                          'kernel': dom_kernel, 'which': dominant,
                          'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
                          'forward_frac': gbps(fwd_bytes, fwd_ms) / HBM_PEAK_GBS, 'forward_kernel': fwd_kernel,

@@ -1130,8 +1130,8 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
 // At a block boundary the state of a tile is re-loaded from the x columns the SAME thread stored in the previous block.
 // With ETAB, exp(-x_k^2/4) comes from the located table interval instead of a full exp: x_k = y_lo + delta with
 // 0 <= delta <= step, exp(-x_k^2/4) = E[i-1] exp(w), w = -delta (y_lo + x_k) / 4, |w| <= 0.1, E[i] = exp(-y_i^2/4)
-// tabulated once per workgroup (the abscissae are the same for every component), exp(w) by its degree-9 Taylor
-// polynomial (truncation 2.8e-17).  The host enables it when the targets are clipped to the table
+// tabulated once per workgroup (the abscissae are the same for every component), exp(w) by its degree-7 Taylor
+// polynomial (truncation 1.6e-16 relative for |y| <= 4; 3e-18 absolute everywhere).  The host enables it when the targets are clipped to the table
 // (root_search_truncation) and step * max|y| / 2 <= 0.1.
 // Search: the bucket function of k_table_index, bit for bit (table_bucket) -> a = number of entries in lower buckets; only
 // the entries of the target's own bucket are compared (at most `per` = 2-3 with nb ~ T): exact without verification.
@@ -1226,18 +1226,19 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
     const unsigned int row0 = (unsigned int)c0 + 2u * (unsigned int)tid, c1_32 = (unsigned int)c1;
     if (ETAB)
         for (int i = tid; i < T; i += CT) etab[i] = exp_q_fast(i == T - 1 ? ylast : (double)i * ystep + y0);
-    // Taylor coefficients 1/9! .. 1/2! of the ETAB put, kept in VGPRs (as scalars they would push the kernel over the
+    // Taylor coefficients 1/7! .. 1/2! of the ETAB put, kept in VGPRs (as scalars they would push the kernel over the
     // SGPR budget and be spilled to VGPR lanes: v_readlane + hazard nops in the middle of every step)
-    double kc[8];
+    double kc[6];
     {
         const __attribute__((address_space(4))) double* kg = (const __attribute__((address_space(4))) double*)g_exp_coef;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            kc[j] = kg[4 + j];
+        for (int j = 0; j < 6; ++j) {
+            kc[j] = kg[6 + j];
             if (ETAB) asm volatile("" : "+v"(kc[j]));
         }
     }
     const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
+    const double y0m = y0 - ystep;
     const int kc_first = ((cint_p)ucomp_)[k0 * TTM_UC_LEN + TTM_UC_KC];    // BAND: column of component k is kc_first + k - k0
     D2 bx1[NP], be1[NP], bx2[NP], be2[NP];                               // BAND: x and exp(-x^2/4) of columns kc-1 and kc-2
 #pragma unroll
@@ -1449,7 +1450,8 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 for (int e = 0; e < NS; ++e) {
                     const double z = (e & 1) ? zc[e >> 1].y : zc[e >> 1].x;
                     double target = -off[e] + z;
-                    if (truncate) {                          // TM:4074-4076: clip; a NaN target stays NaN (fmin / fmax drop it)
+                    if (ETAB || truncate) {                  // TM:4074-4076: clip; a NaN target stays NaN (fmin / fmax drop it)
+                                                             // (ETAB is only instantiated for clipped searches)
                         const double cl = fmin(fmax(target, lo), hi);
                         target = target != target ? target : cl;
                     }
@@ -1489,19 +1491,25 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
                     int i = max(pos[e], 1);
-                    i = min(i, T - 1);
+                    if (!ETAB) i = min(i, T - 1);            // (clipped targets never lie above the last entry)
                     const double x_lo = xsl[i - 1], x_hi = xsl[i];
-                    const double y_lo = (double)(i - 1) * ystep + y0;
-                    // y_hi - y_lo is the grid step up to the rounding of the two abscissae (1e-13 of the step, also in the last
-                    // interval, whose end point np.linspace forces: 2e-15 of x at most)
-                    const double slope = fast_div1(ystep, fmax(x_hi - x_lo, 1e-300));   // (tie at a flat start: table_lookup)
+                    const double y_lo = fma((double)i, ystep, y0m);          // abscissa i - 1 of the grid (to an ulp)
+                    // slope = step / (x_hi - x_lo): v_rcp_f64 (2^-23) with one Newton step (2^-46); its error moves x by
+                    // 0.02 x 2^-46 = 3e-16 at most.  y_hi - y_lo is the grid step up to the rounding of the two abscissae
+                    // (1e-13 of the step, also in the last interval, whose end point np.linspace forces: 2e-15 of x)
+                    const double dx = fmax(x_hi - x_lo, 1e-300);             // (tie at a flat start: table_lookup)
+                    double rc = approx_rcp(dx);
+                    rc = fma(fma(-dx, rc, 1.0), rc, rc);
+                    const double slope = ystep * rc;
                     const double delta = slope * (tg[e] - x_lo);
                     r[e] = delta + y_lo;
                     if (ETAB) {
+                        // exp(w), |w| <= 0.1 (0.04 for |y| <= 4), by its degree-7 Taylor polynomial: truncation w^8 / 8! is
+                        // 1.6e-16 relative at |y| = 4 and at most 2.5e-13 relative where exp(-y^2/4) itself is 1e-11
                         const double w = (delta * -0.25) * (y_lo + r[e]);
                         double p = kc[0];
 #pragma unroll
-                        for (int i2 = 1; i2 < 8; ++i2) p = fma(p, w, kc[i2]);
+                        for (int i2 = 1; i2 < 6; ++i2) p = fma(p, w, kc[i2]);
                         p = fma(p, w, 1.0);
                         p = fma(p, w, 1.0);
                         ev[e] = etab[i - 1] * p;
