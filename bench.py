@@ -320,9 +320,10 @@ def flops_per_eval(tm):
     """fp64 operations per component evaluation of the two U-form map kernels, counted from the arithmetic they
     execute (FMA = 2): forward = spline of the summed special terms (degree TTM_U_DEG = 11 Horner + 4 of index
     arithmetic) + exp(-x_k^2/4) of the column cache (degree-12 series + reduction, 2 x 15) + per nonmonotone group the
-    two Horner passes of its degree class and the combination; inverse = the groups + bucket arithmetic (4) + four
-    compares + interpolation (division: 10) + exp.  Returns (forward, inverse) averaged over the components, or None
-    for maps without a U-form."""
+    two Horner passes of its degree class and the combination; inverse (k_inverse_rt) = the groups + clip and bucket
+    (6) + two compares + interpolation (Newton reciprocal 5, slope / delta / abscissa 6) + the interval exponential
+    (degree-7 Taylor + argument + table factor: 2 x 7 + 4).  Returns (forward, inverse) averaged over the components, or
+    None for maps without a U-form."""
     cm = tm._cm
     if not getattr(cm, 'u_enabled', False) or not getattr(cm, 'u_h_cls', 0):
         return None
@@ -330,7 +331,7 @@ def flops_per_eval(tm):
     ngrp = float(np.mean(np.asarray(cm.ucomp).reshape(-1)[:cm.D * 8].reshape(cm.D, 8)[:, 2]))
     grp = ngrp * (2 * db + 2 * da + 3)
     fwd = grp + (2 * 11 + 4) + 30
-    inv = grp + 4 + 4 + (10 + 6) + 30
+    inv = grp + 6 + 2 + (5 + 6) + (14 + 4)
     return fwd, inv
 
 
