@@ -217,6 +217,19 @@ def other_configs(torch, names, steps=40):
                 a.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); b.record()
             torch.cuda.synchronize()
             r['inverse_newton_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evn]))
+            # FP64-bound path: arithmetic rate next to the byte rate.  Operations per evaluation of
+            # S_k, estimated from the restructured integrand g(t) = sum_n w_n B_n(t): Q nodes x (P recurrence steps of 2
+            # flop + the rectifier's exp ~ 30 + 4 of accumulation) + the nonmonotone part (~ 40); the reference
+            # bisection needs ~ 31 midpoints + 2 bracket points per root (mean 30.5 on the spiral)
+            Q = int(tm._qx_d.numel())
+            P = 5
+            per_eval = Q * (2 * P + 30 + 4) + 40
+            r['fp64'] = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'estimate': True, 'flop_per_forward_eval': per_eval,
+                         'forward_TFLOPs': per_eval * N * D / (r['forward_ms'] * 1e-3) / 1e12,
+                         'bisection_evals_per_root': 33,
+                         'inverse_TFLOPs': 33 * per_eval * N * D / (r['inverse_ms'] * 1e-3) / 1e12}
+            r['fp64']['forward_frac'] = r['fp64']['forward_TFLOPs'] / FP64_PEAK_TFLOPS
+            r['fp64']['inverse_frac'] = r['fp64']['inverse_TFLOPs'] / FP64_PEAK_TFLOPS
             r['roundtrip_median_abs_err_newton'] = float((Xinv[:, :N] - Xs[:, :N]).abs().median().item())
             tm.root_finder = 'reference'
         Nopt = N if separable else 100000            # (integrated-rectifier optimize(): BASELINE.md quotes N = 1e5)
@@ -400,6 +413,7 @@ def main():
     def step_uncached():
         # what a caller pays who changes the coefficients between calls (and what the reference does on every
         # inverse_map, TM:4047-4058): pack + fold + U-form build + table build + index, then the two lookups
+        tm._pack_memo = None                         # (the class keeps the packed vector of unchanged coefficients)
         c = tm._pack_coeffs()
         tm.forward_device(Xs, N, coef=c, Z=Z)
         tm.inverse_device(Z, N, coef=c, X=Xinv)

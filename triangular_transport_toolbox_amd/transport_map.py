@@ -559,8 +559,16 @@ class transport_map():
                 raise ValueError('component %d expects %d nonmonotone and %d monotone coefficients, got %d and %d'
                                  % (k, self._cm.n_nm[k], self._cm.n_mon[k], len(cn), len(cm)))
             parts += [cn, cm]
-        coef = self._to_dev(np.concatenate(parts))
-        return self._fold(coef)
+        host = np.concatenate(parts)
+        # the public methods pack on every call: an unchanged coefficient vector (the common case - map() and
+        # inverse_map() of one fitted map) reuses the packed, folded vector and the inverse tables kept with it
+        memo = getattr(self, '_pack_memo', None)
+        if override_k is None and memo is not None and memo[0] == self._epoch and np.array_equal(memo[1], host):
+            return memo[2]
+        coef = self._fold(self._to_dev(host))
+        if override_k is None:
+            self._pack_memo = (coef._ttm_epoch, host, coef)
+        return coef
 
     def _fold(self, coef):
         """Folded coefficients of a packed coefficient vector (device pre-pass, include/ttm.h "Folded coefficients"),
