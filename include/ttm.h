@@ -307,6 +307,13 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
 int64_t ttm_select_work_size(int32_t nr);
 int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out,
                          void* work, void* stream);
+/* The same select over a column whose rows are sharded over the ranks of a communicator (SURVEY.md section 8e:
+ * special-term placement of a sample-sharded ensemble): N = local rows, ranks = GLOBAL 0-based ranks; every pass
+ * all-reduces its nr x 256 bin counts (ttm_allreduce_i32), every rank ends with the same exact values; no element of
+ * the column moves.  comm NULL: ttm_order_statistics.                                                              */
+struct ttm_comm;
+int ttm_order_statistics_dist(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out,
+                              void* work, struct ttm_comm* comm, void* stream);
 
 /* ---- folded coefficients -------------------------------------------------------
  * The map kernels evaluate the nonmonotone part per variable with summed ("folded") coefficients

@@ -268,6 +268,47 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     return 0;
 }
 
+// radix select over sharded columns: the device algorithm (eight passes over the order-preserving 64-bit keys, bin
+// counts all-reduced per pass) on the host
+int ttm_allreduce_i32(ttm_comm* c, int32_t* buf, int64_t count, int32_t op, void*);
+int ttm_order_statistics_dist(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void*, ttm_comm* comm,
+                              void*) {
+    if (!comm) return ttm_order_statistics(col, N, ranks, nr, out, nullptr, nullptr);
+    auto key = [](double x) {
+        unsigned long long u;
+        memcpy(&u, &x, 8);
+        return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    };
+    std::vector<unsigned long long> prefix(nr, 0ull);
+    std::vector<long long> rank(ranks, ranks + nr);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+        std::vector<int32_t> hist((size_t)nr * 256, 0);
+        for (int64_t n = 0; n < N; ++n) {
+            const unsigned long long k = key(col[n]);
+            for (int j = 0; j < nr; ++j)
+                if (((k ^ prefix[j]) & himask) == 0ull) ++hist[(size_t)j * 256 + ((k >> shift) & 255ull)];
+        }
+        const int rc = ttm_allreduce_i32(comm, hist.data(), (int64_t)nr * 256, TTM_OP_SUM, nullptr);
+        if (rc) return rc;
+        for (int j = 0; j < nr; ++j) {
+            long long before = 0;
+            int t = 0;
+            for (; t < 255; ++t) {
+                if (rank[j] < before + hist[(size_t)j * 256 + t]) break;
+                before += hist[(size_t)j * 256 + t];
+            }
+            rank[j] -= before;
+            prefix[j] |= (unsigned long long)t << shift;
+        }
+    }
+    for (int j = 0; j < nr; ++j) {
+        const unsigned long long u = (prefix[j] >> 63) ? (prefix[j] & 0x7fffffffffffffffull) : ~prefix[j];
+        memcpy(&out[j], &u, 8);
+    }
+    return 0;
+}
+
 static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }
 static bool u_on(const ttm_program* p) { return p->u_enabled && !getenv("TTM_NO_UFORM"); }
 static int plan_ways_of(const ttm_program* p) { return (p->plan_ways < 1 || p->plan_ways > TTM_PLAN_WAYS) ? TTM_PLAN_WAYS : p->plan_ways; }

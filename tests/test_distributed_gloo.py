@@ -70,6 +70,17 @@ def _worker(rank, world, port, case, outdir):
             zlo, zhi = (0, M // 2) if rank == 0 else (M // 2, M)
             tm.alternate_root_finding = False                   # bisection: needs the all-reduced iteration caps
             out['Xinv'] = tm.inverse_map(Zin[zlo:zhi])
+            # exact order statistics of a column sharded over the ranks (duplicates, both signs, uneven shards):
+            # the radix select with all-reduced bin counts, no gather
+            g = np.random.default_rng(11).standard_normal(1501).round(2)
+            g[::7] = -g[::7]
+            mine = g[:600] if rank == 0 else g[600:]
+            before = emu.lib().ttm_hostemu_allreduce_calls()
+            ranks_ = np.array([0, 1, 375, 750, 751, 1499, 1500], dtype=np.int64)
+            vals, n_tot = tm._order_statistics(torch.from_numpy(mine.copy()), ranks_)
+            out['os'], out['os_n'] = vals, n_tot
+            out['os_ref'] = np.sort(g)[ranks_]
+            out['os_allreduces'] = emu.lib().ttm_hostemu_allreduce_calls() - before
             out['allreduce_calls'] = emu.lib().ttm_hostemu_allreduce_calls()
         np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
     finally:
@@ -127,6 +138,8 @@ def test_sample_sharding_world2(case, tmp_path):
     tm, npz, X, kw = _single(case)
     # the data-path reductions went through the C ABI's ttm_allreduce_* (moments, sums / Gram matrix, iteration caps)
     assert int(r0['allreduce_calls']) >= 4 and int(r0['allreduce_calls']) == int(r1['allreduce_calls'])
+    assert np.array_equal(r0['os'], r0['os_ref']) and np.array_equal(r1['os'], r1['os_ref']) and int(r0['os_n']) == 1501
+    assert int(r0['os_allreduces']) == 8                   # one all-reduce of the bin counts per radix pass
     with emu.install():
         assert rel(r0['X_mean'], tm.X_mean) < 1e-13 and rel(r0['X_std'], tm.X_std) < 1e-13
         assert np.array_equal(r0['X_mean'], r1['X_mean'])

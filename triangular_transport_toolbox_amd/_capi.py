@@ -45,6 +45,7 @@ _SIGNATURES = {
     'ttm_export': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ttm_select_work_size': (c_i64, [c_i32]),
     'ttm_order_statistics': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'ttm_order_statistics_dist': (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ttm_fold_size': (c_i64, [ctypes.POINTER(ttm_program)]),
     'ttm_uform_offset': (c_i64, [ctypes.POINTER(ttm_program)]),
     'ttm_fold': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp]),

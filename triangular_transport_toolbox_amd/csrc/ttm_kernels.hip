@@ -2163,6 +2163,21 @@ static int pick_block(int nslots, int extra_doubles, int ns = 1) {
     return 0;
 }
 
+static int select_passes(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, SelState* st, unsigned int* hist,
+                         ttm_comm* comm, hipStream_t s) {
+    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
+    const int nb = grid_for(N, 256 * 8);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
+        if (comm) {
+            const int rc = ttm_allreduce_i32(comm, (int32_t*)hist, (int64_t)nr * 256, TTM_OP_SUM, (void*)s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_select_pick, dim3(nr), dim3(256), 0, s, (int)nr, shift, st, hist, out);
+    }
+    return check_launch("k_select");
+}
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -2244,13 +2259,20 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
     hipStream_t s = (hipStream_t)stream;
     SelState* st = (SelState*)work;
     unsigned int* hist = (unsigned int*)((char*)work + sizeof(SelState));
-    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
-    const int nb = grid_for(N, 256 * 8);
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
-        hipLaunchKernelGGL(k_select_pick, dim3(nr), dim3(256), 0, s, (int)nr, shift, st, hist, out);
-    }
-    return check_launch("k_select");
+    return select_passes(col, N, ranks, nr, out, st, hist, nullptr, s);
+}
+
+// The same radix select over the shards of a column that is spread over the ranks of a communicator: every pass
+// all-reduces the nr x 256 bin counts (one ttm_allreduce_i32 of <= 16 KB) before the bin of the requested GLOBAL rank
+// is picked - identically on every rank - so after eight passes every rank holds the exact order statistic of the
+// whole column without any of its elements having moved.  N: local elements (may be 0 < N on every rank).
+int ttm_order_statistics_dist(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void* work,
+                              ttm_comm* comm, void* stream) {
+    if (!col || !ranks || !out || !work || N < 1 || nr < 1 || nr > TTM_SEL_MAX)
+        return set_err(TTM_E_ARG, "ttm_order_statistics_dist: bad arguments%s");
+    SelState* st = (SelState*)work;
+    unsigned int* hist = (unsigned int*)((char*)work + sizeof(SelState));
+    return select_passes(col, N, ranks, nr, out, st, hist, comm, (hipStream_t)stream);
 }
 
 static int64_t fold_base_size(const ttm_program* p) { return ((int64_t)p->h_fold_off[p->D] + 8 + 1) & ~(int64_t)1; }   // + read-ahead padding, even

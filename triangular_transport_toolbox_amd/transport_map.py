@@ -418,20 +418,28 @@ class transport_map():
         self._std_d = self._to_dev(self.X_std)
 
     def _order_statistics(self, col, ranks):
-        """Exact order statistics of a device column (K9 radix select); sharded ensembles gather the
-        column first (rank order = sample order)."""
+        """Exact order statistics of a device column (K9 radix select).  Sharded ensembles: the same select over the
+        shards, bin counts all-reduced per pass (ttm_order_statistics_dist) - no element of the column moves; without an
+        RCCL / test-double communicator (gloo rehearsals) the column is gathered first (rank order = sample order)."""
         torch = _torch()
         dist = self._dist()
+        handle = None
+        n_total = col.numel()
         if dist is not None:
-            sizes = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=self._dev)
-            sizes[dist.get_rank()] = col.numel()
-            dist.all_reduce(sizes)
-            nmax = int(sizes.max().item())
-            pad = torch.zeros(nmax, dtype=col.dtype, device=self._dev)
-            pad[:col.numel()] = col
-            parts = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
-            dist.all_gather(parts, pad)
-            col = torch.cat([p_[:int(n_)] for p_, n_ in zip(parts, sizes.tolist())])
+            t = torch.tensor([n_total], dtype=torch.int64, device=self._dev)
+            dist.all_reduce(t)
+            n_total = int(t.item())
+            handle = comm.get(self._lib, force=self._dev.type != 'cuda')
+            if handle is None:
+                sizes = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=self._dev)
+                sizes[dist.get_rank()] = col.numel()
+                dist.all_reduce(sizes)
+                nmax = int(sizes.max().item())
+                pad = torch.zeros(nmax, dtype=col.dtype, device=self._dev)
+                pad[:col.numel()] = col
+                parts = [torch.empty_like(pad) for _ in range(dist.get_world_size())]
+                dist.all_gather(parts, pad)
+                col = torch.cat([p_[:int(n_)] for p_, n_ in zip(parts, sizes.tolist())])
         col = col.contiguous()
         ranks = np.asarray(ranks, dtype=np.int64)
         out = np.empty(len(ranks))
@@ -439,11 +447,15 @@ class transport_map():
         for i in range(0, len(ranks), 16):
             r = self._to_dev(ranks[i:i + 16])
             o = self._empty(len(ranks[i:i + 16]))
-            _capi.check(self._lib.ttm_order_statistics(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()),
-                                                       r.numel(), self._ptr(o), ctypes.c_void_p(work.data_ptr()),
-                                                       self._stream()))
+            if handle is not None:
+                _capi.check(self._lib.ttm_order_statistics_dist(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()), r.numel(),
+                                                                self._ptr(o), ctypes.c_void_p(work.data_ptr()), handle, self._stream()))
+            else:
+                _capi.check(self._lib.ttm_order_statistics(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()),
+                                                           r.numel(), self._ptr(o), ctypes.c_void_p(work.data_ptr()),
+                                                           self._stream()))
             out[i:i + 16] = o.cpu().numpy()
-        return out, col.numel()
+        return out, n_total
 
     def _device_quantile(self, col, q, shift=None):
         """np.quantile(col - shift, q) (method 'linear'), bit-identical, from device order statistics."""
