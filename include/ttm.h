@@ -462,10 +462,13 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
  * ttm_optimize_separable: the reduced separable problem of one component (TM:2978-3018) minimised without leaving the
  *   library: J(c) = c'Ac/2 - sum_n log dS_n / Ntotal + c.b with dS = dPsi.c + delta rowsum(dPsi) from the cached
  *   derivative basis (ttm_objective_sep_cached).  A (m x m, row-major), b, lb, ub, x (start / result): host.
- *   sums_host: >= 1 + m doubles, pinned host memory the device can write; sums_dev (device, >= 1 + m doubles) and
+ *   sums_host: >= 2 + m doubles, pinned host memory the device can write (the last one is the completion mark); sums_dev (device, >= 1 + m doubles) and
  *   comm: non-NULL when the samples are sharded over ranks - the local sums are then combined by ONE
  *   ttm_allreduce_f64 of the fused [objective | gradient] buffer per evaluation; Ntotal = samples of all ranks.
  *   One stream synchronisation per evaluation, nothing else crosses the host boundary.                             */
+/* ttm_signal: *flag = value, ordered behind everything already enqueued on the stream.  With flag in pinned host memory
+ * a host loop polls it instead of paying hipStreamSynchronize per objective evaluation (ttm_optimize_separable does). */
+int ttm_signal(double* flag, double value, void* stream);
 typedef int32_t (*ttm_objective_cb)(int32_t n, const double* x, double* f, double* g, void* user);
 int ttm_lbfgsb_minimize(int32_t n, double* x, const double* lb, const double* ub, ttm_objective_cb fun, void* user,
                         int32_t maxiter, double* result);

@@ -801,6 +801,8 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
 }
 }
 
+extern "C" int ttm_signal(double* flag, double value, void*) { if (!flag) return TTM_E_ARG; *flag = value; return TTM_OK; }
+
 // the optimiser loops of the product, compiled for the host (no streams)
 #define TTM_HOST_ONLY
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_optim.cpp"

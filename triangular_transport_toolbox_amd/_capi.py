@@ -68,6 +68,7 @@ _SIGNATURES = {
     'ttm_lorenz63_rk4': (ctypes.c_int, [c_vp, c_i64, c_i64, c_dbl, c_i32, c_vp]),
     'ttm_perturb': (ctypes.c_int, [c_vp, c_vp, c_dbl, ctypes.c_uint64, ctypes.c_uint32, c_i64, c_i64, c_vp, c_vp]),
     'ttm_map_columns': (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp]),
+    'ttm_signal': (ctypes.c_int, [c_vp, c_dbl, c_vp]),
     'ttm_lbfgsb_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_optimize_separable': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -1941,6 +1941,9 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     }
 }
 
+// stream-ordered completion mark in (pinned host) memory: the host polls it instead of calling hipStreamSynchronize
+__global__ void k_signal(double* flag, double value) { *flag = value; }
+
 // out[i] = sum_b partial[b*nout + i], one wave per output
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblocks, int nout,
                                                          double* __restrict__ out) {
@@ -2806,6 +2809,12 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
     }
     hipLaunchKernelGGL(k_map_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ldi, cm, (int)ncols, N, out, ldo);
     return check_launch("k_map_columns");
+}
+
+int ttm_signal(double* flag, double value, void* stream) {
+    if (!flag) return set_err(TTM_E_ARG, "ttm_signal: null flag%s");
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
+    return check_launch("k_signal");
 }
 
 }  // extern "C"

@@ -58,7 +58,9 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
         ttm_comm* comm;
         void* stream;
         int rc;
-    } c{dPsi, A, b, ldp, N, (int)m, 1.0 / Ntotal, delta, work, sums_dev, sums_host, counter, comm, stream, 0};
+        long seq;
+    } c{dPsi, A, b, ldp, N, (int)m, 1.0 / Ntotal, delta, work, sums_dev, sums_host, counter, comm, stream, 0, 0};
+    sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n log dS_n, sums[1 + i] = sum_n dPsi_{n,i} / dS_n  (TM:2990-3006), over the local samples
@@ -76,7 +78,18 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
 #endif
         }
 #ifndef TTM_HOST_ONLY
-        if (hipStreamSynchronize((hipStream_t)c.stream) != hipSuccess) return c.rc = TTM_E_HIP;
+        // completion: a mark written behind the reduction into the pinned result buffer (slot 1 + n), polled here - a
+        // hipStreamSynchronize per evaluation costs ~12 us of host / driver latency on top of the ~13 us of device work
+        const double mark = (double)(++c.seq);
+        volatile double* flag = c.sums_host + 1 + n;
+        c.rc = ttm_signal((double*)flag, mark, c.stream);
+        if (c.rc) return c.rc;
+        for (long spins = 0; *flag != mark; ++spins) {
+            if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)c.stream) == hipSuccess && *flag != mark) {
+                if (hipStreamSynchronize((hipStream_t)c.stream) != hipSuccess) return c.rc = TTM_E_HIP;   // (mark lost: cannot happen; do not spin forever)
+                break;
+            }
+        }
 #endif
         // J = c'Ac/2 - sum log dS / N + c.b,  grad = Ac - sums/N + b   (TM:3008-3018)
         double quad = 0.0, lin = 0.0;
