@@ -28,18 +28,32 @@ def get(lib, force=False):
     if not force and dist.get_backend() != 'nccl':
         _state.update(key=key, comm=None, lib=lib)
         return None
-    from . import _capi
+    # Every rank must take the same branch at every step of the rendezvous (a rank that raises while the others wait in
+    # a collective hangs the job): failures are agreed on through torch.distributed and turn into "no communicator" -
+    # the class then reduces through torch.distributed, as it does for non-RCCL process groups.
+    import warnings
+
+    import torch
     buf = ctypes.create_string_buffer(128)
+    ok = 1
     if dist.get_rank() == 0:
-        rc = lib.ttm_comm_unique_id(buf)
-        if rc != 0:
-            raise _capi.TTMError('ttm_comm_unique_id: %d: %s' % (rc, lib.ttm_comm_last_error().decode()))
-    box = [buf.raw]
+        ok = 1 if lib.ttm_comm_unique_id(buf) == 0 else 0
+    box = [(ok, buf.raw)]
     dist.broadcast_object_list(box, src=0)
+    ok, raw = box[0]
     handle = ctypes.c_void_p()
-    rc = lib.ttm_comm_create(ctypes.c_char_p(box[0]), dist.get_rank(), dist.get_world_size(), ctypes.byref(handle))
-    if rc != 0:
-        raise _capi.TTMError('ttm_comm_create: %d: %s' % (rc, lib.ttm_comm_last_error().decode()))
+    if ok:
+        ok = 1 if lib.ttm_comm_create(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size(), ctypes.byref(handle)) == 0 else 0
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if ok and handle:
+            lib.ttm_comm_destroy(handle)
+        warnings.warn('libttm communicator not available (%s): reductions go through torch.distributed'
+                      % lib.ttm_comm_last_error().decode())
+        _state.update(key=key, comm=None, lib=lib)
+        return None
     _state.update(key=key, comm=handle, lib=lib)
     return handle
 
