@@ -35,7 +35,7 @@ def build(cfgname, fixture, N):
     return tm, om, X
 
 
-def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails():
+def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails(ttm_opt):
     N = 1000000
     tm, om, X = build('C5', 'c5_sep', N)
     assert tm._cm.u_enabled and tm._cm.u_h_cls > 0
@@ -53,6 +53,10 @@ def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails():
     jdx = np.concatenate((np.arange(50), subset_with_tails(Zr, 10000)))
     Xr = tm.inverse_map(Zr)
     assert relerr(Xr[jdx], om.inverse_map(Zr[jdx])) < 1e-9
+    assert tm._lib.ttm_last_kernel().decode() in ('k_export', 'k_inverse_rt<band>')
+    ttm_opt('rt_window', 0)                                                   # whole tables resident: the same bits as the planned window
+    assert np.array_equal(tm.inverse_map(Zr), Xr)
+    ttm_opt('rt_window', -1)
     perm = np.random.default_rng(3).permutation(N)
     assert np.array_equal(tm.inverse_map(Zr[perm]), Xr[perm])                 # samples are independent: exact
     assert np.array_equal(tm.map(X[perm]), Z[perm])

@@ -250,6 +250,19 @@ def test_every_hot_kernel_class_against_the_oracle(backend, monkeypatch, D, band
         E = D // 2
         Zq = om.map(X[:200])
         assert relerr(tm.inverse_map(Zq[:, E:], X_star=X[:200, :E]), om.inverse_map(Zq[:, E:], X_star=X[:200, :E])) < 1e-9
+    # windowed tables of the resident-table inverse (only the middle of every table in LDS, the rest searched in
+    # memory): the same bits as with whole tables, whatever the window and however many rows fall outside it
+    Zw = rng.standard_normal((1500, D))
+    Zw[:40] *= 4.0
+    Zw[40] = np.nan
+    full = tm.inverse_map(Zw)
+    keep = np.arange(len(Zw)) != 40
+    assert relerr(full[keep], om.inverse_map(Zw[keep])) < 1e-9 and np.all(np.isnan(full[40]))
+    for rows in (2, 4):
+        ttm_opt('rt_ns', rows)
+        for window in (0, 40, 300, 650, 990):
+            ttm_opt('rt_window', window)
+            assert np.array_equal(tm.inverse_map(Zw), full, equal_nan=True), (rows, window)
     assert tm.uform_fit_error[:, 0].max() < 5e-14
 
 

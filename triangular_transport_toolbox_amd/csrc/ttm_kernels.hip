@@ -1135,9 +1135,14 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
 // (root_search_truncation) and step * max|y| / 2 <= 0.1.
 // Search: the bucket function of k_table_index, bit for bit (table_bucket) -> a = number of entries in lower buckets; only
 // the entries of the target's own bucket are compared (at most `per` = 2-3 with nb ~ T): exact without verification.
-// LDS (doubles): [tables: B x tab_slot | E: Teven (ETAB) | column cache, 2 x ways x NS x blockDim]
-// table slot: [lo, hi, bucket scale, bucket bias, int32 {entries per bucket at most, 0}, 0 | xs: T entries + 4 sentinels
-//              (+inf), rounded up to even | bucket index: nb + 1 uint16]
+// LDS (doubles): [tables: B x tab_slot | E: Weven (ETAB) | column cache, 2 x ways x NS x blockDim]
+// table slot: [lo, hi, bucket scale, bucket bias, int32 {entries per bucket at most, band code}, 0 | xs: W entries + 4
+//              sentinels (+inf), rounded up to even | bucket index: nb + 1 uint16]
+// Windowed tables (W < T): only entries [w0, w0 + W) of every table (and of E) are resident - the middle of the grid,
+// where all but a handful per million of a standard-normal ensemble's rows land - so more components fit a block and
+// the chunk is passed over fewer times.  The bucket index stays whole and holds entry numbers of the whole table; a
+// row whose bucket starts outside [w0 + 1, w0 + W - 5) (its compares or its interval could leave the window) is an
+// outlier: np.searchsorted over the table in memory, then the same interpolation.
 // ---------------------------------------------------------------------------
 // The bucket function of the table search, shared bit for bit by the index kernel and the lookup kernels (IEEE
 // division, one fma): bucket(x) = clamp((int)fma(x, scale, bias), 0, nb - 1), scale = nb / (hi - lo), bias = -lo scale.
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                                                      const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
                                                      const double* __restrict__ tmin, const double* __restrict__ tmax,
                                                      const int* __restrict__ bkt, int nb, int truncate,
-                                                     int tab_slot, int B, int ways, int64_t rows_per_wg) {
+                                                     int tab_slot, int B, int ways, int64_t rows_per_wg, int w0, int W) {
     constexpr int NP = NS / 2;
     constexpr int DB = CLS == 1 ? 3 : (CLS == 2 ? 5 : 7), DA = CLS == 1 ? 1 : (CLS == 2 ? 5 : 7), GS = CLS == 1 ? 8 : (CLS == 2 ? 16 : 24);
     constexpr int HS = TTM_H_HDR + NG * GS;
@@ -1216,16 +1221,18 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
     if (c0 >= N) return;
     const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
     const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
-    const int Teven = (T + 4 + 1) & ~1;
+    // resident part of every table: entries [w0, w0 + W) (the whole table when W == T), 4 sentinels behind it
+    const int Weven = (W + 4 + 1) & ~1;
     double* tabs = g_smem;
     double* etab = tabs + (size_t)B * tab_slot;
-    double* cache = etab + (ETAB ? Teven : 0);
+    double* cache = etab + (ETAB ? Weven : 0);
+    const double* etabw = etab - w0;                                     // indexed by the entry's number in the whole table
     const RtCache<NP> cc{cache + 2 * tid, 2 * CT};
     // (row numbers are 32-bit - N < 2^28 - and every access is `uniform column base + 32-bit byte offset`)
     const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);        // first row of the last readable pair
     const unsigned int row0 = (unsigned int)c0 + 2u * (unsigned int)tid, c1_32 = (unsigned int)c1;
     if (ETAB)
-        for (int i = tid; i < T; i += CT) etab[i] = exp_q_fast(i == T - 1 ? ylast : (double)i * ystep + y0);
+        for (int i = tid; i < W; i += CT) etab[i] = exp_q_fast(w0 + i == T - 1 ? ylast : (double)(w0 + i) * ystep + y0);
     // Taylor coefficients 1/7! .. 1/2! of the ETAB put, kept in VGPRs (as scalars they would push the kernel over the
     // SGPR budget and be spilled to VGPR lanes: v_readlane + hazard nops in the middle of every step)
     double kc[6];
@@ -1256,7 +1263,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
             const double lo = tmin[c - k0], hi = tmax[c - k0];
             double scale, bias;
             table_bucket_params(lo, hi, nb, scale, bias);
-            slot[0] = lo; slot[1] = hi; slot[2] = scale; slot[3] = bias;
+            slot[2] = scale; slot[3] = bias;                             // ([0], [1]: the resident search's target range, below)
             int code = 0;
             if (BAND) {                                                  // n_grp | lag of group 0 << 4 | lag of group 1 << 8
                 const int* uc = ucomp_ + c * TTM_UC_LEN;
@@ -1267,20 +1274,20 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
             }
             ((int*)slot)[8] = 0;                                         // entries per bucket, at most
             ((int*)slot)[9] = code;
-            slot[5] = 0.0;
+            slot[5] = 0.0;                                               // int32 {degenerate, 0}
         }
         __syncthreads();
         // The tables of the block, sixteen components' loads in flight per thread: a loop over the components with one
         // load -> wait -> LDS store per pass costs a memory latency per component and kind - 80 latencies per workgroup
         // and launch at C5, a quarter of the kernel, while every wave waits at the barrier.
         for (int cg = 0; cg < nk; cg += 16) {
-            for (int i = tid; i < Teven; i += CT) {
+            for (int i = tid; i < Weven; i += CT) {
                 double v[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tab_x[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * T + min(i, T - 1)];   // (clamped, unconditional)
+                for (int u = 0; u < 16; ++u) v[u] = tab_x[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * T + w0 + min(i, W - 1)];   // (clamped, unconditional)
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    if (cg + u < nk) tabs[(size_t)(cg + u) * tab_slot + TTM_RT_HDR + i] = i < T ? v[u] : INFINITY;
+                    if (cg + u < nk) tabs[(size_t)(cg + u) * tab_slot + TTM_RT_HDR + i] = i < W ? v[u] : INFINITY;
             }
             for (int i = tid; i <= nb; i += CT) {
                 int v[16];
@@ -1288,17 +1295,37 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 for (int u = 0; u < 16; ++u) v[u] = bkt[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * (nb + 1) + i];
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    if (cg + u < nk) ((unsigned short*)(tabs + (size_t)(cg + u) * tab_slot + TTM_RT_HDR + Teven))[i] = (unsigned short)v[u];
+                    if (cg + u < nk) ((unsigned short*)(tabs + (size_t)(cg + u) * tab_slot + TTM_RT_HDR + Weven))[i] = (unsigned short)v[u];
             }
         }
         __syncthreads();
         // entries per bucket, at most: one wave per component scans its bucket index in LDS
         for (int c = tid >> 6; c < nk; c += CT >> 6) {
-            const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + TTM_RT_HDR + Teven);
+            const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + TTM_RT_HDR + Weven);
             int per = 0;
-            for (int i = tid & 63; i < nb; i += 64) per = max(per, (int)bs[i + 1] - (int)bs[i]);
+            for (int i = tid & 63; i < nb; i += 64) {                    // (buckets with an entry in the window)
+                const int b0 = bs[i], b1 = bs[i + 1];
+                if (b1 > w0 && b0 < w0 + W) per = max(per, b1 - b0);
+            }
             for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
-            if ((tid & 63) == 0) ((int*)(tabs + (size_t)c * tab_slot))[8] = per;
+            // Targets in [wl, wh] = [xs[w0 + per], xs[w0 + W - 2]] are searched in the resident window: a bucket that
+            // holds entry w0 + per or a later one starts at a >= w0 + 1 (it has at most per entries), so the position p
+            // lies in [w0 + 1, w0 + W - 2] and every entry read (a .. a + 3, p - 1, p) is resident or a sentinel.
+            // Everything else - the tails of the table, NaN - is an outlier of the step (below).
+            // A degenerate table (one bucket holds most of the window) sends every row there: bounds and bucket index are
+            // overwritten so that the resident search stays inside the window whatever it is given.
+            double* slot = tabs + (size_t)c * tab_slot;
+            const int pm = max(per, 1);
+            const bool deg = pm + 3 >= W;
+            if ((tid & 63) == 0) {
+                const double* xw = slot + TTM_RT_HDR;
+                ((int*)slot)[8] = per;
+                ((int*)slot)[10] = deg ? 1 : 0;
+                slot[0] = deg ? xw[1] : xw[pm];
+                slot[1] = deg ? xw[1] : xw[W - 2];
+            }
+            if (deg)
+                for (int i = tid & 63; i <= nb; i += 64) const_cast<unsigned short*>(bs)[i] = (unsigned short)(w0 + 1);
         }
         __syncthreads();
 
@@ -1393,11 +1420,11 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                     }
                 }
                 // ---- the table's search parameters (LDS broadcast reads) ---------------------------------------------
-                double lo, hi, scale, bias;
-                load_pair(slot, lo, hi);
+                double wl, wh, scale, bias;
+                load_pair(slot, wl, wh);
                 load_pair(slot + 2, scale, bias);
-                const double* xsl = slot + TTM_RT_HDR;
-                const unsigned short* bkl = (const unsigned short*)(xsl + Teven);
+                const double* xsl = slot + TTM_RT_HDR - w0;              // indexed by the entry's number in the whole table
+                const unsigned short* bkl = (const unsigned short*)(slot + TTM_RT_HDR + Weven);
                 // ---- nonmonotone offset (h_offset's arithmetic, operand for operand) ------------------------------------
                 double off[NS];
 #pragma unroll
@@ -1444,19 +1471,18 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 // bucket of this table holds (2-3 with nb ~ T) - what lies behind the bucket compares as not smaller, and
                 // behind the table stand +inf sentinels: no verification, no second pass.
                 const int per = __builtin_amdgcn_readfirstlane(((const int*)slot)[8]);
-                double tg[NS];
+                double traw[NS], tg[NS];
                 int pos[NS];
+                // the resident search runs on the target clipped to [wl, wh]; a row whose target that changes (the tails of
+                // the table, beyond the window, NaN) is an outlier: redone from the table in memory further down
+                unsigned long long outl = __builtin_amdgcn_readfirstlane(((const int*)slot)[10]) ? ~0ull : 0ull;
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
                     const double z = (e & 1) ? zc[e >> 1].y : zc[e >> 1].x;
-                    double target = -off[e] + z;
-                    if (ETAB || truncate) {                  // TM:4074-4076: clip; a NaN target stays NaN (fmin / fmax drop it)
-                                                             // (ETAB is only instantiated for clipped searches)
-                        const double cl = fmin(fmax(target, lo), hi);
-                        target = target != target ? target : cl;
-                    }
-                    tg[e] = target;
-                    pos[e] = (int)bkl[table_bucket(target, scale, bias, nb)];
+                    traw[e] = -off[e] + z;
+                    tg[e] = fmin(fmax(traw[e], wl), wh);
+                    outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
+                    pos[e] = (int)bkl[table_bucket(tg[e], scale, bias, nb)];
                 }
                 if (per <= 2) {
 #pragma unroll
@@ -1488,11 +1514,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 }
                 // ---- interp1d slope form (TM:4062-4065) and, with ETAB, exp(-x^2/4) from the located interval -------------
                 double r[NS], ev[NS];
-#pragma unroll
-                for (int e = 0; e < NS; ++e) {
-                    int i = max(pos[e], 1);
-                    if (!ETAB) i = min(i, T - 1);            // (clipped targets never lie above the last entry)
-                    const double x_lo = xsl[i - 1], x_hi = xsl[i];
+                auto interp = [&](int i, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
                     const double y_lo = fma((double)i, ystep, y0m);          // abscissa i - 1 of the grid (to an ulp)
                     // slope = step / (x_hi - x_lo): v_rcp_f64 (2^-23) with one Newton step (2^-46); its error moves x by
                     // 0.02 x 2^-46 = 3e-16 at most.  y_hi - y_lo is the grid step up to the rounding of the two abscissae
@@ -1501,18 +1523,48 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                     double rc = approx_rcp(dx);
                     rc = fma(fma(-dx, rc, 1.0), rc, rc);
                     const double slope = ystep * rc;
-                    const double delta = slope * (tg[e] - x_lo);
-                    r[e] = delta + y_lo;
+                    const double delta = slope * (tgt - x_lo);
+                    rr = delta + y_lo;
                     if (ETAB) {
                         // exp(w), |w| <= 0.1 (0.04 for |y| <= 4), by its degree-7 Taylor polynomial: truncation w^8 / 8! is
                         // 1.6e-16 relative at |y| = 4 and at most 2.5e-13 relative where exp(-y^2/4) itself is 1e-11
-                        const double w = (delta * -0.25) * (y_lo + r[e]);
+                        const double w = (delta * -0.25) * (y_lo + rr);
                         double p = kc[0];
 #pragma unroll
                         for (int i2 = 1; i2 < 6; ++i2) p = fma(p, w, kc[i2]);
                         p = fma(p, w, 1.0);
                         p = fma(p, w, 1.0);
-                        ev[e] = etab[i - 1] * p;
+                        ee = e_lo * p;
+                    }
+                };
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const int i = pos[e];                    // (in [w0 + 1, w0 + W - 2] for a target in [wl, wh])
+                    interp(i, xsl[i - 1], xsl[i], ETAB ? etabw[i - 1] : 0.0, tg[e], r[e], ev[e]);
+                }
+                if (outl != 0) {
+                    // outliers (a handful per million rows of a standard-normal ensemble): clip as TM:4074-4076 does,
+                    // np.searchsorted (left) over the whole row in memory, the same interpolation
+                    const double* xg = tab_x + (int64_t)(kb - k0 + j) * T;
+                    const bool deg = __builtin_amdgcn_readfirstlane(((const int*)slot)[10]) != 0;
+                    const double lo = tmin[kb - k0 + j], hi = tmax[kb - k0 + j];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        if (deg || traw[e] != tg[e]) {
+                            double t = traw[e];
+                            if (ETAB || truncate) {          // a NaN target stays NaN (fmin / fmax drop it)
+                                                             // (ETAB is only instantiated for clipped searches)
+                                const double cl = fmin(fmax(t, lo), hi);
+                                t = t != t ? t : cl;
+                            }
+                            int a = 0, b = T;
+                            while (a < b) {
+                                const int mid = (a + b) >> 1;
+                                if (xg[mid] < t) a = mid + 1; else b = mid;
+                            }
+                            const int i = min(max(a, 1), T - 1);
+                            interp(i, xg[i - 1], xg[i], ETAB ? exp_q_fast((double)(i - 1) * ystep + y0) : 0.0, t, r[e], ev[e]);
+                        }
                     }
                 }
                 // ---- keep x_k (and exp(-x_k^2/4)) for the components behind; the store is deferred to the next step -----
@@ -2081,7 +2133,8 @@ static const DeviceInfo& device_info() {
     X(rt_ns, -1)         /* rows per thread of k_inverse_rt (2, 4)                                                   */ \
     X(rt_block, -1)      /* components per block of k_inverse_rt                                                     */ \
     X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */ \
-    X(rt_band, -1)       /* 0: banded maps through the LDS column cache instead of the register shift                */
+    X(rt_band, -1)       /* 0: banded maps through the LDS column cache instead of the register shift                */ \
+    X(rt_window, -1)     /* resident entries per table of k_inverse_rt: 0 whole tables, > 0 that many, -1 planned    */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2565,8 +2618,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
         int NS = tn.rt_ns == 4 ? 4 : 2;
-        const int Teven = (T + 4 + 1) & ~1;
-        const int tab_slot = TTM_RT_HDR + Teven + (((nb + 1 + 3) / 4 + 1) & ~1);   // doubles: header + xs row + uint16 bucket index (even)
+        int W = T, w0 = 0;                                               // resident window of every table (entries [w0, w0 + W))
+        int Weven = (W + 4 + 1) & ~1;
+        int tab_slot = TTM_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);   // doubles: header + xs window + uint16 bucket index (even)
         const double ymax = fabs(h_y_affine[0]) > fabs(h_y_affine[2]) ? fabs(h_y_affine[0]) : fabs(h_y_affine[2]);
         bool etab = truncate && h_y_affine[1] > 0.0 && h_y_affine[1] * ymax * 0.5 <= 0.1;
         if (tn.rt_etab == 0) etab = false;
@@ -2589,24 +2643,48 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         if (band && tn.rt_ns <= 0 && (N + di.cus - 1) / di.cus <= 4 * 1024) NS = 4;
         int CT = tn.rt_threads >= 64 && tn.rt_threads <= 1024 ? (tn.rt_threads & ~63) : 1024;
         const size_t budget = di.lds_per_cu / wgs;
-        int Bc = 0;
+        int Bc = 0, nblk = 0;
         size_t lds = 0;
-        for (; CT >= 256; CT -= 256) {                                   // fewer rows in flight if the tables would not fit
-            const size_t fixed = ((size_t)(etab ? Teven : 0) + (band ? 0 : (size_t)2 * ways * NS * CT)) * 8;
-            if (fixed + (size_t)tab_slot * 8 > budget) continue;
-            Bc = (int)((budget - fixed) / ((size_t)tab_slot * 8));
-            if (Bc > ncomp) Bc = ncomp;
-            if (tn.rt_block > 0 && tn.rt_block < Bc) Bc = tn.rt_block;
-            const int nblk = (ncomp + Bc - 1) / Bc;
-            Bc = (ncomp + nblk - 1) / nblk;                              // even out the blocks
-            lds = fixed + (size_t)Bc * tab_slot * 8;
-            if (Bc >= 4 || Bc == ncomp) break;
+        const int CT0 = CT;
+        auto plan_blocks = [&]() {
             Bc = 0;
+            for (CT = CT0; CT >= 256; CT -= 256) {                       // fewer rows in flight if the tables would not fit
+                const size_t fixed = ((size_t)(etab ? Weven : 0) + (band ? 0 : (size_t)2 * ways * NS * CT)) * 8;
+                if (fixed + (size_t)tab_slot * 8 > budget) continue;
+                Bc = (int)((budget - fixed) / ((size_t)tab_slot * 8));
+                if (Bc > ncomp) Bc = ncomp;
+                if (tn.rt_block > 0 && tn.rt_block < Bc) Bc = tn.rt_block;
+                nblk = (ncomp + Bc - 1) / Bc;
+                Bc = (ncomp + nblk - 1) / nblk;                          // even out the blocks
+                lds = fixed + (size_t)Bc * tab_slot * 8;
+                if (Bc >= 4 || Bc == ncomp) break;
+                Bc = 0;
+            }
+        };
+        plan_blocks();
+        // Windowed tables: with only the middle of every table resident (|y| <= 6.5 of the +-10 the grid spans; rows
+        // beyond it are searched in memory, k_inverse_rt "outliers") more components fit a block.  Taken when that
+        // saves a pass over the chunk - every block boundary costs the table load and a drained pipeline (~8 us at C5).
+        if (tn.rt_window != 0 && aligned && T >= 64 && (tn.rt_window > 0 || (Bc > 0 && nblk > 1))) {
+            const int Bfull = Bc, nfull = nblk, CTfull = CT;
+            const size_t ldsfull = lds;
+            W = tn.rt_window > 0 ? (tn.rt_window < 16 ? 16 : tn.rt_window) : (int)(0.65 * T);
+            if (W >= T) W = T - 1;
+            w0 = (T - W) / 2;
+            Weven = (W + 4 + 1) & ~1;
+            tab_slot = TTM_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);
+            plan_blocks();
+            if (Bc == 0 || (tn.rt_window < 0 && !(Bfull > 0 && nblk < nfull))) {            // no gain: whole tables
+                W = T; w0 = 0;
+                Weven = (W + 4 + 1) & ~1;
+                tab_slot = TTM_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);
+                Bc = Bfull; nblk = nfull; CT = CTfull; lds = ldsfull;
+            }
         }
         if (aligned && Bc > 0) {
             typedef void (*rkern_t)(const int*, const int*, const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t,
                                     int64_t, const double*, int, double, double, double, const double*, const double*, const int*, int,
-                                    int, int, int, int, int64_t);
+                                    int, int, int, int, int64_t, int, int);
             rkern_t rk;
 #define TTM_RK4(NGV, CLSV, NSV, E) (band ? k_inverse_rt<NGV, CLSV, NSV, E, true> : k_inverse_rt<NGV, CLSV, NSV, E, false>)
 #define TTM_RK3(NGV, CLSV, NSV) (etab ? TTM_RK4(NGV, CLSV, NSV, true) : TTM_RK4(NGV, CLSV, NSV, false))
@@ -2624,7 +2702,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
             allow_big_lds((const void*)rk, lds);
             hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(CT), lds, (hipStream_t)stream, p->ucomp, p->ugrp, fold + fold_base_size(p),
                                (int64_t)p->u_h_off, (int)p->D, (int)k0, (int)k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine[0],
-                               h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, Bc, ways, rows);
+                               h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, Bc, ways, rows, w0, W);
             return check_launch(band ? "k_inverse_rt<band>" : "k_inverse_rt");
         }
     }
