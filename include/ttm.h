@@ -465,7 +465,17 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
  *   sums_host: >= 2 + m doubles, pinned host memory the device can write (the last one is the completion mark); sums_dev (device, >= 1 + m doubles) and
  *   comm: non-NULL when the samples are sharded over ranks - the local sums are then combined by ONE
  *   ttm_allreduce_f64 of the fused [objective | gradient] buffer per evaluation; Ntotal = samples of all ranks.
- *   One stream synchronisation per evaluation, nothing else crosses the host boundary.                             */
+ *   One completion poll per evaluation, nothing else crosses the host boundary.
+ * TM:3252-3257 (scipy.optimize.minimize, method 'BFGS': gtol 1e-5 on max |g|, 200 n iterations, More-Thuente line
+ * search with the Nocedal-Wright bracketing search as its fallback) as a host C++ loop (csrc/ttm_bfgs.h).
+ * ttm_bfgs_minimize: generic front end; result (nullable, 5 doubles): {f, max |g|, iterations, evaluations, status:
+ *   0 = converged, 1 = iteration limit, 2 = no acceptable step (precision loss), 3 = NaN}.
+ * ttm_optimize_integrated: component k of an integrated-rectifier map minimised without leaving the library:
+ *   J(c) = sums[0] / Ntotal + penalty(c), grad = sums[1..m] / Ntotal + penalty'(c) with the sums of
+ *   ttm_objective_host (TM:3300-3380, 3435-3573) over the local samples, m = n_nonmon + n_mon <= 64 coefficients
+ *   [nonmonotone | monotone] in x (host, start / result); regularization 0 none, 1 l1: sum lambda_i |c_i|, 2 l2:
+ *   sum lambda_i c_i^2 (TM:3382-3431, 3575-3633; lambda: host, m doubles, NULL for 0).  work / counter as
+ *   ttm_objective_host; sums_host / sums_dev / comm / Ntotal as ttm_optimize_separable.                                */
 /* ttm_signal: *flag = value, ordered behind everything already enqueued on the stream.  With flag in pinned host memory
  * a host loop polls it instead of paying hipStreamSynchronize per objective evaluation (ttm_optimize_separable does). */
 int ttm_signal(double* flag, double value, void* stream);
@@ -477,6 +487,11 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
                            double Ntotal, double delta, const double* lb, const double* ub, double* x, double* work,
                            uint32_t* counter, double* sums_dev, double* sums_host, struct ttm_comm* comm, void* stream,
                            int32_t maxiter, double* result);
+int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, int32_t maxiter, double* result);
+int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const double* Xsoa, int64_t ldx, int64_t N,
+                            double Ntotal, int32_t regularization, const double* lambda, double* x, double* work,
+                            uint32_t* counter, double* sums_dev, double* sums_host, struct ttm_comm* comm, void* stream,
+                            int32_t maxiter, double* result);
 
 /* ---- C1: the one collective of the path (RCCL over xGMI) ---------------------------------------------
  * Replaces nothing in the reference (its only parallelism is the fork pool of TM:2789-2845, whose "collective" is

@@ -1,0 +1,148 @@
+"""The native BFGS loop (csrc/ttm_bfgs.h behind ttm_bfgs_minimize) against scipy.optimize.minimize(method='BFGS'), the
+optimiser the reference drives for integrated-rectifier components (TM:3252-3257).  Same algorithm - quasi-Newton update
+of the inverse Hessian, More-Thuente search with the bracketing search as fallback - so evaluation points agree to
+rounding on well-conditioned problems and iteration counts / minimisers agree on the others."""
+import ctypes
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize, rosen, rosen_der
+
+from triangular_transport_toolbox_amd import _capi
+
+
+def native_bfgs(lib, fun, x0, maxiter=0):
+    n = len(x0)
+    x = np.array(x0, dtype=float, copy=True)
+    calls = []
+
+    @_capi.OBJECTIVE_CB
+    def cb(n_, xp, fp, gp, user):
+        xx = np.ctypeslib.as_array(xp, shape=(n_,)).copy()
+        f, g = fun(xx)
+        fp[0] = f
+        for i in range(n_):
+            gp[i] = g[i]
+        calls.append(xx)
+        return 0
+    res = np.zeros(5)
+    rc = lib.ttm_bfgs_minimize(n, x.ctypes.data, ctypes.cast(cb, ctypes.c_void_p), None, maxiter, res.ctypes.data)
+    assert rc == 0
+    return x, dict(f=res[0], gnorm=res[1], nit=int(res[2]), nfev=int(res[3]), status=int(res[4])), calls
+
+
+def scipy_bfgs(fun, x0, **kw):
+    pts = []
+
+    def f(x):
+        pts.append(np.array(x, copy=True))
+        return fun(x)[0]
+    ref = minimize(f, x0, jac=lambda x: fun(x)[1], method='BFGS', **kw)
+    uniq = [pts[0]]
+    for p in pts[1:]:
+        if not np.array_equal(p, uniq[-1]):
+            uniq.append(p)
+    return ref, uniq
+
+
+def softplus_problem(seed, m, N=300):
+    """A component objective of the integrated-rectifier shape: 0.5 S^2 - log dS with S linear in the nonmonotone
+    coefficients and dS a softplus of a linear form of the monotone ones."""
+    rng = np.random.default_rng(seed)
+    Pn = rng.standard_normal((N, m // 2))
+    Pm = rng.standard_normal((N, m - m // 2)) * 0.7
+    base = rng.standard_normal(N)
+
+    def fun(c):
+        cn, cm = c[:m // 2], c[m // 2:]
+        u = Pm @ cm
+        sp = np.logaddexp(0.0, u)
+        sg = 1.0 / (1.0 + np.exp(-u))
+        S = Pn @ cn + base * sp
+        J = np.mean(0.5 * S ** 2 - np.log(sp))
+        gS = S / N
+        gn = Pn.T @ gS
+        gm = Pm.T @ (gS * base * sg - sg / sp / N)
+        return J, np.concatenate((gn, gm))
+    return fun
+
+
+@pytest.mark.parametrize('seed,m', [(0, 4), (1, 7), (2, 12), (3, 20)])
+def test_same_evaluation_points_as_scipy_on_component_shaped_problems(seed, m):
+    from tests.hostemu import emu
+    fun = softplus_problem(seed, m)
+    x0 = np.concatenate((np.zeros(m // 2), np.full(m - m // 2, 0.2)))
+    ref, pts = scipy_bfgs(fun, x0)
+    x, info, calls = native_bfgs(emu.lib(), fun, x0)
+    assert info['status'] == 0 and ref.status == 0
+    assert info['nit'] == ref.nit and len(calls) == len(pts)
+    for a, b in zip(calls[:12], pts[:12]):                       # (rounding of the matrix products grows along the run)
+        assert np.max(np.abs(a - b)) < 1e-10
+    assert abs(info['f'] - ref.fun) <= 1e-12 * (1 + abs(ref.fun))
+    assert np.max(np.abs(x - ref.x)) < 1e-6
+
+
+def test_rosenbrock_agrees():
+    from tests.hostemu import emu
+    x0 = np.array([-1.2, 1.0, 0.7, -0.4, 1.9])
+    fun = lambda v: (rosen(v), rosen_der(v))                     # noqa: E731
+    ref, pts = scipy_bfgs(fun, x0)
+    x, info, calls = native_bfgs(emu.lib(), fun, x0)
+    assert info['status'] == 0
+    assert abs(info['nit'] - ref.nit) <= 2 and abs(len(calls) - len(pts)) <= 4
+    assert np.max(np.abs(x - ref.x)) < 1e-5
+    for a, b in zip(calls[:8], pts[:8]):
+        assert np.max(np.abs(a - b)) < 1e-9
+
+
+def test_limits_and_failure_codes():
+    from tests.hostemu import emu
+    x0 = np.array([-1.2, 1.0, 0.7])
+    fun = lambda v: (rosen(v), rosen_der(v))                     # noqa: E731
+    ref = minimize(rosen, x0, jac=rosen_der, method='BFGS', options=dict(maxiter=4))
+    x, info, _ = native_bfgs(emu.lib(), fun, x0, maxiter=4)
+    assert info['status'] == 1 and info['nit'] == 4 and ref.status == 1
+    assert np.max(np.abs(x - ref.x)) < 1e-9
+    # an objective without a minimum along the gradient: no acceptable step -> status 2, as SciPy's "precision loss"
+    lin = lambda v: (float(-np.sum(v)), -np.ones_like(v))        # noqa: E731
+    ref = minimize(lambda v: lin(v)[0], x0, jac=lambda v: lin(v)[1], method='BFGS')
+    x, info, _ = native_bfgs(emu.lib(), lin, x0)
+    assert ref.status == 2 and info['status'] == 2
+    # NaN objective
+    x, info, _ = native_bfgs(emu.lib(), lambda v: (np.nan, np.full_like(v, np.nan)), x0)
+    assert info['status'] == 3
+    # already converged at the start
+    x, info, calls = native_bfgs(emu.lib(), lambda v: (float(v @ v), 2 * v), np.zeros(3))
+    assert info['status'] == 0 and info['nit'] == 0 and len(calls) == 1
+
+
+NONSMOOTH = {
+    'abs': (lambda v: (float(np.sum(np.abs(v)) + 0.5 * np.sum(v ** 2)), np.sign(v) + v), [2.0, -3.0, 1.0]),
+    'abs_quartic': (lambda v: (float(np.sum(np.abs(v - 0.3)) + 0.05 * np.sum(v ** 4)), np.sign(v - 0.3) + 0.2 * v ** 3), [2.0, -3.0, 1.0]),
+    'abs_shifted': (lambda v: (float(np.sum(np.abs(v - np.array([0.5, -0.2, 0.1]))) + 0.5 * np.sum(v ** 2)),
+                               np.sign(v - np.array([0.5, -0.2, 0.1])) + v), [2.1, -3.3, 1.7]),
+}
+
+
+@pytest.mark.parametrize('name', sorted(NONSMOOTH))
+def test_fallback_search_follows_scipy_point_for_point(name):
+    """Kinks make the More-Thuente search give up (rounding / xtol warnings); SciPy then runs the bracketing / zoom
+    search (cubic, quadratic, bisection trials) and finally reports precision loss.  The native loop must take the
+    same trial points all the way and end in the same state."""
+    from tests.hostemu import emu
+    fun, x0 = NONSMOOTH[name]
+    x0 = np.array(x0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ref, pts = scipy_bfgs(fun, x0)
+    x, info, calls = native_bfgs(emu.lib(), fun, x0)
+    assert ref.status == 2 and info['status'] == 2 and info['nit'] == ref.nit
+    # the More-Thuente search gives up on an interval of relative width 1e-14: whether that happens at trial j or j + 1
+    # is decided by the last bits of the steps, so the counts may differ by a trial or two; every point SciPy
+    # evaluated - all cubic / quadratic / bisection trials of the fallback included - must be among the native ones
+    assert abs(len(calls) - len(pts)) <= 2
+    C = np.array(calls)
+    for b in pts:
+        assert np.min(np.max(np.abs(C - b), axis=1)) <= 1e-9 * (1 + np.max(np.abs(b)))
+    assert np.max(np.abs(x - ref.x)) < 1e-9

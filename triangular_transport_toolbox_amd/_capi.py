@@ -72,6 +72,9 @@ _SIGNATURES = {
     'ttm_lbfgsb_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_optimize_separable': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_bfgs_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_optimize_integrated': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_vp, c_i64, c_i64, c_dbl, c_i32, c_vp, c_vp,
+                                               c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_comm_last_error': (ctypes.c_char_p, []),
     'ttm_comm_unique_id': (ctypes.c_int, [c_vp]),
     'ttm_comm_create': (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),

@@ -3,7 +3,8 @@
 // The reference hands every map component to scipy.optimize.minimize (TM:3108-3114 L-BFGS-B for separable maps,
 // TM:3252-3257 BFGS for integrated-rectifier maps), one Python call per objective evaluation.  Here the same
 // algorithm (csrc/ttm_lbfgsb.h) runs as a host loop that launches the device reduction, waits for the stream and
-// reads the 1 + m sums from pinned memory: ~10 us per evaluation instead of ~80 us.  With a communicator the sums of
+// reads the 1 + m sums from pinned memory: ~10 us per evaluation instead of ~80 us; csrc/ttm_bfgs.h is the same for
+// SciPy's BFGS over the integrated-rectifier objective (ttm_optimize_integrated).  With a communicator the sums of
 // all ranks are combined by ONE all-reduce of the fused [objective | gradient] buffer per evaluation (RCCL,
 // ttm_allreduce_f64) before they are read - the sample-sharded optimisation of SURVEY.md section 8e.
 
@@ -18,7 +19,32 @@
 #endif
 
 #include "../../include/ttm.h"
+#include "ttm_bfgs.h"
 #include "ttm_lbfgsb.h"
+
+namespace {
+
+// Completion of the work queued on `stream` so far: a mark written behind it into pinned host memory (*flag), polled
+// here - a hipStreamSynchronize per evaluation costs ~12 us of host / driver latency on top of the ~13 us of device work.
+int wait_for_mark(double* flag_, long& seq, void* stream) {
+#ifndef TTM_HOST_ONLY
+    const double mark = (double)(++seq);
+    volatile double* flag = flag_;
+    const int rc = ttm_signal((double*)flag, mark, stream);
+    if (rc) return rc;
+    for (long spins = 0; *flag != mark; ++spins) {
+        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)stream) == hipSuccess && *flag != mark) {
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return TTM_E_HIP;   // (mark lost: cannot happen; do not spin forever)
+            break;
+        }
+    }
+#else
+    (void)flag_; (void)seq; (void)stream;
+#endif
+    return TTM_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -77,20 +103,8 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
                 return c.rc = TTM_E_HIP;
 #endif
         }
-#ifndef TTM_HOST_ONLY
-        // completion: a mark written behind the reduction into the pinned result buffer (slot 1 + n), polled here - a
-        // hipStreamSynchronize per evaluation costs ~12 us of host / driver latency on top of the ~13 us of device work
-        const double mark = (double)(++c.seq);
-        volatile double* flag = c.sums_host + 1 + n;
-        c.rc = ttm_signal((double*)flag, mark, c.stream);
+        c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
         if (c.rc) return c.rc;
-        for (long spins = 0; *flag != mark; ++spins) {
-            if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)c.stream) == hipSuccess && *flag != mark) {
-                if (hipStreamSynchronize((hipStream_t)c.stream) != hipSuccess) return c.rc = TTM_E_HIP;   // (mark lost: cannot happen; do not spin forever)
-                break;
-            }
-        }
-#endif
         // J = c'Ac/2 - sum log dS / N + c.b,  grad = Ac - sums/N + b   (TM:3008-3018)
         double quad = 0.0, lin = 0.0;
         for (int i = 0; i < n; ++i) {
@@ -104,6 +118,79 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
         return 0;
     };
     const int rc = ttm_lbfgsb_minimize(m, x, lb, ub, fun, &c, maxiter, result);
+    return c.rc ? c.rc : rc;
+}
+
+int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, int32_t maxiter, double* result) {
+    if (n < 1 || !x || !fun) return TTM_E_ARG;
+    ttm_opt::BfgsOptions opt;
+    if (maxiter > 0) opt.maxiter = maxiter;
+    const ttm_opt::BfgsResult r =
+        ttm_opt::bfgs_minimize(n, x, [&](const double* xx, double* f, double* g) { return fun(n, xx, f, g, user); }, opt);
+    if (result) {
+        result[0] = r.f; result[1] = r.gnorm; result[2] = r.nit; result[3] = r.nfev; result[4] = r.status;
+    }
+    return r.status < 0 ? TTM_E_HIP : TTM_OK;
+}
+
+int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const double* Xsoa, int64_t ldx, int64_t N, double Ntotal,
+                            int32_t regularization, const double* lambda, double* x, double* work, uint32_t* counter,
+                            double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result) {
+    if (!p || !Xsoa || !x || !work || !counter || !sums_host || m < 1 || m > 64 || N < 1 || !(Ntotal > 0.0) || regularization < 0 ||
+        regularization > 2 || (regularization && !lambda))
+        return TTM_E_ARG;
+    if (comm && !sums_dev) return TTM_E_ARG;
+    struct Ctx {
+        const ttm_program* p;
+        int k;
+        const double* Xsoa;
+        int64_t ldx, N;
+        double invN;
+        int reg;
+        const double* lam;
+        double *work, *sums_dev, *sums_host;
+        uint32_t* counter;
+        ttm_comm* comm;
+        void* stream;
+        int rc;
+        long seq;
+    } c{p, (int)k, Xsoa, ldx, N, 1.0 / Ntotal, (int)regularization, lambda, work, sums_dev, sums_host, counter, comm, stream, 0, 0};
+    sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
+    auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
+        Ctx& c = *(Ctx*)user;
+        // sums[0] = sum_n of the objective's sample terms, sums[1 + i] = sum_n of their derivatives (TM:3300-3380, 3435-3573)
+        double* out = c.comm ? c.sums_dev : c.sums_host;
+        c.rc = ttm_objective_host(c.p, c.k, cc, c.Xsoa, c.ldx, c.N, c.work, c.counter, out, c.stream);
+        if (c.rc) return c.rc;
+        if (c.comm) {
+            c.rc = ttm_allreduce_f64(c.comm, c.sums_dev, 1 + n, TTM_OP_SUM, c.stream);
+            if (c.rc) return c.rc;
+#ifdef TTM_HOST_ONLY
+            memcpy(c.sums_host, c.sums_dev, (size_t)(1 + n) * 8);
+#else
+            if (hipMemcpyAsync(c.sums_host, c.sums_dev, (size_t)(1 + n) * 8, hipMemcpyDeviceToHost, (hipStream_t)c.stream) != hipSuccess)
+                return c.rc = TTM_E_HIP;
+#endif
+        }
+        c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
+        if (c.rc) return c.rc;
+        // mean over the ensemble + the penalty on the coefficients (TM:3382-3431, 3575-3633)
+        double pen = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double gi = c.sums_host[1 + i] * c.invN;
+            if (c.reg == 1) {
+                pen += c.lam[i] * fabs(cc[i]);
+                gi += c.lam[i] * (cc[i] > 0.0 ? 1.0 : cc[i] < 0.0 ? -1.0 : 0.0);
+            } else if (c.reg == 2) {
+                pen += c.lam[i] * cc[i] * cc[i];
+                gi += c.lam[i] * 2 * cc[i];
+            }
+            g[i] = gi;
+        }
+        *f = c.sums_host[0] * c.invN + pen;
+        return 0;
+    };
+    const int rc = ttm_bfgs_minimize(m, x, fun, &c, maxiter, result);
     return c.rc ? c.rc : rc;
 }
 

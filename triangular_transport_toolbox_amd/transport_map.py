@@ -1355,9 +1355,56 @@ class transport_map():
         out.x, out.fun, out.nit, out.nfev, out.status = x, float(res[0]), int(res[2]), int(res[3]), int(res[4])
         return out
 
+    def _optimize_integrated_native(self, k, x0, div):
+        """TM:3252-3257 for one component without leaving the library (ttm_optimize_integrated: SciPy's BFGS restated
+        over ttm_objective_host); None when the native loop does not apply (more than 64 coefficients, a penalty it
+        does not know, ranks that share samples without an RCCL / test-double communicator)."""
+        m = len(x0)
+        if not self.native_optimizer or m > 64:
+            return None
+        reg, lam = 0, None
+        if self.regularization is not None:
+            if type(self.regularization) != str or self.regularization.lower() not in ('l1', 'l2'):
+                return None                                            # (the Python objective raises the reference's error)
+            reg = 1 if self.regularization.lower() == 'l1' else 2
+            if np.isscalar(self.regularization_lambda):
+                lam = np.full(m, float(self.regularization_lambda))
+            elif type(self.regularization_lambda) == list:
+                lam = np.ascontiguousarray(self.regularization_lambda[k], dtype=float)
+                if lam.shape != (m,):
+                    return None
+            else:
+                return None
+        handle = None
+        if self._dist() is not None:
+            handle = comm.get(self._lib, force=self._dev.type != 'cuda')
+            if handle is None:
+                return None
+        torch = _torch()
+        if getattr(self, '_obj_out', None) is None:
+            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            self._obj_cnt = self._zeros(16, dtype=torch.int32)
+        x = np.array(x0, dtype=float, copy=True)
+        work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
+        sums_dev = self._empty(1 + m) if handle is not None else None
+        res = np.zeros(5)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data) if a is not None else None                   # noqa: E731
+        _capi.check(self._lib.ttm_optimize_integrated(
+            self._pp, int(k), m, self._ptr(self._Xs), self._Xs.shape[1], self._N, float(self._Nglobal), reg, p(lam), p(x),
+            self._ptr(work), ctypes.c_void_p(self._obj_cnt.data_ptr()), self._ptr(sums_dev),
+            ctypes.c_void_p(self._obj_out.data_ptr()), handle, self._stream(), 0, p(res)))
+        self._obj_cache = None
+
+        class _Result:
+            pass
+        out = _Result()
+        out.x, out.fun, out.nit, out.nfev, out.status = x, float(res[0]), int(res[2]), int(res[3]), int(res[4])
+        out.success = out.status == 0
+        return out
+
     def optimize(self, K=None):
         """TM:2714-2901: per-component minimisation (BFGS / L-BFGS-B as TM:3252-3257 / TM:3108-3114) on the device
-        reductions: separable components by the library's own L-BFGS-B loop, integrated ones by SciPy's BFGS."""
+        reductions, by the library's own optimiser loops (L-BFGS-B for separable, BFGS for integrated components)."""
         from scipy.optimize import minimize
         if K is None:
             K = np.arange(self.D)
@@ -1375,8 +1422,10 @@ class transport_map():
                 div = len(self.coeffs_nonmon[k])
                 x0 = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float),
                                      np.asarray(self.coeffs_mon[k], dtype=float)))
-                opt = minimize(method='BFGS', fun=self.objective_function, jac=self.objective_function_jacobian,
-                               x0=x0, args=(k, div))
+                opt = self._optimize_integrated_native(k, x0, div)
+                if opt is None:
+                    opt = minimize(method='BFGS', fun=self.objective_function, jac=self.objective_function_jacobian,
+                                   x0=x0, args=(k, div))
                 self.coeffs_nonmon[k] = copy.deepcopy(opt.x[:div])
                 self.coeffs_mon[k] = copy.deepcopy(opt.x[div:])
             elif self.monotonicity == "separable monotonicity":
