@@ -487,7 +487,41 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
                            double Ntotal, double delta, const double* lb, const double* ub, double* x, double* work,
                            uint32_t* counter, double* sums_dev, double* sums_host, struct ttm_comm* comm, void* stream,
                            int32_t maxiter, double* result);
+/* ttm_optimize_separable_batch: ntasks independent component problems of one ensemble (same N, Ntotal, delta; the
+ * reference's fork pool over components, TM:2789-2845) on nthreads host threads, each with a HIP stream of its own
+ * (created once per process and device), so that the reductions of different components overlap on the device and
+ * their completion polls on the host.  Every task carries its own dPsi / A / b / bounds / x / work / counter /
+ * sums_host (as ttm_optimize_separable; nothing may be shared between tasks) and receives rc and result.  The call
+ * first waits for `stream` (the producer of the dPsi bases); it returns when every task is done, with the first
+ * non-zero rc.  nthreads = 1 runs the tasks in order on `stream` itself.  No communicator: ranks that share the
+ * samples of an ensemble call ttm_optimize_separable per component, in the same order on every rank.              */
+typedef struct ttm_sep_task {
+    const double* dPsi;          /* device, m rows of N doubles, row stride ldp */
+    int64_t ldp;
+    int32_t m, rc;
+    const double *A, *b, *lb, *ub;   /* host */
+    double* x;                   /* host, m: start / result */
+    double* work;                /* device, >= ttm_reduce_work_size(1 + m) doubles */
+    uint32_t* counter;           /* device uint32[16], zero */
+    double* sums_host;           /* pinned host, >= 2 + m doubles */
+    double result[5];
+} ttm_sep_task;
+int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta,
+                                 int32_t nthreads, void* stream, int32_t maxiter);
 int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, int32_t maxiter, double* result);
+/* ttm_optimize_integrated_batch: the same for the components of an integrated-rectifier map (one task per component
+ * k; fields as the arguments of ttm_optimize_integrated; work >= ttm_reduce_work_size(1 + m) doubles per task).   */
+typedef struct ttm_int_task {
+    int32_t k, m, regularization, rc;
+    const double* lambda;        /* host, m doubles (NULL without regularization) */
+    double* x;                   /* host, m: start / result [nonmonotone | monotone] */
+    double* work;                /* device */
+    uint32_t* counter;           /* device uint32[16], zero */
+    double* sums_host;           /* pinned host, >= 2 + m doubles */
+    double result[5];
+} ttm_int_task;
+int ttm_optimize_integrated_batch(const ttm_program* p, ttm_int_task* tasks, int32_t ntasks, const double* Xsoa,
+                                  int64_t ldx, int64_t N, double Ntotal, int32_t nthreads, void* stream, int32_t maxiter);
 int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const double* Xsoa, int64_t ldx, int64_t N,
                             double Ntotal, int32_t regularization, const double* lambda, double* x, double* work,
                             uint32_t* counter, double* sums_dev, double* sums_host, struct ttm_comm* comm, void* stream,

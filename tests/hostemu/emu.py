@@ -43,7 +43,7 @@ def build():
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in DEPS):
         return LIB
     tmp = '%s.tmp.%d' % (LIB, os.getpid())
-    subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-o', tmp, SRC], check=True)
+    subprocess.run(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread', '-o', tmp, SRC], check=True)
     os.replace(tmp, LIB)
     return LIB
 

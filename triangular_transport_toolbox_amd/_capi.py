@@ -18,6 +18,18 @@ c_i32, c_i64, c_dbl, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, cty
 OBJECTIVE_CB = ctypes.CFUNCTYPE(c_i32, c_i32, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), c_vp)
 
 
+class ttm_sep_task(ctypes.Structure):
+    """Mirror of `struct ttm_sep_task` (include/ttm.h: one component problem of ttm_optimize_separable_batch)."""
+    _fields_ = [('dPsi', c_vp), ('ldp', c_i64), ('m', c_i32), ('rc', c_i32), ('A', c_vp), ('b', c_vp), ('lb', c_vp), ('ub', c_vp),
+                ('x', c_vp), ('work', c_vp), ('counter', c_vp), ('sums_host', c_vp), ('result', c_dbl * 5)]
+
+
+class ttm_int_task(ctypes.Structure):
+    """Mirror of `struct ttm_int_task` (include/ttm.h: one component problem of ttm_optimize_integrated_batch)."""
+    _fields_ = [('k', c_i32), ('m', c_i32), ('regularization', c_i32), ('rc', c_i32), ('lam', c_vp), ('x', c_vp), ('work', c_vp),
+                ('counter', c_vp), ('sums_host', c_vp), ('result', c_dbl * 5)]
+
+
 class ttm_program(ctypes.Structure):
     """Mirror of `struct ttm_program` (include/ttm.h)."""
     _fields_ = [('itab', c_vp), ('ftab', c_vp), ('fdesc', c_vp), ('fints', c_vp), ('dpar', c_vp), ('quad_x', c_vp), ('quad_w', c_vp),
@@ -72,6 +84,9 @@ _SIGNATURES = {
     'ttm_lbfgsb_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_optimize_separable': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_optimize_separable_batch': (ctypes.c_int, [ctypes.POINTER(ttm_sep_task), c_i32, c_i64, c_dbl, c_dbl, c_i32, c_vp, c_i32]),
+    'ttm_optimize_integrated_batch': (ctypes.c_int, [ctypes.POINTER(ttm_program), ctypes.POINTER(ttm_int_task), c_i32, c_vp, c_i64, c_i64,
+                                                     c_dbl, c_i32, c_vp, c_i32]),
     'ttm_bfgs_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_optimize_integrated': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_vp, c_i64, c_i64, c_dbl, c_i32, c_vp, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),

@@ -20,7 +20,7 @@ HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', 'ttm_ufor
            os.path.join('..', '..', 'include', 'ttm.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
          '-DNDEBUG'] + shlex.split(os.environ.get('TTM_BUILD_FLAGS', ''))
-LINK = ['-ldl']                   # (RCCL is bound at run time, csrc/ttm_comm.cpp)
+LINK = ['-ldl', '-pthread']                   # (RCCL is bound at run time, csrc/ttm_comm.cpp)
 
 
 def hipcc_path():

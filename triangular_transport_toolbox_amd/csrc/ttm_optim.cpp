@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #ifndef TTM_HOST_ONLY          // (tests/hostemu compiles this file for the host: no streams, nothing to wait for)
@@ -41,6 +43,58 @@ int wait_for_mark(double* flag_, long& seq, void* stream) {
 #else
     (void)flag_; (void)seq; (void)stream;
 #endif
+    return TTM_OK;
+}
+
+// Independent component problems side by side (the reference's process pool over components, TM:2789-2845): worker
+// threads draw tasks from a shared counter; each worker owns one HIP stream, so the reductions of different components
+// overlap on the device and their completion polls overlap on the host.  run(t, stream) -> rc of task t.
+template <class Run>
+int run_batch(int ntasks, int nthreads, void* stream, Run run) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > ntasks) nthreads = ntasks;
+    if (nthreads > 64) nthreads = 64;
+    std::vector<int> rcs(ntasks, TTM_OK);
+    if (nthreads == 1) {
+        for (int t = 0; t < ntasks; ++t) rcs[t] = run(t, stream);
+    } else {
+#ifndef TTM_HOST_ONLY
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return TTM_E_HIP;
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return TTM_E_HIP;    // the producers of the inputs are done
+        static std::vector<hipStream_t> pool[64];                                         // per device; kept for the process
+        static std::atomic_flag pool_lock = ATOMIC_FLAG_INIT;
+        while (pool_lock.test_and_set(std::memory_order_acquire)) {}
+        std::vector<hipStream_t>& streams = pool[dev & 63];
+        bool ok = true;
+        while ((int)streams.size() < nthreads && ok) {
+            hipStream_t s2;
+            ok = hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess;
+            if (ok) streams.push_back(s2);
+        }
+        std::vector<hipStream_t> mine(streams.begin(), streams.begin() + (ok ? nthreads : 0));
+        pool_lock.clear(std::memory_order_release);
+        if (!ok) return TTM_E_HIP;
+#endif
+        std::atomic<int> next(0);
+        auto worker = [&](int w) {
+#ifndef TTM_HOST_ONLY
+            const bool on_device = hipSetDevice(dev) == hipSuccess;
+            void* st = (void*)mine[w];
+#else
+            const bool on_device = true;
+            void* st = stream;
+            (void)w;
+#endif
+            for (int t; (t = next.fetch_add(1)) < ntasks;) rcs[t] = on_device ? run(t, st) : (int)TTM_E_HIP;
+        };
+        std::vector<std::thread> threads;
+        for (int w = 1; w < nthreads; ++w) threads.emplace_back(worker, w);
+        worker(0);
+        for (auto& th : threads) th.join();
+    }
+    for (int t = 0; t < ntasks; ++t)
+        if (rcs[t]) return rcs[t];
     return TTM_OK;
 }
 
@@ -119,6 +173,26 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
     };
     const int rc = ttm_lbfgsb_minimize(m, x, lb, ub, fun, &c, maxiter, result);
     return c.rc ? c.rc : rc;
+}
+
+int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta, int32_t nthreads,
+                                 void* stream, int32_t maxiter) {
+    if (!tasks || ntasks < 1 || N < 1) return TTM_E_ARG;
+    return run_batch(ntasks, nthreads, stream, [&](int t, void* st) {
+        ttm_sep_task& q = tasks[t];
+        return q.rc = ttm_optimize_separable(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
+                                             q.sums_host, nullptr, st, maxiter, q.result);
+    });
+}
+
+int ttm_optimize_integrated_batch(const ttm_program* p, ttm_int_task* tasks, int32_t ntasks, const double* Xsoa, int64_t ldx, int64_t N,
+                                  double Ntotal, int32_t nthreads, void* stream, int32_t maxiter) {
+    if (!p || !tasks || ntasks < 1 || N < 1) return TTM_E_ARG;
+    return run_batch(ntasks, nthreads, stream, [&](int t, void* st) {
+        ttm_int_task& q = tasks[t];
+        return q.rc = ttm_optimize_integrated(p, q.k, q.m, Xsoa, ldx, N, Ntotal, q.regularization, q.lambda, q.x, q.work, q.counter,
+                                              nullptr, q.sums_host, nullptr, st, maxiter, q.result);
+    });
 }
 
 int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, int32_t maxiter, double* result) {

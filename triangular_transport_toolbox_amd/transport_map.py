@@ -958,7 +958,21 @@ class transport_map():
         self._allreduce(out)
         return out.cpu().numpy().reshape(m, m)
 
-    def separable_setup(self, k):
+    def _gram_many(self, K):
+        """Gram matrices of several components: the launches back to back, ONE all-reduce and ONE device-to-host
+        copy for all of them."""
+        sizes = [int(self._cm.n_nm[k] + self._cm.n_mon[k]) for k in K]
+        offs = np.concatenate(([0], np.cumsum([m * m for m in sizes]))).astype(int)
+        out = self._empty(int(offs[-1]))
+        work = self._workspace(self._lib.ttm_reduce_work_size(max(m * m for m in sizes)))
+        for k, o in zip(K, offs):
+            _capi.check(self._lib.ttm_gram(self._pp, int(k), self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
+                                           self._ptr(out, int(o)), self._stream()))
+        self._allreduce(out)
+        host = out.cpu().numpy()
+        return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(K, offs, sizes)}
+
+    def separable_setup(self, k, G=None):
         """The reduced separable problem of TM:2959-3050 from the Gram matrix of
         [Psi_nonmon | Psi_mon] (one device pass instead of QR / inv on N x m
         matrices).  Returns (A, solve_nonmon) with solve_nonmon(c_mon) -> c_nonmon
@@ -966,7 +980,8 @@ class transport_map():
         n_nm = int(self._cm.n_nm[k])
         if n_nm == 0:
             raise ValueError('separable monotonicity needs at least one nonmonotone term (TM:2966)')
-        G = self._gram(k)
+        if G is None:
+            G = self._gram(k)
         Gnn, Gnm, Gmm = G[:n_nm, :n_nm], G[:n_nm, n_nm:], G[n_nm:, n_nm:]
         N = self._Nglobal
         if self.regularization is None:
@@ -1355,6 +1370,126 @@ class transport_map():
         out.x, out.fun, out.nit, out.nfev, out.status = x, float(res[0]), int(res[2]), int(res[3]), int(res[4])
         return out
 
+    # host threads of the batched component optimisation (each with a HIP stream of its own)
+    optimizer_threads = 8
+    # device memory the cached derivative bases of one batch may take (bytes)
+    optimizer_batch_bytes = 8 << 30
+
+    def _optimize_separable_batch(self, K):
+        """TM:2746-2845 for separable maps: the components of K are independent problems (the reference hands them to
+        a process pool).  Per batch: every Gram matrix in one pass, the reduced problems on the host, every derivative
+        basis cached on the device, then ttm_optimize_separable_batch - the L-BFGS-B loops of the components side by
+        side on host threads with a HIP stream each.  Returns {k: result} or None when the batched native path does
+        not apply (the caller then walks the components one by one)."""
+        if not self.native_optimizer or len(K) < 2 or self.optimizer_threads < 2 or self._dist() is not None:
+            return None
+        if any(int(self._cm.n_mon[k]) < 1 or int(self._cm.n_mon[k]) > 16 or int(self._cm.n_nm[k]) == 0 for k in K):
+            return None
+        torch = _torch()
+        results = {}
+        per_k = [int(self._cm.n_mon[k]) * self._Xs.shape[1] * 8 for k in K]
+        start = 0
+        while start < len(K):
+            stop, used = start, 0
+            while stop < len(K) and (stop == start or used + per_k[stop] <= self.optimizer_batch_bytes):
+                used += per_k[stop]
+                stop += 1
+            batch = K[start:stop]
+            start = stop
+            grams = self._gram_many(batch)
+            n = len(batch)
+            wsz = int(self._lib.ttm_reduce_work_size(17))
+            work = self._empty(n * wsz)
+            counters = self._zeros(n * 16, dtype=torch.int32)
+            sums = torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            tasks = (_capi.ttm_sep_task * n)()
+            keep = []
+            for i, k in enumerate(batch):
+                A, solve_nonmon = self.separable_setup(k, G=grams[k])
+                m = int(self._cm.n_mon[k])
+                dpsi = self._cols(m, self._N)
+                _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
+                                                self._ptr(dpsi), dpsi.shape[1], self._stream()))
+                A = np.ascontiguousarray(A, dtype=float)
+                b = np.ascontiguousarray(self.delta * np.sum(A, axis=-1))
+                x = np.array(self.coeffs_mon[k], dtype=float, copy=True)
+                lb = np.array([-np.inf if v is None else v for v in self.optimization_constraints_lb[k]], dtype=float)
+                ub = np.array([np.inf if v is None else v for v in self.optimization_constraints_ub[k]], dtype=float)
+                keep.append((A, b, x, lb, ub, dpsi, solve_nonmon))
+                t = tasks[i]
+                t.dPsi, t.ldp, t.m = dpsi.data_ptr(), dpsi.shape[1], m
+                t.A, t.b, t.lb, t.ub, t.x = A.ctypes.data, b.ctypes.data, lb.ctypes.data, ub.ctypes.data, x.ctypes.data
+                t.work = work.data_ptr() + 8 * i * wsz
+                t.counter = counters.data_ptr() + 4 * 16 * i
+                t.sums_host = sums.data_ptr() + 8 * 32 * i
+            _capi.check(self._lib.ttm_optimize_separable_batch(tasks, n, self._N, float(self._Nglobal), float(self.delta),
+                                                               int(min(self.optimizer_threads, n)), self._stream(), 0))
+            for i, k in enumerate(batch):
+                class _Result:
+                    pass
+                out = _Result()
+                r = tasks[i].result
+                out.x, out.fun, out.nit, out.nfev, out.status = keep[i][2], float(r[0]), int(r[2]), int(r[3]), int(r[4])
+                out.solve_nonmon = keep[i][6]
+                results[k] = out
+        return results
+
+    def _penalty_vector(self, k, m):
+        """(kind, lambda per coefficient) of the penalty of TM:3382-3431 for the native loops: kind 0 none, 1 l1, 2 l2;
+        None when the setting is one the Python objective has to answer (it raises the reference's errors)."""
+        if self.regularization is None:
+            return 0, None
+        if type(self.regularization) != str or self.regularization.lower() not in ('l1', 'l2'):
+            return None
+        kind = 1 if self.regularization.lower() == 'l1' else 2
+        if np.isscalar(self.regularization_lambda):
+            return kind, np.full(m, float(self.regularization_lambda))
+        if type(self.regularization_lambda) == list:
+            lam = np.ascontiguousarray(self.regularization_lambda[k], dtype=float)
+            return (kind, lam) if lam.shape == (m,) else None
+        return None
+
+    def _optimize_integrated_batch(self, K):
+        """TM:2746-2845 for integrated-rectifier maps: the BFGS loops of the components of K side by side
+        (ttm_optimize_integrated_batch); {k: result} or None when the batched native path does not apply."""
+        if not self.native_optimizer or len(K) < 2 or self.optimizer_threads < 2 or self._dist() is not None:
+            return None
+        torch = _torch()
+        n = len(K)
+        sizes = [len(self.coeffs_nonmon[k]) + len(self.coeffs_mon[k]) for k in K]
+        pens = [self._penalty_vector(k, m) for k, m in zip(K, sizes)]
+        if any(m < 1 or m > 64 for m in sizes) or any(p is None for p in pens):
+            return None
+        wsz = int(self._lib.ttm_reduce_work_size(1 + max(sizes)))
+        work = self._empty(n * wsz)
+        counters = self._zeros(n * 16, dtype=torch.int32)
+        sums = torch.zeros(n * 128, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+        tasks = (_capi.ttm_int_task * n)()
+        xs = []
+        for i, (k, m, (kind, lam)) in enumerate(zip(K, sizes, pens)):
+            x = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float), np.asarray(self.coeffs_mon[k], dtype=float)))
+            xs.append((x, lam))
+            t = tasks[i]
+            t.k, t.m, t.regularization = int(k), m, kind
+            t.lam = lam.ctypes.data if lam is not None else None
+            t.x = x.ctypes.data
+            t.work = work.data_ptr() + 8 * i * wsz
+            t.counter = counters.data_ptr() + 4 * 16 * i
+            t.sums_host = sums.data_ptr() + 8 * 128 * i
+        _capi.check(self._lib.ttm_optimize_integrated_batch(self._pp, tasks, n, self._ptr(self._Xs), self._Xs.shape[1], self._N,
+                                                            float(self._Nglobal), int(min(self.optimizer_threads, n)),
+                                                            self._stream(), 0))
+        self._obj_cache = None
+        results = {}
+        for i, k in enumerate(K):
+            class _Result:
+                pass
+            out = _Result()
+            r = tasks[i].result
+            out.x, out.fun, out.nit, out.nfev, out.status = xs[i][0], float(r[0]), int(r[2]), int(r[3]), int(r[4])
+            results[k] = out
+        return results
+
     def _optimize_integrated_native(self, k, x0, div):
         """TM:3252-3257 for one component without leaving the library (ttm_optimize_integrated: SciPy's BFGS restated
         over ttm_objective_host); None when the native loop does not apply (more than 64 coefficients, a penalty it
@@ -1362,19 +1497,10 @@ class transport_map():
         m = len(x0)
         if not self.native_optimizer or m > 64:
             return None
-        reg, lam = 0, None
-        if self.regularization is not None:
-            if type(self.regularization) != str or self.regularization.lower() not in ('l1', 'l2'):
-                return None                                            # (the Python objective raises the reference's error)
-            reg = 1 if self.regularization.lower() == 'l1' else 2
-            if np.isscalar(self.regularization_lambda):
-                lam = np.full(m, float(self.regularization_lambda))
-            elif type(self.regularization_lambda) == list:
-                lam = np.ascontiguousarray(self.regularization_lambda[k], dtype=float)
-                if lam.shape != (m,):
-                    return None
-            else:
-                return None
+        pen = self._penalty_vector(k, m)
+        if pen is None:
+            return None
+        reg, lam = pen
         handle = None
         if self._dist() is not None:
             handle = comm.get(self._lib, force=self._dev.type != 'cuda')
@@ -1417,8 +1543,23 @@ class transport_map():
         # strided subset (most expensive, i.e. last, components first as TM:2814-2822) on its replica of X
         K_local = list(reversed(K))[tdist.get_rank()::tdist.get_world_size()] if part else K
         J_local = 0.0
+        if self.monotonicity == "separable monotonicity":
+            batched = self._optimize_separable_batch(K_local)
+        elif self.monotonicity == "integrated rectifier":
+            batched = self._optimize_integrated_batch(K_local)
+        else:
+            batched = None
         for k in K_local:
-            if self.monotonicity == "integrated rectifier":
+            if batched is not None and self.monotonicity == "separable monotonicity":
+                opt = batched[k]
+                self.coeffs_mon[k] = copy.deepcopy(opt.x)
+                self.coeffs_nonmon[k] = opt.solve_nonmon(opt.x)
+            elif batched is not None:
+                opt = batched[k]
+                div = len(self.coeffs_nonmon[k])
+                self.coeffs_nonmon[k] = copy.deepcopy(opt.x[:div])
+                self.coeffs_mon[k] = copy.deepcopy(opt.x[div:])
+            elif self.monotonicity == "integrated rectifier":
                 div = len(self.coeffs_nonmon[k])
                 x0 = np.concatenate((np.asarray(self.coeffs_nonmon[k], dtype=float),
                                      np.asarray(self.coeffs_mon[k], dtype=float)))
