@@ -10,6 +10,8 @@ from scipy.optimize import minimize, rosen, rosen_der
 
 from triangular_transport_toolbox_amd import _capi
 
+pytestmark = pytest.mark.filterwarnings('ignore')          # (SciPy's own RuntimeWarnings on the NaN / unbounded problems)
+
 
 def native_bfgs(lib, fun, x0, maxiter=0):
     n = len(x0)
@@ -132,10 +134,7 @@ def test_fallback_search_follows_scipy_point_for_point(name):
     from tests.hostemu import emu
     fun, x0 = NONSMOOTH[name]
     x0 = np.array(x0)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        ref, pts = scipy_bfgs(fun, x0)
+    ref, pts = scipy_bfgs(fun, x0)
     x, info, calls = native_bfgs(emu.lib(), fun, x0)
     assert ref.status == 2 and info['status'] == 2 and info['nit'] == ref.nit
     # the More-Thuente search gives up on an interval of relative width 1e-14: whether that happens at trial j or j + 1
