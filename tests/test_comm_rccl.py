@@ -108,6 +108,7 @@ def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
         line = [ln for ln in o.splitlines() if ln.startswith('RESULT ')]
         assert line, o[-2000:]
         res.append(json.loads(line[0][7:]))
+    print('communicator created:', res[0]['handle'], '|', res[0]['warned'])
     assert res[0]['handle'] == res[1]['handle']                # the ranks agree
     assert res[0]['after'] == res[1]['after'] == 3.0            # and are still in step afterwards
     if res[0]['handle']:

@@ -89,7 +89,13 @@ int run_batch(int ntasks, int nthreads, void* stream, Run run) {
             for (int t; (t = next.fetch_add(1)) < ntasks;) rcs[t] = on_device ? run(t, st) : (int)TTM_E_HIP;
         };
         std::vector<std::thread> threads;
-        for (int w = 1; w < nthreads; ++w) threads.emplace_back(worker, w);
+        for (int w = 1; w < nthreads; ++w) {
+            try {
+                threads.emplace_back(worker, w);
+            } catch (...) {                                              // no more threads to be had: the ones running share the tasks
+                break;
+            }
+        }
         worker(0);
         for (auto& th : threads) th.join();
     }
