@@ -238,7 +238,8 @@ typedef struct ttm_program {
     const int32_t* h_fold_off;  /* length D+1: prefix offsets of folded coefficients */
     const int32_t* h_ftab_off;  /* length D+1: prefix offsets into ftab              */
     const int32_t* h_nb1;       /* length D: nB+1 (distinct x_k functions + 1)      */
-    const int32_t* h_complex;   /* length D: 1 = component needs the generic interpreter (cross / generic terms) */
+    const int32_t* h_complex;   /* length D: bit 0 = component needs the generic interpreter (cross / generic terms),
+                                   bit 1 = integrated component with a dense B set (orders 1..P, no special terms)   */
     /* device copy of the five prefix tables, 5 x (D+1) int32:
        [comp_off | dpar_off | coef_off | fold_off | ftab_off]                        */
     const int32_t* d_offsets;

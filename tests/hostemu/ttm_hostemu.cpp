@@ -75,7 +75,7 @@ void comp_of(const ttm_program* p, int k, const double* coef_k, HostComp& h, con
 bool all_fast(const ttm_program* p, int ka, int kb) {
     if (getenv("TTM_NO_PLAN")) return false;
     for (int k = ka; k < kb; ++k)
-        if (p->h_complex[k]) return false;
+        if (p->h_complex[k] & 1) return false;
     return true;
 }
 
@@ -735,9 +735,8 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
             const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
             const double off = nonmon_sum<double>(c, g, x);
-            mon_weights<double>(c, g, x, w);
             int it = 0;
-            const double r = sample_bisect<-1>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, cap ? cap[k - k0] : -1, it);
+            const double r = sample_root<-1, false>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it);
             X[(int64_t)c.kc * ldx + n] = r;
             x.put(c.kc, r);
             if (it > iters[k - k0]) iters[k - k0] = it;
@@ -759,9 +758,8 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
             const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
             const double off = nonmon_sum<double>(c, g, x);
-            mon_weights<double>(c, g, x, w);
             int it = 0;
-            const double r = sample_newton<-1>(c, g, off, Z[(int64_t)(k - k0) * ldz + n], w, it);
+            const double r = sample_root<-1, true>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], -1, it);
             X[(int64_t)c.kc * ldx + n] = r;
             x.put(c.kc, r);
             if (it > iters[k - k0]) iters[k - k0] = it;

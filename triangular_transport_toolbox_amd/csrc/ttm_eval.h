@@ -526,6 +526,111 @@ TTM_HD R integrate_rect(const Comp& c, const Prog& p, const R& xk, const W& w) {
     return res;
 }
 
+// ---------------------------------------------------------------------------
+// Dense B set: the x_k-univariate functions of the component are the Hermite-function orders 1..Ph and the plain
+// polynomial orders 1..Pp, no special terms - what an integrated-rectifier component of a polynomial map looks like.
+// g(t) = w0 + E(t) sum_n wh_n P_n(t) + sum_n wp_n P_n(t) then needs no term table at all: the quadrature loop of
+// for_each_B spends more scalar instructions (order tests, parameter loads, the family switch per order) than vector
+// ones - the scalar unit, one per CU, was the busiest pipe of the integrated kernels (2.6e9 SALU against 2.0e9 VALU
+// wave-instructions per bisection launch at C2a).  The weights come from per-sample slots with the normalisation
+// constants a_n folded in (dense_weights); the family and the rectifier are fixed outside the node loop.
+// ---------------------------------------------------------------------------
+#ifndef TTM_DENSE_NODES
+#define TTM_DENSE_NODES 5
+#endif
+TTM_HD bool dense_B(const Comp& c) { return c.nB_st == 0 && c.nB_hf == c.maxP_hf && c.nB_poly == c.maxP_poly; }
+
+// weights of the dense B set in the sample's slots: [a_n w_n (Hermite functions) | w_n (polynomials) | w_none]
+template <class R, class XA, class Slots>
+TTM_HD void dense_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
+    mon_weights<R>(c, p, x, w);
+    for (int b = 0; b < c.nB_hf; ++b) w.set(b, c.dpar[TTM_UNI(c.bfuns[4 * b + 2])] * w.get(b));
+}
+
+template <int FAM, bool DER, class R, class W>
+TTM_HD void g_eval_dense(int fam, int Ph, int Pp, const R& t, const W& w, R& g, R& dg) {
+    const int F = (FAM >= 0) ? FAM : fam;
+    const int P = Ph > Pp ? Ph : Pp;
+    R ah(0.0), dah(0.0), ap(w.get(Ph + Pp)), dap(0.0);
+    R pm(1.0), dpm(0.0), pn, dp;
+    poly_first(F, t, pn, dp);
+    for (int n = 1; n <= P; ++n) {
+        if (n <= Ph) {
+            const auto wn = w.get(n - 1);
+            ah = vfma(wn, pn, ah);
+            if (DER) dah = vfma(wn, dp, dah);
+        }
+        if (n <= Pp) {
+            const auto wn = w.get(Ph + n - 1);
+            ap = vfma(wn, pn, ap);
+            if (DER) dap = vfma(wn, dp, dap);
+        }
+        if (n < P) poly_next<DER>(F, n, t, pm, pn, dpm, dp);
+    }
+    g = ap; dg = dap;
+    if (Ph > 0) {
+        const R E = fast_exp(-0.25 * (t * t));
+        g = vfma(ah, E, ap);
+        if (DER) dg = vfma(E, dah - 0.5 * (t * ah), dap);    // d/dt [P e^{-t^2/4}] = e^{-t^2/4} (P' - t P / 2)
+    }
+}
+
+// int_0^{xk} (r(g(t)) + delta) dt, node order and grouping of TM:4238-4258
+template <int FAM, int RECT, class R, class W>
+TTM_HD R integrate_rect_dense(const Comp& c, const Prog& p, const R& xk, const W& w) {
+    const int rect = (RECT >= 0) ? RECT : p.rect;
+    const R half = xk * 0.5;
+    R res(0.0);
+    int q = 0;
+    if constexpr (lanes_of<R>::value == 1) {
+        // one sample per lane (root searches, objective): TTM_DENSE_NODES quadrature nodes are evaluated together as a
+        // short vector - the scalar instructions of a node (loop control, the 64-bit constants of exp / log, which the
+        // compiler re-materialises with two s_mov each per use) are then paid once per group; terms are still added in
+        // node order
+        typedef VecD<TTM_DENSE_NODES> V;
+        for (; q + TTM_DENSE_NODES <= p.Q; q += TTM_DENSE_NODES) {
+            V t;
+#pragma unroll
+            for (int e = 0; e < TTM_DENSE_NODES; ++e) t[e] = half * p.qx[q + e] + half;
+            V g, dg;
+            g_eval_dense<FAM, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+            const V r = rect_eval(rect, g);
+#pragma unroll
+            for (int e = 0; e < TTM_DENSE_NODES; ++e) {
+                const R term = half * (p.qw[q + e] * (r[e] + p.delta));
+                res = (q + e == 0) ? term : res + term;
+            }
+        }
+    }
+    for (; q < p.Q; ++q) {
+        const R t = half * p.qx[q] + half;
+        R g, dg;
+        g_eval_dense<FAM, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+        const R fr = rect_eval(rect, g) + p.delta;
+        const R term = half * (p.qw[q] * fr);
+        res = (q == 0) ? term : res + term;
+    }
+    return res;
+}
+
+// mon_eval for a dense B set (w: dense_weights)
+template <int MONO, bool DER, class R, class W>
+TTM_HD void mon_eval_dense(const Comp& c, const Prog& p, const R& t, const W& w, R& m, R& dm) {
+    const int mono = (MONO >= 0) ? MONO : p.mono;
+    if (mono == TTM_MONO_SEPARABLE) {
+        g_eval_dense<-1, DER>(p.family, c.maxP_hf, c.maxP_poly, t, w, m, dm);
+        return;
+    }
+    const bool common = p.family == TTM_FAM_HERMITE_E && p.rect == TTM_RECT_SOFTPLUS;      // the reference's defaults
+    m = common ? integrate_rect_dense<TTM_FAM_HERMITE_E, TTM_RECT_SOFTPLUS>(c, p, t, w) : integrate_rect_dense<-1, -1>(c, p, t, w);
+    dm = R(0.0);
+    if (DER) {
+        R g, dg;
+        g_eval_dense<-1, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+        dm = rect_eval(p.rect, g) + p.delta;
+    }
+}
+
 // monotone part of S_k at x_k = t given the sample's weights: value and dS/dx_k
 // MONO >= 0 fixes the monotonicity mode at compile time (kernels), MONO < 0 reads it from the program
 template <int MONO, bool DER, class R, class W>
@@ -544,6 +649,17 @@ TTM_HD void mon_eval(const Comp& c, const Prog& p, const R& t, const W& w, R& m,
     }
 }
 
+// weights of a dense B set as a type of their own: the root searches take any weight source and evaluate through
+// mon_eval - with DenseSet<W> that is the table-free evaluator
+template <class W>
+struct DenseSet {
+    const W& w;
+};
+template <int MONO, bool DER, class R, class W>
+TTM_HD void mon_eval(const Comp& c, const Prog& p, const R& t, const DenseSet<W>& d, R& m, R& dm) {
+    mon_eval_dense<MONO, DER>(c, p, t, d.w, m, dm);
+}
+
 // ---------------------------------------------------------------------------
 // per-sample bodies
 // ---------------------------------------------------------------------------
@@ -553,7 +669,12 @@ template <int MONO, bool DER, class R, class XA, class Slots>
 TTM_HD void sample_forward(const Comp& c, const Prog& p, VarCache<XA, R>& x, Slots& w, bool want_value, R& S, R& dS) {
     R m, dm;
     const R xk = x.get(c.kc);
-    if (c.n_mnt == 0) {
+    const int mono = (MONO >= 0) ? MONO : p.mono;
+    if (mono == TTM_MONO_INTEGRATED && dense_B(c)) {
+        dense_weights<R>(c, p, x, w);
+        const DenseSet<Slots> dw{w};
+        mon_eval<MONO, DER>(c, p, xk, dw, m, dm);
+    } else if (c.n_mnt == 0) {
         const UniformW uw{c.fold + c.off_wb};
         mon_eval<MONO, DER>(c, p, xk, uw, m, dm);
     } else {
@@ -592,8 +713,113 @@ TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, XA& x, Out&& o
 // Objective + gradient contribution of one sample, integrated rectifier
 // (TM:3343-3376, 3475-3569).  acc layout: [0] J, [1..n_nm] d/dc_nonmon, then d/dc_mon.
 // scratch slots: w (nB+1) | Bv (nB+1) | I (nB+1)
+// The same for a component with a dense B set: per group of TTM_DENSE_NODES quadrature nodes one pass of the
+// recurrence for g, one for the integrals of cq B_b (the polynomial values are cheaper to recompute than to keep);
+// sums over the nodes of a group are taken in node order.
+template <int FAM, int RECT, class XA, class Slots, class Acc>
+TTM_HD void sample_objective_int_dense(const Comp& c, const Prog& p, VarCache<XA, double>& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
+    typedef VecD<TTM_DENSE_NODES> V;
+    const int F = (FAM >= 0) ? FAM : p.family;
+    const int rect = (RECT >= 0) ? RECT : p.rect;
+    const int Ph = c.maxP_hf, Pp = c.maxP_poly, P = Ph > Pp ? Ph : Pp;
+    dense_weights<double>(c, p, x, w);
+    const double xk = x.get(c.kc);
+    const double half = xk * 0.5;
+    double mono = 0.0;
+    for (int b = 0; b <= c.nB; ++b) I.set(b, 0.0);
+    auto nodes = [&](auto tag, int q) {
+        typedef decltype(tag) T;                                // V or double
+        constexpr int L = lanes_of<T>::value;
+        T t;
+#pragma unroll
+        for (int e = 0; e < L; ++e) set_elem(t, e, half * p.qx[q + e] + half);
+        T E(1.0);
+        if (Ph > 0) E = fast_exp(-0.25 * (t * t));
+        T ah(0.0), ap(w.get(Ph + Pp));
+        {
+            T pm(1.0), dpm(0.0), pn, dp;
+            poly_first(F, t, pn, dp);
+            for (int n = 1; n <= P; ++n) {
+                if (n <= Ph) ah = vfma(w.get(n - 1), pn, ah);
+                if (n <= Pp) ap = vfma(w.get(Ph + n - 1), pn, ap);
+                if (n < P) poly_next<false>(F, n, t, pm, pn, dpm, dp);
+            }
+        }
+        const T g = vfma(ah, E, ap);
+        T r, dr, logr;
+        rect_all(rect, 0.0, g, r, dr, logr);                    // logr unused here
+        T cq;
+        double csum = 0.0;
+#pragma unroll
+        for (int e = 0; e < L; ++e) {
+            const double term = half * (p.qw[q + e] * (elem(r, e) + p.delta));
+            mono = (q + e == 0) ? term : mono + term;
+            const double ce = (half * p.qw[q + e]) * elem(dr, e);      // lim_dif*0.5*W_q * r'(g_q)   (TM:4264-4278, 5127-5133)
+            set_elem(cq, e, ce);
+            csum += ce;
+        }
+        const T cqE = cq * E;
+        {
+            T pm(1.0), dpm(0.0), pn, dp;
+            poly_first(F, t, pn, dp);
+            for (int n = 1; n <= P; ++n) {
+                if (n <= Ph) {
+                    const T v = cqE * pn;
+                    double sh = 0.0;
+#pragma unroll
+                    for (int e = 0; e < L; ++e) sh += elem(v, e);
+                    I.set(n - 1, I.get(n - 1) + sh);
+                }
+                if (n <= Pp) {
+                    const T v = cq * pn;
+                    double sp = 0.0;
+#pragma unroll
+                    for (int e = 0; e < L; ++e) sp += elem(v, e);
+                    I.set(Ph + n - 1, I.get(Ph + n - 1) + sp);
+                }
+                if (n < P) poly_next<false>(F, n, t, pm, pn, dpm, dp);
+            }
+        }
+        I.set(c.nB, I.get(c.nB) + csum);
+    };
+    int q = 0;
+    for (; q + TTM_DENSE_NODES <= p.Q; q += TTM_DENSE_NODES) nodes(V(0.0), q);
+    for (; q < p.Q; ++q) nodes(0.0, q);
+    // the Hermite-function integrals carry their normalisation constants from here on
+    for (int b = 0; b < c.nB_hf; ++b) I.set(b, c.dpar[TTM_UNI(c.bfuns[4 * b + 2])] * I.get(b));
+    const double S = nonmon_sum<double>(c, p, x) + mono;
+    // values at x_k for the log term
+    double g, dg;
+    g_eval_dense<FAM, false>(p.family, Ph, Pp, xk, w, g, dg);
+    for_each_B<false>(c, p, xk, [&](int b, double v, double) { Bv.set(b, v); });
+    Bv.set(c.nB, 1.0);
+    double r, dr, logr;
+    rect_all(rect, p.delta, g, r, dr, logr);
+    acc.add(0, 0.5 * S * S - logr);
+    for (int i = 0; i < c.n_nm; ++i) {
+        cint_p T = c.nm_terms + 4 * i;
+        acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
+    }
+    const double rinv = dr * fast_rcp(r + p.delta);
+    for (int i = 0; i < c.n_mon; ++i) {
+        cint_p T = c.mon_terms + 4 * i;
+        const int nf = TTM_UNI(T[1]);
+        int b = TTM_UNI(T[2]);
+        if (b < 0) b = c.nB;
+        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
+        acc.add(1 + c.n_nm + TTM_UNI(T[3]), a * (S * I.get(b) - rinv * Bv.get(b)));
+    }
+}
+
 template <class XA, class Slots, class Acc>
 TTM_HD void sample_objective_int(const Comp& c, const Prog& p, VarCache<XA, double>& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
+    if (dense_B(c)) {
+        if (p.family == TTM_FAM_HERMITE_E && p.rect == TTM_RECT_SOFTPLUS)
+            sample_objective_int_dense<TTM_FAM_HERMITE_E, TTM_RECT_SOFTPLUS>(c, p, x, w, Bv, I, acc);
+        else
+            sample_objective_int_dense<-1, -1>(c, p, x, w, Bv, I, acc);
+        return;
+    }
     mon_weights<double>(c, p, x, w);
     const double xk = x.get(c.kc);
     const double half = xk * 0.5;
@@ -1013,6 +1239,24 @@ TTM_HD double sample_newton(const Comp& c, const Prog& p, double off, double zk,
         x = xn;
     }
     return last;
+}
+
+// root search of one sample for one component with the weight source the component calls for (kernels and the host
+// test double share this dispatch)
+template <int MONO, bool NEWTON, class XA, class Slots>
+TTM_HD double sample_root(const Comp& c, const Prog& p, VarCache<XA, double>& x, Slots& w, double off, double zk, int cap, int& it) {
+    const int mono = (MONO >= 0) ? MONO : p.mono;
+    if (mono == TTM_MONO_INTEGRATED && dense_B(c)) {
+        dense_weights<double>(c, p, x, w);
+        const DenseSet<Slots> dw{w};
+        return NEWTON ? sample_newton<MONO>(c, p, off, zk, dw, it) : sample_bisect<MONO>(c, p, off, zk, dw, cap, it);
+    }
+    if (c.n_mnt == 0) {
+        const UniformW uw{c.fold + c.off_wb};
+        return NEWTON ? sample_newton<MONO>(c, p, off, zk, uw, it) : sample_bisect<MONO>(c, p, off, zk, uw, cap, it);
+    }
+    mon_weights<double>(c, p, x, w);
+    return NEWTON ? sample_newton<MONO>(c, p, off, zk, w, it) : sample_bisect<MONO>(c, p, off, zk, w, cap, it);
 }
 
 // interp1d lookup (TM:4062-4082): xs non-decreasing table of map outputs, ys the abscissae

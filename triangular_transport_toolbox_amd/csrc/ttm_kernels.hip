@@ -1809,15 +1809,8 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k
             if (active) {
                 const double off = nonmon_sum<double>(c, g, x);
                 const int capk = cap ? cap[k - k0] : -1;
-                double r;
                 const double zk = Z[(int64_t)(k - k0) * ldz + n];
-                if (c.n_mnt == 0) {
-                    const UniformW uw{c.fold + c.off_wb};
-                    r = NEWTON ? sample_newton<MONO>(c, g, off, zk, uw, it) : sample_bisect<MONO>(c, g, off, zk, uw, capk, it);
-                } else {
-                    mon_weights<double>(c, g, x, w);
-                    r = NEWTON ? sample_newton<MONO>(c, g, off, zk, w, it) : sample_bisect<MONO>(c, g, off, zk, w, capk, it);
-                }
+                const double r = sample_root<MONO, NEWTON>(c, g, x, w, off, zk, capk, it);
                 X[(int64_t)c.kc * ldx + n] = r;
                 x.put(c.kc, r);
             }
@@ -2190,7 +2183,7 @@ static int validate(const ttm_program* p, int k0, int k1) {
 static bool all_fast(const ttm_program* p, int ka, int kb) {
     if (tuning().no_plan) return false;                                   // (option: generic kernels)
     for (int k = ka; k < kb; ++k)
-        if (p->h_complex[k]) return false;
+        if (p->h_complex[k] & 1) return false;
     return true;
 }
 
@@ -2390,12 +2383,19 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const int nsl = map_slots(p, k0, k1);
     // several samples per thread: the scalar (table-interpreter) work is paid once per NS*64 samples
     int NS = N >= 4 * 256 * 256 ? 2 : 1;
+    const bool sep = p->monotonicity == TTM_MONO_SEPARABLE;
+    if (!sep) {
+        // integrated components with dense B sets evaluate their quadrature nodes in short vectors when a lane holds ONE
+        // sample (ttm_eval.h, integrate_rect_dense): that amortises the scalar work better than two samples per lane
+        bool dense = true;
+        for (int k = k0; k < k1; ++k) dense = dense && (p->h_complex[k] & 2);
+        if (dense) NS = 1;
+    }
     if (tuning().forward_ns > 0) NS = tuning().forward_ns;
     if (NS != 1 && NS != 2 && NS != 4) NS = 1;
     while (NS > 1 && !pick_block(nsl, 0, NS)) NS >>= 1;
     const int bd = pick_block(nsl, 0, NS);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_forward: %s%lld scratch slots per sample do not fit the LDS budget", "", nsl);
-    const bool sep = p->monotonicity == TTM_MONO_SEPARABLE;
     if (sep && u_on(p) && all_fast(p, k0, k1) && N < ((int64_t)1 << 29)) {
         // U-form: monomial groups + special-term splines staged per component in LDS
         int tab_cap = 0;

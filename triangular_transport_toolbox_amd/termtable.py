@@ -587,8 +587,11 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         comp_off.append(len(itab))
         dpar_off.append(len(dpar))
         coef_off.append(coef_off[-1] + len(nm_terms) + len(mon_terms))
-        nslots.append(len(bfuns) + 1 if len(mnt_idx) else 0)
-        complex_all.append(complex_comp)
+        # per-sample weight slots: components with monotone cross terms, and integrated components whose B functions are
+        # the dense order sets 1..P (ttm_eval.h "dense B set": their weights are copied there with the constants folded in)
+        dense_b = (not separable and len(b_st) == 0 and len(b_hf) == hdr[HDR_MAXP_HF] and len(b_poly) == hdr[HDR_MAXP_POLY])
+        nslots.append(len(bfuns) + 1 if (len(mnt_idx) or dense_b) else 0)
+        complex_all.append(int(complex_comp) | (2 if dense_b else 0))
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
         n_mon_all.append(len(mon_terms))
