@@ -547,11 +547,11 @@ TTM_HD void dense_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
     for (int b = 0; b < c.nB_hf; ++b) w.set(b, c.dpar[TTM_UNI(c.bfuns[4 * b + 2])] * w.get(b));
 }
 
-template <int FAM, bool DER, class R, class W>
-TTM_HD void g_eval_dense(int fam, int Ph, int Pp, const R& t, const W& w, R& g, R& dg) {
+template <int FAM, bool DER, class R, class W, class W0>
+TTM_HD void g_eval_dense(int fam, int Ph, int Pp, const R& t, const W& w, const W0& w0, R& g, R& dg) {
     const int F = (FAM >= 0) ? FAM : fam;
     const int P = Ph > Pp ? Ph : Pp;
-    R ah(0.0), dah(0.0), ap(w.get(Ph + Pp)), dap(0.0);
+    R ah(0.0), dah(0.0), ap(w0), dap(0.0);
     R pm(1.0), dpm(0.0), pn, dp;
     poly_first(F, t, pn, dp);
     for (int n = 1; n <= P; ++n) {
@@ -576,8 +576,8 @@ TTM_HD void g_eval_dense(int fam, int Ph, int Pp, const R& t, const W& w, R& g, 
 }
 
 // int_0^{xk} (r(g(t)) + delta) dt, node order and grouping of TM:4238-4258
-template <int FAM, int RECT, class R, class W>
-TTM_HD R integrate_rect_dense(const Comp& c, const Prog& p, const R& xk, const W& w) {
+template <int FAM, int RECT, class R, class W, class W0>
+TTM_HD R integrate_rect_dense(const Prog& p, int Ph, int Pp, const R& xk, const W& w, const W0& w0) {
     const int rect = (RECT >= 0) ? RECT : p.rect;
     const R half = xk * 0.5;
     R res(0.0);
@@ -593,7 +593,7 @@ TTM_HD R integrate_rect_dense(const Comp& c, const Prog& p, const R& xk, const W
 #pragma unroll
             for (int e = 0; e < TTM_DENSE_NODES; ++e) t[e] = half * p.qx[q + e] + half;
             V g, dg;
-            g_eval_dense<FAM, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+            g_eval_dense<FAM, false>(p.family, Ph, Pp, t, w, w0, g, dg);
             const V r = rect_eval(rect, g);
 #pragma unroll
             for (int e = 0; e < TTM_DENSE_NODES; ++e) {
@@ -605,7 +605,7 @@ TTM_HD R integrate_rect_dense(const Comp& c, const Prog& p, const R& xk, const W
     for (; q < p.Q; ++q) {
         const R t = half * p.qx[q] + half;
         R g, dg;
-        g_eval_dense<FAM, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+        g_eval_dense<FAM, false>(p.family, Ph, Pp, t, w, w0, g, dg);
         const R fr = rect_eval(rect, g) + p.delta;
         const R term = half * (p.qw[q] * fr);
         res = (q == 0) ? term : res + term;
@@ -617,16 +617,19 @@ TTM_HD R integrate_rect_dense(const Comp& c, const Prog& p, const R& xk, const W
 template <int MONO, bool DER, class R, class W>
 TTM_HD void mon_eval_dense(const Comp& c, const Prog& p, const R& t, const W& w, R& m, R& dm) {
     const int mono = (MONO >= 0) ? MONO : p.mono;
+    const int Ph = c.maxP_hf, Pp = c.maxP_poly;
+    const auto w0 = w.get(Ph + Pp);
     if (mono == TTM_MONO_SEPARABLE) {
-        g_eval_dense<-1, DER>(p.family, c.maxP_hf, c.maxP_poly, t, w, m, dm);
+        g_eval_dense<-1, DER>(p.family, Ph, Pp, t, w, w0, m, dm);
         return;
     }
     const bool common = p.family == TTM_FAM_HERMITE_E && p.rect == TTM_RECT_SOFTPLUS;      // the reference's defaults
-    m = common ? integrate_rect_dense<TTM_FAM_HERMITE_E, TTM_RECT_SOFTPLUS>(c, p, t, w) : integrate_rect_dense<-1, -1>(c, p, t, w);
+    m = common ? integrate_rect_dense<TTM_FAM_HERMITE_E, TTM_RECT_SOFTPLUS>(p, Ph, Pp, t, w, w0)
+               : integrate_rect_dense<-1, -1>(p, Ph, Pp, t, w, w0);
     dm = R(0.0);
     if (DER) {
         R g, dg;
-        g_eval_dense<-1, false>(p.family, c.maxP_hf, c.maxP_poly, t, w, g, dg);
+        g_eval_dense<-1, false>(p.family, Ph, Pp, t, w, w0, g, dg);
         dm = rect_eval(p.rect, g) + p.delta;
     }
 }
@@ -790,7 +793,7 @@ TTM_HD void sample_objective_int_dense(const Comp& c, const Prog& p, VarCache<XA
     const double S = nonmon_sum<double>(c, p, x) + mono;
     // values at x_k for the log term
     double g, dg;
-    g_eval_dense<FAM, false>(p.family, Ph, Pp, xk, w, g, dg);
+    g_eval_dense<FAM, false>(p.family, Ph, Pp, xk, w, w.get(Ph + Pp), g, dg);
     for_each_B<false>(c, p, xk, [&](int b, double v, double) { Bv.set(b, v); });
     Bv.set(c.nB, 1.0);
     double r, dr, logr;
@@ -1108,11 +1111,29 @@ TTM_HD void g_eval_fast(const FastComp& f, const Prog& p, const R& t, R& g, R& d
     g = acc; dg = dacc;
 }
 
+struct StreamW {             // uniform weights of a fast-path component: wHF | wPoly with the constants folded in
+    cdbl_p s;
+    TTM_HD double get(int i) const { return s[i]; }
+};
+
 template <int MONO, int FAM, bool DER, class R>
 TTM_HD void mon_eval_fast(const FastComp& f, const Prog& p, const R& t, R& m, R& dm) {
     const int mono = (MONO >= 0) ? MONO : p.mono;
     if (mono == TTM_MONO_SEPARABLE) {
         g_eval_fast<FAM, DER>(f, p, t, m, dm);
+    } else if (f.n_st == 0 && lanes_of<R>::value == 1) {
+        // dense B set with uniform weights, one sample per lane: quadrature nodes in short vectors (integrate_rect_dense)
+        const StreamW sw{f.stream};
+        const double w0 = f.st8[0];
+        const bool common = ((FAM >= 0) ? FAM : p.family) == TTM_FAM_HERMITE_E && p.rect == TTM_RECT_SOFTPLUS;
+        m = common ? integrate_rect_dense<TTM_FAM_HERMITE_E, TTM_RECT_SOFTPLUS>(p, f.maxP_hf, f.maxP_poly, t, sw, w0)
+                   : integrate_rect_dense<FAM, -1>(p, f.maxP_hf, f.maxP_poly, t, sw, w0);
+        dm = R(0.0);
+        if (DER) {
+            R g, dg;
+            g_eval_fast<FAM, false>(f, p, t, g, dg);
+            dm = rect_eval(p.rect, g) + p.delta;
+        }
     } else {
         const R half = t * 0.5;
         R res(0.0);
