@@ -431,6 +431,15 @@ int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, 
  * counter / out as ttm_objective_host.                                                                             */
 int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
                              double delta, double* work, uint32_t* counter, double* out, void* stream);
+/* The two host-loop reductions with a completion mark: the finishing workgroup writes *flag = mark (flag: pinned host
+ * memory, nullable) after its results have reached memory, so a host loop polls ONE location per evaluation and needs
+ * neither hipStreamSynchronize nor a separate ttm_signal launch (ttm_optimize_separable / _integrated do that).      */
+int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa,
+                              int64_t ldx, int64_t N, double* work, uint32_t* counter, double* out, double* flag,
+                              double mark, void* stream);
+int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
+                                    double delta, double* work, uint32_t* counter, double* out, double* flag,
+                                    double mark, void* stream);
 
 /* ---- K8: Gram matrix of [Psi_nonmon | Psi_mon] -------------------------------------
  * replaces the N x m passes of TM:2966-2975 (QR projection) and TM:3031-3050 (L2 normal

@@ -569,6 +569,20 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
     return 0;
 }
 
+// marked variants: the reduction is done when the call returns
+int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_coef_k, const double* X, int64_t ldx, int64_t N,
+                              double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
+    const int rc = ttm_objective_host(p, k, h_coef_k, X, ldx, N, work, counter, out, stream);
+    if (!rc && flag) *flag = mark;
+    return rc;
+}
+int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
+                                    double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
+    const int rc = ttm_objective_sep_cached(dPsi, ldp, N, m, h_coef_mon, delta, work, counter, out, stream);
+    if (!rc && flag) *flag = mark;
+    return rc;
+}
+
 int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*) {
     const Prog g = make_prog(p);
     HostComp h;

@@ -16,7 +16,7 @@ for wl in (sys.argv[1:] or ['C5']):
         for k in range(tm.D):
             tm.coeffs_mon[k] = tm.coeffs_mon[k] * 0 + tm.coeffs_init
             tm.coeffs_nonmon[k] = tm.coeffs_nonmon[k] * 0 + tm.coeffs_init
-    for threads in (1, 2, 4, 8, 12, 16, 8):
+    for threads in [int(t) for t in os.environ.get('TTM_OPT_THREADS', '1,2,4,8,12,16,8').split(',')]:
         tm.optimizer_threads = threads
         best = 1e9
         for rep in range(3):

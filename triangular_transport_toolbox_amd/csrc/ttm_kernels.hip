@@ -1856,12 +1856,35 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* counter) {
     return is_last != 0;
 }
 
+// Results of a finishing workgroup and the completion mark behind them (all threads of the workgroup call; fin: the n
+// results in LDS).  ONE wave stores the results, waits until every one of those stores has been acknowledged
+// (s_waitcnt vmcnt(0): the results span several cache lines, which travel through different L2 channels and would
+// otherwise be free to overtake each other and the mark) and only then stores the mark.  The destination is
+// fine-grained host memory and results and mark are written through at system scope, so the acknowledged stores are on
+// their way in order and a host that sees the mark sees the results.  (A workgroup-scope release alone does not wait for global stores;
+// device- or system-scope fences in every wave - an L2 write-back each - made this launch take 8.5 us.)
+__device__ __forceinline__ void publish(const double* fin, int n, double* out, double* flag, double mark) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // (system-scope stores: write-through.  A plain store may stay dirty in the L2 until the end of the kernel while
+        // the mark - written through - is already visible: the host then reads the results of the evaluation before)
+        for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(out + i, fin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (flag) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (compiler ordering)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+            if (threadIdx.x == 0) *(volatile double*)flag = mark;
+        }
+    }
+}
+#define TTM_FIN_MAX 72
+
 // LDS: erf table | per-thread columns [scratch (nscr) | acc (nacc)]
 __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const double* __restrict__ coef_k,
                                                    const double* __restrict__ fold_k,
                                                    const double* __restrict__ X, int64_t ldx, int64_t N,
                                                    int nscr, int nacc, double* __restrict__ partial,
-                                                   unsigned int* __restrict__ counter, double* __restrict__ out) {
+                                                   unsigned int* __restrict__ counter, double* __restrict__ out,
+                                                   double* flag, double mark) {
     double* slots;
     CacheStore<double> cst;
     const Prog g = make_prog_lds(P, cst, slots);
@@ -1893,12 +1916,15 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
         // single-launch variant: the workgroup that draws the last ticket adds the partials up, in the very order
         // k_reduce_partials uses (bit-identical sums), and writes the result - `out` may be pinned host memory
         if (last_workgroup(counter)) {
+            double* fin = slots;                  // (the per-thread columns are free: every thread is past its partial sums;
+                                                  // a static array here would sit on top of a dynamic image sized to the budget)
             for (int i = wv; i < nacc; i += nw) {
                 double v = 0.0;
                 for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
                 v = wave_sum(v);
-                if (lane == 0) out[i] = v;
+                if (lane == 0) fin[i] = v;
             }
+            publish(fin, nacc, out, flag, mark);
         }
     }
 }
@@ -1929,7 +1955,8 @@ struct SepCoef { double c[TTM_SEPC_MAXM]; };
 template <int M>
 __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __restrict__ dPsi, int64_t ldp, int64_t N,
                                                               SepCoef hc, double delta, double* __restrict__ partial,
-                                                              unsigned int* __restrict__ counter, double* __restrict__ out) {
+                                                              unsigned int* __restrict__ counter, double* __restrict__ out,
+                                                              double* flag, double mark) {
     // M is a template parameter: the M column loads of a row are issued together (a run-time `i < m` guard per load
     // made every load wait for the one before it: 77 us per launch at N = 1e6, m = 4 - 0.4 TB/s), two rows per
     // pass of the loop are independent chains
@@ -1977,17 +2004,34 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     // counter == nullptr: the finishing sum is a second launch (large grids: a device-scope fence per workgroup - an L2
     // write-back + invalidate on gfx950 - costs ~60 ns each and they serialise: 64 us for the 977 workgroups of N = 1e6)
     if (counter && last_workgroup(counter)) {
+        __shared__ double fin[M + 1];
         for (int i = wv; i < nacc; i += 4) {
             double v = 0.0;
             for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
             v = wave_sum(v);
-            if (lane == 0) out[i] = v;
+            if (lane == 0) fin[i] = v;
         }
+        publish(fin, nacc, out, flag, mark);
     }
 }
 
 // stream-ordered completion mark in (pinned host) memory: the host polls it instead of calling hipStreamSynchronize
 __global__ void k_signal(double* flag, double value) { *flag = value; }
+
+// out[i] = sum_b partial[b*nout + i] for ALL outputs in ONE workgroup (a wave per output, the summation order of
+// k_reduce_partials), then the completion mark: the finishing launch of a reduction whose host waits on the mark
+__global__ __launch_bounds__(1024) void k_reduce_partials_mark(const double* __restrict__ partial, int nblocks, int nout,
+                                                              double* __restrict__ out, double* flag, double mark) {
+    __shared__ double fin[TTM_FIN_MAX];
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int i = threadIdx.x >> 6; i < nout; i += nw) {
+        double v = 0.0;
+        for (int b = lane; b < nblocks; b += 64) v += partial[(int64_t)b * nout + i];
+        v = wave_sum(v);
+        if (lane == 0) fin[i] = v;
+    }
+    publish(fin, nout, out, flag, mark);
+}
 
 // out[i] = sum_b partial[b*nout + i], one wave per output
 __global__ __launch_bounds__(256) void k_reduce_partials(const double* __restrict__ partial, int nblocks, int nout,
@@ -2778,13 +2822,19 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     double* partial = work + TTM_OBJ_FOLD_MAX;
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, (int)k, coef_k, fold_k);
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k, coef_k,
-                       (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)nullptr, (double*)nullptr);
+                       (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)nullptr, (double*)nullptr,
+                       (double*)nullptr, 0.0);
     hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
     return check_launch("k_objective");
 }
 
 int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa, int64_t ldx, int64_t N,
                        double* work, uint32_t* counter, double* out, void* stream) {
+    return ttm_objective_host_marked(p, k, h_coef_k, Xsoa, ldx, N, work, counter, out, nullptr, 0.0, stream);
+}
+
+int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa, int64_t ldx, int64_t N,
+                              double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
     int rc = validate(p, k, k + 1);
     if (rc) return rc;
     if (!h_coef_k || !Xsoa || !work || !counter || !out || N < 1 || ldx < N) return set_err(TTM_E_ARG, "ttm_objective_host: bad arguments%s");
@@ -2814,14 +2864,23 @@ int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, 
     const bool ticket = nb <= 64;                    // (see ttm_objective_sep_cached)
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k,
                        (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial,
-                       ticket ? (unsigned int*)counter : (unsigned int*)nullptr, ticket ? out : (double*)nullptr);
-    if (!ticket)
-        hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
+                       ticket ? (unsigned int*)counter : (unsigned int*)nullptr, ticket ? out : (double*)nullptr, flag, mark);
+    if (!ticket) {
+        if (flag)
+            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (nacc < 16 ? nacc : 16)), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out, flag, mark);
+        else
+            hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
+    }
     return check_launch("k_objective");
 }
 
 int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
                              double* work, uint32_t* counter, double* out, void* stream) {
+    return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, h_coef_mon, delta, work, counter, out, nullptr, 0.0, stream);
+}
+
+int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
+                                    double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
     if (!dPsi || !h_coef_mon || !work || !counter || !out || N < 1 || ldp < N || m < 1)
         return set_err(TTM_E_ARG, "ttm_objective_sep_cached: bad arguments%s");
     if (m > TTM_SEPC_MAXM) return set_err(TTM_E_LIMIT, "ttm_objective_sep_cached: more than %s%lld monotone terms", "", TTM_SEPC_MAXM);
@@ -2829,7 +2888,7 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
     for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
     int nb = grid_for(N, 256 * 4);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
-    typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*);
+    typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*, double*, double);
     static const skern_t kerns[TTM_SEPC_MAXM] = {
         k_objective_sep_cached<1>, k_objective_sep_cached<2>, k_objective_sep_cached<3>, k_objective_sep_cached<4>,
         k_objective_sep_cached<5>, k_objective_sep_cached<6>, k_objective_sep_cached<7>, k_objective_sep_cached<8>,
@@ -2837,10 +2896,15 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
         k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
     const bool ticket = nb <= 64;                    // small grids: one launch, the last workgroup finishes
     hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta,
-                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out);
-    if (!ticket)
-        hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                           (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
+                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
+    if (!ticket) {
+        if (flag)
+            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
+                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out, flag, mark);
+        else
+            hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
+    }
     return check_launch("k_objective_sep_cached");
 }
 

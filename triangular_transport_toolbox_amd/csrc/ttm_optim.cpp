@@ -36,7 +36,9 @@ int wait_for_mark(double* flag_, long& seq, void* stream) {
     if (rc) return rc;
     for (long spins = 0; *flag != mark; ++spins) {
         if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)stream) == hipSuccess && *flag != mark) {
-            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return TTM_E_HIP;   // (mark lost: cannot happen; do not spin forever)
+            // the stream is idle and the mark is not there: the launch behind it failed - never read results that were not written
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            if (*flag != mark) return TTM_E_HIP;
             break;
         }
     }
@@ -104,6 +106,28 @@ int run_batch(int ntasks, int nthreads, void* stream, Run run) {
     return TTM_OK;
 }
 
+// launch(flag, mark) enqueues a reduction that writes *flag = mark behind its results; wait until it has
+template <class Launch>
+int objective_and_wait(double* flag_, long& seq, void* stream, Launch launch) {
+    const double mark = (double)(++seq);
+    const int rc = launch(flag_, mark);
+    if (rc) return rc;
+#ifndef TTM_HOST_ONLY
+    volatile double* flag = flag_;
+    for (long spins = 0; *flag != mark; ++spins) {
+        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)stream) == hipSuccess && *flag != mark) {
+            // the stream is idle and the mark is not there: the launch behind it failed - never read results that were not written
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            if (*flag != mark) return TTM_E_HIP;
+            break;
+        }
+    }
+#else
+    (void)stream;
+#endif
+    return TTM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -151,8 +175,15 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n log dS_n, sums[1 + i] = sum_n dPsi_{n,i} / dS_n  (TM:2990-3006), over the local samples
         double* out = c.comm ? c.sums_dev : c.sums_host;
-        c.rc = ttm_objective_sep_cached(c.dPsi, c.ldp, c.N, n, cc, c.delta, c.work, c.counter, out, c.stream);
-        if (c.rc) return c.rc;
+        if (!c.comm) {                                       // results and completion mark from the reduction itself
+            c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream, [&](double* flag, double mark) {
+                return ttm_objective_sep_cached_marked(c.dPsi, c.ldp, c.N, n, cc, c.delta, c.work, c.counter, out, flag, mark, c.stream);
+            });
+            if (c.rc) return c.rc;
+        } else {
+            c.rc = ttm_objective_sep_cached(c.dPsi, c.ldp, c.N, n, cc, c.delta, c.work, c.counter, out, c.stream);
+            if (c.rc) return c.rc;
+        }
         if (c.comm) {
             c.rc = ttm_allreduce_f64(c.comm, c.sums_dev, 1 + n, TTM_OP_SUM, c.stream);
             if (c.rc) return c.rc;
@@ -162,9 +193,9 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
             if (hipMemcpyAsync(c.sums_host, c.sums_dev, (size_t)(1 + n) * 8, hipMemcpyDeviceToHost, (hipStream_t)c.stream) != hipSuccess)
                 return c.rc = TTM_E_HIP;
 #endif
+            c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
+            if (c.rc) return c.rc;
         }
-        c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
-        if (c.rc) return c.rc;
         // J = c'Ac/2 - sum log dS / N + c.b,  grad = Ac - sums/N + b   (TM:3008-3018)
         double quad = 0.0, lin = 0.0;
         for (int i = 0; i < n; ++i) {
@@ -240,8 +271,15 @@ int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const do
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n of the objective's sample terms, sums[1 + i] = sum_n of their derivatives (TM:3300-3380, 3435-3573)
         double* out = c.comm ? c.sums_dev : c.sums_host;
-        c.rc = ttm_objective_host(c.p, c.k, cc, c.Xsoa, c.ldx, c.N, c.work, c.counter, out, c.stream);
-        if (c.rc) return c.rc;
+        if (!c.comm) {
+            c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream, [&](double* flag, double mark) {
+                return ttm_objective_host_marked(c.p, c.k, cc, c.Xsoa, c.ldx, c.N, c.work, c.counter, out, flag, mark, c.stream);
+            });
+            if (c.rc) return c.rc;
+        } else {
+            c.rc = ttm_objective_host(c.p, c.k, cc, c.Xsoa, c.ldx, c.N, c.work, c.counter, out, c.stream);
+            if (c.rc) return c.rc;
+        }
         if (c.comm) {
             c.rc = ttm_allreduce_f64(c.comm, c.sums_dev, 1 + n, TTM_OP_SUM, c.stream);
             if (c.rc) return c.rc;
@@ -251,9 +289,9 @@ int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const do
             if (hipMemcpyAsync(c.sums_host, c.sums_dev, (size_t)(1 + n) * 8, hipMemcpyDeviceToHost, (hipStream_t)c.stream) != hipSuccess)
                 return c.rc = TTM_E_HIP;
 #endif
+            c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
+            if (c.rc) return c.rc;
         }
-        c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
-        if (c.rc) return c.rc;
         // mean over the ensemble + the penalty on the coefficients (TM:3382-3431, 3575-3633)
         double pen = 0.0;
         for (int i = 0; i < n; ++i) {
