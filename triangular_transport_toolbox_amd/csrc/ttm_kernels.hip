@@ -1373,7 +1373,10 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
             cdbl_p rec = (cdbl_p)(U_ + h_off) + (int64_t)kb * HS;
             const double* slot = tabs;
             const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;   // column of THIS step's z
-            for (int j = 0; j < nk; ++j, rec += HS, slot += tab_slot, zcol += ldzb) {
+            // one step = one component for the rows of the tile.  Banded maps: the registers of the column at lag 2 take the
+            // new column, so the two register sets swap roles from step to step - steps are issued in pairs with the roles
+            // exchanged instead of moving 8 registers per row pair and step
+            auto step = [&](int j, D2 (&L1x)[NP], D2 (&L1e)[NP], D2 (&L2x)[NP], D2 (&L2e)[NP]) {
                 // ---- uniform data of the step: the whole record by scalar loads issued together --------------------
                 cint_p ri = (cint_p)rec;
                 const int put2 = ri[0], flg = ri[1], kcol = ri[3], n_grp = ri[13];
@@ -1449,8 +1452,8 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
 #pragma unroll
                     for (int g = 0; g < (NG < 2 ? NG : 2); ++g) {
                         if (g < (code & 15)) {
-                            if (((code >> (4 + 4 * g)) & 15) == 1) group(g, bx1, be1);
-                            else group(g, bx2, be2);
+                            if (((code >> (4 + 4 * g)) & 15) == 1) group(g, L1x, L1e);
+                            else group(g, L2x, L2e);
                         }
                     }
                 } else {
@@ -1574,8 +1577,7 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
                         D2 eo = {ev[2 * q], ev[2 * q + 1]};
-                        bx2[q] = bx1[q]; be2[q] = be1[q];
-                        bx1[q] = rprev[q]; be1[q] = ETAB ? eo : rt_expq(rprev[q]);
+                        L2x[q] = rprev[q]; L2e[q] = ETAB ? eo : rt_expq(rprev[q]);     // the oldest column's registers take the new one
                     }
                 } else if (put2 >= 0) {
 #pragma unroll
@@ -1590,6 +1592,33 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 xprev_col = (const char*)X + (int64_t)kcol * ldxb;
                 xprev_off = tbase * 8u;
                 xprev_full = full;
+                rec += HS; slot += tab_slot; zcol += ldzb;
+            };
+            int j = 0;
+#ifndef TTM_RT_UNPAIRED
+            for (; j + 1 < nk; j += 2) {
+                step(j, bx1, be1, bx2, be2);
+                step(j + 1, bx2, be2, bx1, be1);
+            }
+#else
+            for (; j + 1 < nk; ++j) {                                    // (tuning builds: the register shift per step)
+                step(j, bx1, be1, bx2, be2);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const D2 tx = bx1[q], te = be1[q];
+                    bx1[q] = bx2[q]; be1[q] = be2[q]; bx2[q] = tx; be2[q] = te;
+                }
+            }
+#endif
+            if (j < nk) {
+                step(j, bx1, be1, bx2, be2);
+                if (BAND) {                                              // odd number of steps: back to the canonical roles
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const D2 tx = bx1[q], te = be1[q];
+                        bx1[q] = bx2[q]; be1[q] = be2[q]; bx2[q] = tx; be2[q] = te;
+                    }
+                }
             }
         }
         if (xprev_col) {                                                 // the last step's x
