@@ -1135,7 +1135,7 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
 // (root_search_truncation) and step * max|y| / 2 <= 0.1.
 // Search: the bucket function of k_table_index, bit for bit (table_bucket) -> a = number of entries in lower buckets; only
 // the entries of the target's own bucket are compared (at most `per` = 2-3 with nb ~ T): exact without verification.
-// LDS (doubles): [tables: B x tab_slot | E: Weven (ETAB) | column cache, 2 x ways x NS x blockDim]
+// LDS (doubles): [tables: B x tab_slot | {E_i, y_i}: 2 x Weven (ETAB) | column cache, 2 x ways x NS x blockDim]
 // table slot: [lo, hi, bucket scale, bucket bias, int32 {entries per bucket at most, band code}, 0 | xs: W entries + 4
 //              sentinels (+inf), rounded up to even | bucket index: nb + 1 uint16]
 // Windowed tables (W < T): only entries [w0, w0 + W) of every table (and of E) are resident - the middle of the grid,
@@ -1225,14 +1225,19 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
     const int Weven = (W + 4 + 1) & ~1;
     double* tabs = g_smem;
     double* etab = tabs + (size_t)B * tab_slot;
-    double* cache = etab + (ETAB ? Weven : 0);
-    const double* etabw = etab - w0;                                     // indexed by the entry's number in the whole table
+    double* cache = etab + (ETAB ? 2 * Weven : 0);
+    const double* etabw = etab - 2 * w0;                                 // pairs {E_i, y_i}, indexed by the entry's number in the whole table
     const RtCache<NP> cc{cache + 2 * tid, 2 * CT};
     // (row numbers are 32-bit - N < 2^28 - and every access is `uniform column base + 32-bit byte offset`)
     const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);        // first row of the last readable pair
     const unsigned int row0 = (unsigned int)c0 + 2u * (unsigned int)tid, c1_32 = (unsigned int)c1;
     if (ETAB)
-        for (int i = tid; i < W; i += CT) etab[i] = exp_q_fast(w0 + i == T - 1 ? ylast : (double)(w0 + i) * ystep + y0);
+        for (int i = tid; i < W; i += CT) {
+            // E of grid point w0 + i and, next to it, that point's abscissa exactly as the interpolation forms it from the
+            // interval number (fma(i + 1, step, y0 - step)): one 16-byte read per row instead of a read, a convert and an fma
+            etab[2 * i] = exp_q_fast(w0 + i == T - 1 ? ylast : (double)(w0 + i) * ystep + y0);
+            etab[2 * i + 1] = fma((double)(w0 + i + 1), ystep, y0 - ystep);
+        }
     // Taylor coefficients 1/7! .. 1/2! of the ETAB put, kept in VGPRs (as scalars they would push the kernel over the
     // SGPR budget and be spilled to VGPR lanes: v_readlane + hazard nops in the middle of every step)
     double kc[6];
@@ -1485,7 +1490,9 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                     traw[e] = -off[e] + z;
                     tg[e] = fmin(fmax(traw[e], wl), wh);
                     outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
-                    pos[e] = (int)bkl[table_bucket(tg[e], scale, bias, nb)];
+                    // (tg >= wl >= lo: the lower clamp of table_bucket cannot bind - a product that rounds below zero
+                    // converts to 0)
+                    pos[e] = (int)bkl[min((int)fma(tg[e], scale, bias), nb - 1)];
                 }
                 if (per <= 2) {
 #pragma unroll
@@ -1517,8 +1524,8 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                 }
                 // ---- interp1d slope form (TM:4062-4065) and, with ETAB, exp(-x^2/4) from the located interval -------------
                 double r[NS], ev[NS];
-                auto interp = [&](int i, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
-                    const double y_lo = fma((double)i, ystep, y0m);          // abscissa i - 1 of the grid (to an ulp)
+                auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
+                    // (y_lo: abscissa i - 1 of the grid, fma(i, step, y0 - step) - the grid point to an ulp)
                     // slope = step / (x_hi - x_lo): v_rcp_f64 (2^-23) with one Newton step (2^-46); its error moves x by
                     // 0.02 x 2^-46 = 3e-16 at most.  y_hi - y_lo is the grid step up to the rounding of the two abscissae
                     // (1e-13 of the step, also in the last interval, whose end point np.linspace forces: 2e-15 of x)
@@ -1543,7 +1550,10 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
                     const int i = pos[e];                    // (in [w0 + 1, w0 + W - 2] for a target in [wl, wh])
-                    interp(i, xsl[i - 1], xsl[i], ETAB ? etabw[i - 1] : 0.0, tg[e], r[e], ev[e]);
+                    double e_lo = 0.0, y_lo;
+                    if (ETAB) load_pair(etabw + 2 * (i - 1), e_lo, y_lo);
+                    else y_lo = fma((double)i, ystep, y0m);
+                    interp(y_lo, xsl[i - 1], xsl[i], e_lo, tg[e], r[e], ev[e]);
                 }
                 if (outl != 0) {
                     // outliers (a handful per million rows of a standard-normal ensemble): clip as TM:4074-4076 does,
@@ -1566,7 +1576,8 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                                 if (xg[mid] < t) a = mid + 1; else b = mid;
                             }
                             const int i = min(max(a, 1), T - 1);
-                            interp(i, xg[i - 1], xg[i], ETAB ? exp_q_fast((double)(i - 1) * ystep + y0) : 0.0, t, r[e], ev[e]);
+                            interp(fma((double)i, ystep, y0m), xg[i - 1], xg[i], ETAB ? exp_q_fast((double)(i - 1) * ystep + y0) : 0.0, t, r[e],
+                                   ev[e]);
                         }
                     }
                 }
@@ -2722,7 +2733,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         auto plan_blocks = [&]() {
             Bc = 0;
             for (CT = CT0; CT >= 256; CT -= 256) {                       // fewer rows in flight if the tables would not fit
-                const size_t fixed = ((size_t)(etab ? Weven : 0) + (band ? 0 : (size_t)2 * ways * NS * CT)) * 8;
+                const size_t fixed = ((size_t)(etab ? 2 * Weven : 0) + (band ? 0 : (size_t)2 * ways * NS * CT)) * 8;
                 if (fixed + (size_t)tab_slot * 8 > budget) continue;
                 Bc = (int)((budget - fixed) / ((size_t)tab_slot * 8));
                 if (Bc > ncomp) Bc = ncomp;
