@@ -699,17 +699,16 @@ TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, XA& x, Out&& o
         return;
     }
     const double xk = x(c.kc);
-    for (int i = 0; i < c.n_mon; ++i) {
-        cint_p T = c.mon_terms + 4 * i;
-        const int bsel = TTM_UNI(T[2]);
-        double v = 1.0, dv = 0.0;
-        if (bsel >= 0) {
-            for_each_B<true>(c, p, xk, [&](int b, double bv, double bdv) {
-                if (b == bsel) { v = bv; dv = bdv; }
-            });
+    // every distinct x_k-function once; the terms that carry it are found by a scalar scan of the term table
+    for_each_B<true>(c, p, xk, [&](int b, double bv, double bdv) {
+        for (int i = 0; i < c.n_mon; ++i) {
+            cint_p T = c.mon_terms + 4 * i;
+            if (TTM_UNI(T[2]) == b) out(TTM_UNI(T[3]), eval_A<double>(T, c, p, x) * (which == 1 ? bv : bdv));
         }
-        const double a = eval_A<double>(T, c, p, x);
-        out(TTM_UNI(T[3]), a * (which == 1 ? v : dv));
+    });
+    for (int i = 0; i < c.n_mon; ++i) {                      // terms without a factor in x_k: value 1, derivative 0
+        cint_p T = c.mon_terms + 4 * i;
+        if (TTM_UNI(T[2]) < 0) out(TTM_UNI(T[3]), eval_A<double>(T, c, p, x) * (which == 1 ? 1.0 : 0.0));
     }
 }
 
