@@ -1114,7 +1114,7 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
 // ---------------------------------------------------------------------------
 // Table inverse with RESIDENT tables (the kernel the large-ensemble path runs).
 //
-// k_inverse_hl streams the 12 KB table + bucket index of a component into LDS for every 512-row step: 945 MB of
+// Round 1's kernel streamed the 12 KB table + bucket index of a component into LDS for every 512-row step: 945 MB of
 // L2 -> LDS traffic per launch at C5 (1.5 x the algorithmic bytes), two loader waves per workgroup and one barrier
 // per step.  Here a workgroup owns a contiguous chunk of rows and walks the components in BLOCKS of B: the tables of
 // a block (xs row + 16-bit bucket index, 10 KB per component) are loaded into LDS once per workgroup and launch, then
@@ -1122,11 +1122,11 @@ __global__ TTM_HL_FWD_BOUNDS(WANT_LD) void k_forward_hl(const int* __restrict__ 
 // and no rings: a thread carries its NS rows through the B components, reads z_k with one 16-byte global load per row
 // pair (issued one step ahead) and stores x_k the same way (one step behind).
 //
-// What a later component reads of the earlier ones (x_j and exp(-x_j^2/4) of the columns its nonmonotone groups use)
-// lives in the planned column cache (termtable.py:_plan_column_cache) in per-thread 16-byte LDS words, 32 B per row
-// and way: one workgroup of 16 waves per CU, 8 components per block at C5.  (Measured and dropped: carrying the last
-// two columns of a banded map in registers instead - no cache traffic, 15 components per block, or two workgroups
-// = 32 waves per CU under a 64-register cap: 0.215 / 0.234 ms against 0.215 ms)
+// What a later component reads of the earlier ones (x_j and exp(-x_j^2/4) of the columns its nonmonotone groups use):
+// BAND (every group reads column kc-1 or kc-2, columns consecutive - BASELINE config 5): the last two columns live in
+// registers and the two register sets exchange roles from step to step; otherwise the planned column cache
+// (termtable.py:_plan_column_cache) in per-thread 16-byte LDS words, 32 B per row and way.  One workgroup of 16 waves
+// per CU either way.
 // At a block boundary the state of a tile is re-loaded from the x columns the SAME thread stored in the previous block.
 // With ETAB, exp(-x_k^2/4) comes from the located table interval instead of a full exp: x_k = y_lo + delta with
 // 0 <= delta <= step, exp(-x_k^2/4) = E[i-1] exp(w), w = -delta (y_lo + x_k) / 4, |w| <= 0.1, E[i] = exp(-y_i^2/4)
