@@ -145,3 +145,17 @@ def test_fallback_search_follows_scipy_point_for_point(name):
     for b in pts:
         assert np.min(np.max(np.abs(C - b), axis=1)) <= 1e-9 * (1 + np.max(np.abs(b)))
     assert np.max(np.abs(x - ref.x)) < 1e-9
+
+
+def test_entry_points_reject_bad_arguments():
+    """The optimiser entry points validate before they touch anything (include/ttm.h: TTM_E_ARG = -1)."""
+    from tests.hostemu import emu
+    lib = emu.lib()
+    x = np.zeros(3)
+    res = np.zeros(5)
+    assert lib.ttm_bfgs_minimize(0, x.ctypes.data, None, None, 0, res.ctypes.data) != 0
+    assert lib.ttm_bfgs_minimize(3, None, None, None, 0, res.ctypes.data) != 0
+    assert lib.ttm_optimize_separable_batch(None, 1, 10, 10.0, 1e-8, 2, None, 0) != 0
+    tasks = (_capi.ttm_sep_task * 1)()
+    assert lib.ttm_optimize_separable_batch(tasks, 0, 10, 10.0, 1e-8, 2, None, 0) != 0
+    assert lib.ttm_optimize_integrated_batch(None, None, 1, None, 10, 10, 10.0, 2, None, 0) != 0
