@@ -440,6 +440,15 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
 int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
                                     double delta, double* work, uint32_t* counter, double* out, double* flag,
                                     double mark, void* stream);
+/* The separable reduction with the derivative basis recomputed from the x_k column (xk: device, N doubles) instead of
+ * read from a cached N x m matrix - for components whose monotone terms are all plain special terms of x_k: kinds
+ * (device, m int32: TTM_KIND_LET / RET / RBF / IRBF) and pars (device, 5 m doubles: {centre, scale, 1/(sqrt2 scale),
+ * scale sqrt(2/pi), 1/(sqrt(2 pi) scale)} per term, as in the program's constant array), both in coefficient order.
+ * Same sums, bit for bit, as ttm_objective_sep_cached on the basis ttm_basis(which = 2) writes; 8 bytes of HBM per row
+ * instead of 8 m.                                                                                                    */
+int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
+                                    const double* h_coef_mon, double delta, double* work, uint32_t* counter,
+                                    double* out, double* flag, double mark, void* stream);
 
 /* ---- K8: Gram matrix of [Psi_nonmon | Psi_mon] -------------------------------------
  * replaces the N x m passes of TM:2966-2975 (QR projection) and TM:3031-3050 (L2 normal
@@ -506,7 +515,7 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
  * non-zero rc.  nthreads = 1 runs the tasks in order on `stream` itself.  No communicator: ranks that share the
  * samples of an ensemble call ttm_optimize_separable per component, in the same order on every rank.              */
 typedef struct ttm_sep_task {
-    const double* dPsi;          /* device, m rows of N doubles, row stride ldp */
+    const double* dPsi;          /* device, m rows of N doubles, row stride ldp; NULL: see xk below */
     int64_t ldp;
     int32_t m, rc;
     const double *A, *b, *lb, *ub;   /* host */
@@ -515,6 +524,10 @@ typedef struct ttm_sep_task {
     uint32_t* counter;           /* device uint32[16], zero */
     double* sums_host;           /* pinned host, >= 2 + m doubles */
     double result[5];
+    /* dPsi == NULL: the derivative basis is recomputed per evaluation (ttm_objective_sep_direct_marked) from */
+    const double* xk;            /* device, the component's x_k column (N doubles) */
+    const int32_t* kinds;        /* device, m */
+    const double* pars;          /* device, 5 m */
 } ttm_sep_task;
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta,
                                  int32_t nthreads, void* stream, int32_t maxiter);

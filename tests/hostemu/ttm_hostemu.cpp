@@ -569,6 +569,33 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
     return 0;
 }
 
+// the separable sums with the derivative basis recomputed from the x_k column (special terms only)
+int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
+                                    const double* h_coef_mon, double delta, double*, uint32_t*, double* out, double* flag,
+                                    double mark, void*) {
+    if (!xk || !kinds || !pars || !h_coef_mon || !out || N < 1 || m < 1 || m > 16) return TTM_E_ARG;
+    Prog g;
+    g.qx = nullptr; g.qw = nullptr; g.erf_tab = kErfTab; g.Q = 0; g.family = 0; g.mono = TTM_MONO_SEPARABLE; g.rect = 0; g.delta = delta;
+    std::vector<double> acc(1 + m, 0.0), d(m);
+    for (int64_t n = 0; n < N; ++n) {
+        double dS = 0.0, rowsum = 0.0;
+        for (int i = 0; i < m; ++i) {
+            double v, dv;
+            st_eval<false, true>(g, kinds[i], xk[n], pars + 5 * i, v, dv);
+            d[i] = dv;
+            dS = fma(h_coef_mon[i], dv, dS);
+            rowsum += dv;
+        }
+        dS += rowsum * delta;
+        acc[0] += fast_log(dS);
+        const double inv = fast_rcp(dS);
+        for (int i = 0; i < m; ++i) acc[1 + i] += d[i] * inv;
+    }
+    for (int i = 0; i <= m; ++i) out[i] = acc[i];
+    if (flag) *flag = mark;
+    return 0;
+}
+
 // marked variants: the reduction is done when the call returns
 int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_coef_k, const double* X, int64_t ldx, int64_t N,
                               double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {

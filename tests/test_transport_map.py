@@ -220,6 +220,14 @@ def test_batched_component_optimisation_equals_the_sequential_one(backend, name)
         for k in range(len(runs[1][0])):
             assert np.array_equal(runs[threads][0][k], runs[1][0][k]) and np.array_equal(runs[threads][1][k], runs[1][1][k])
         assert runs[threads][2] == runs[1][2]
+    if not name.endswith('_int'):
+        # the memory-lean variant (derivative basis recomputed from the x_k column in every evaluation): the same bits
+        tm = make_tm(name, npz, desc, with_coeffs=False)
+        tm.direct_objective = True
+        assert all(d is not None for d in tm._cm.sep_direct)
+        tm.optimize()
+        for k in range(tm.D):
+            assert np.array_equal(tm.coeffs_mon[k], runs[1][0][k]) and np.array_equal(tm.coeffs_nonmon[k], runs[1][1][k])
     tm = make_tm(name, npz, desc, with_coeffs=False)
     tm.optimizer_batch_bytes = 1                      # one component per batch: still the same results
     tm.optimize(K=[tm.D - 1, 0])

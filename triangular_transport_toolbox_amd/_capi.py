@@ -21,7 +21,8 @@ OBJECTIVE_CB = ctypes.CFUNCTYPE(c_i32, c_i32, ctypes.POINTER(c_dbl), ctypes.POIN
 class ttm_sep_task(ctypes.Structure):
     """Mirror of `struct ttm_sep_task` (include/ttm.h: one component problem of ttm_optimize_separable_batch)."""
     _fields_ = [('dPsi', c_vp), ('ldp', c_i64), ('m', c_i32), ('rc', c_i32), ('A', c_vp), ('b', c_vp), ('lb', c_vp), ('ub', c_vp),
-                ('x', c_vp), ('work', c_vp), ('counter', c_vp), ('sums_host', c_vp), ('result', c_dbl * 5)]
+                ('x', c_vp), ('work', c_vp), ('counter', c_vp), ('sums_host', c_vp), ('result', c_dbl * 5),
+                ('xk', c_vp), ('kinds', c_vp), ('pars', c_vp)]
 
 
 class ttm_int_task(ctypes.Structure):
@@ -78,6 +79,7 @@ _SIGNATURES = {
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_host_marked': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_objective_sep_cached_marked': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
+    'ttm_objective_sep_direct_marked': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'ttm_lorenz63_rk4': (ctypes.c_int, [c_vp, c_i64, c_i64, c_dbl, c_i32, c_vp]),
     'ttm_perturb': (ctypes.c_int, [c_vp, c_vp, c_dbl, ctypes.c_uint64, ctypes.c_uint32, c_i64, c_i64, c_vp, c_vp]),

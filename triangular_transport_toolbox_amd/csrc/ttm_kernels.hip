@@ -2055,6 +2055,83 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     }
 }
 
+// The same reduction with the derivative basis RECOMPUTED from the x_k column: every monotone term of the component is
+// a plain special term of x_k (LET / RET / RBF / iRBF; kinds[i], pars[5 i ..] = its constants, in coefficient order), so
+// a row costs 8 bytes of HBM instead of 8 M and ~25 instructions per term (st_eval - the very code ttm_basis runs, hence
+// the same bits as the cached basis).  No N x M matrix is built or kept.
+template <int M>
+__global__ __launch_bounds__(256) void k_objective_sep_direct(const double* __restrict__ xk, int64_t N, const int* __restrict__ kinds,
+                                                              const double* __restrict__ pars, SepCoef hc, double delta,
+                                                              double* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                              double* __restrict__ out, double* flag, double mark) {
+    __shared__ double et[TTM_ERF_TABLE_LEN];
+    __shared__ double red[4][M + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
+    __syncthreads();
+    Prog g;
+    g.qx = nullptr; g.qw = nullptr; g.erf_tab = et; g.Q = 0; g.family = 0; g.mono = TTM_MONO_SEPARABLE; g.rect = 0; g.delta = delta;
+    cint_p kd = (cint_p)kinds;
+    cdbl_p pr = (cdbl_p)pars;
+    double acc[M + 1];
+#pragma unroll
+    for (int i = 0; i <= M; ++i) acc[i] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto basis = [&](double x, double (&d)[M]) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double v, dv;
+            st_eval<false, true>(g, kd[i], x, pr + 5 * i, v, dv);
+            d[i] = dv;
+        }
+    };
+    auto row = [&](const double (&d)[M]) {
+        double dS = 0.0, rowsum = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            dS = fma(hc.c[i], d[i], dS);
+            rowsum += d[i];
+        }
+        dS += rowsum * delta;
+        acc[0] += fast_log(dS);
+        const double inv = fast_rcp(dS);
+#pragma unroll
+        for (int i = 0; i < M; ++i) acc[1 + i] += d[i] * inv;
+    };
+    int64_t n = (int64_t)blockIdx.x * blockDim.x + tid;
+    for (; n + stride < N; n += 2 * stride) {
+        const double x0 = xk[n], x1 = xk[n + stride];
+        double d0[M], d1[M];
+        basis(x0, d0);
+        basis(x1, d1);
+        row(d0);
+        row(d1);
+    }
+    if (n < N) {
+        double d0[M];
+        basis(xk[n], d0);
+        row(d0);
+    }
+#pragma unroll
+    for (int i = 0; i <= M; ++i) {
+        const double v = wave_sum(acc[i]);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    const int nacc = 1 + M;
+    if (tid < nacc) partial[(int64_t)blockIdx.x * nacc + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (counter && last_workgroup(counter)) {
+        __shared__ double fin[M + 1];
+        for (int i = wv; i < nacc; i += 4) {
+            double v = 0.0;
+            for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
+            v = wave_sum(v);
+            if (lane == 0) fin[i] = v;
+        }
+        publish(fin, nacc, out, flag, mark);
+    }
+}
+
 // stream-ordered completion mark in (pinned host) memory: the host polls it instead of calling hipStreamSynchronize
 __global__ void k_signal(double* flag, double value) { *flag = value; }
 
@@ -2946,6 +3023,36 @@ int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, 
                                (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
     }
     return check_launch("k_objective_sep_cached");
+}
+
+int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
+                                    const double* h_coef_mon, double delta, double* work, uint32_t* counter, double* out,
+                                    double* flag, double mark, void* stream) {
+    if (!xk || !kinds || !pars || !h_coef_mon || !work || !counter || !out || N < 1 || m < 1)
+        return set_err(TTM_E_ARG, "ttm_objective_sep_direct_marked: bad arguments%s");
+    if (m > TTM_SEPC_MAXM) return set_err(TTM_E_LIMIT, "ttm_objective_sep_direct_marked: more than %s%lld monotone terms", "", TTM_SEPC_MAXM);
+    SepCoef hc;
+    for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
+    int nb = grid_for(N, 256 * 4);
+    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    typedef void (*dkern_t)(const double*, int64_t, const int*, const double*, SepCoef, double, double*, unsigned int*, double*, double*, double);
+    static const dkern_t kerns[TTM_SEPC_MAXM] = {
+        k_objective_sep_direct<1>, k_objective_sep_direct<2>, k_objective_sep_direct<3>, k_objective_sep_direct<4>,
+        k_objective_sep_direct<5>, k_objective_sep_direct<6>, k_objective_sep_direct<7>, k_objective_sep_direct<8>,
+        k_objective_sep_direct<9>, k_objective_sep_direct<10>, k_objective_sep_direct<11>, k_objective_sep_direct<12>,
+        k_objective_sep_direct<13>, k_objective_sep_direct<14>, k_objective_sep_direct<15>, k_objective_sep_direct<16>};
+    const bool ticket = nb <= 64;
+    hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta,
+                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
+    if (!ticket) {
+        if (flag)
+            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
+                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out, flag, mark);
+        else
+            hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
+    }
+    return check_launch("k_objective_sep_direct");
 }
 
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N, double* work, double* out,

@@ -153,38 +153,38 @@ int ttm_lbfgsb_minimize(int32_t n, double* x, const double* lb, const double* ub
     return r.status < 0 ? TTM_E_HIP : TTM_OK;
 }
 
-int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* A, const double* b, double Ntotal,
-                           double delta, const double* lb, const double* ub, double* x, double* work, uint32_t* counter,
-                           double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result) {
-    if (!dPsi || !A || !b || !x || !work || !counter || !sums_host || m < 1 || N < 1 || !(Ntotal > 0.0)) return TTM_E_ARG;
-    if (comm && !sums_dev) return TTM_E_ARG;
+}  // extern "C"
+
+namespace {
+
+// the reduced separable problem of one component (TM:2978-3018) minimised by the L-BFGS-B loop; launch(cc, out, flag,
+// mark, stream) enqueues the reduction of the sums for coefficients cc into out (flag != NULL: with the completion mark)
+template <class Launch>
+int optimize_separable_with(Launch launch, int32_t m, const double* A, const double* b, double Ntotal, const double* lb,
+                            const double* ub, double* x, double* sums_dev, double* sums_host, ttm_comm* comm, void* stream,
+                            int32_t maxiter, double* result) {
     struct Ctx {
-        const double *dPsi, *A, *b;
-        int64_t ldp, N;
-        int m;
-        double invN, delta;
-        double *work, *sums_dev, *sums_host;
-        uint32_t* counter;
+        Launch& launch;
+        const double *A, *b;
+        double invN;
+        double *sums_dev, *sums_host;
         ttm_comm* comm;
         void* stream;
         int rc;
         long seq;
-    } c{dPsi, A, b, ldp, N, (int)m, 1.0 / Ntotal, delta, work, sums_dev, sums_host, counter, comm, stream, 0, 0};
+    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0};
     sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n log dS_n, sums[1 + i] = sum_n dPsi_{n,i} / dS_n  (TM:2990-3006), over the local samples
         double* out = c.comm ? c.sums_dev : c.sums_host;
         if (!c.comm) {                                       // results and completion mark from the reduction itself
-            c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream, [&](double* flag, double mark) {
-                return ttm_objective_sep_cached_marked(c.dPsi, c.ldp, c.N, n, cc, c.delta, c.work, c.counter, out, flag, mark, c.stream);
-            });
+            c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream,
+                                      [&](double* flag, double mark) { return c.launch(cc, out, flag, mark, c.stream); });
             if (c.rc) return c.rc;
         } else {
-            c.rc = ttm_objective_sep_cached(c.dPsi, c.ldp, c.N, n, cc, c.delta, c.work, c.counter, out, c.stream);
+            c.rc = c.launch(cc, out, (double*)nullptr, 0.0, c.stream);
             if (c.rc) return c.rc;
-        }
-        if (c.comm) {
             c.rc = ttm_allreduce_f64(c.comm, c.sums_dev, 1 + n, TTM_OP_SUM, c.stream);
             if (c.rc) return c.rc;
 #ifdef TTM_HOST_ONLY
@@ -212,13 +212,37 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
     return c.rc ? c.rc : rc;
 }
 
+}  // namespace
+
+extern "C" {
+
+int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* A, const double* b, double Ntotal,
+                           double delta, const double* lb, const double* ub, double* x, double* work, uint32_t* counter,
+                           double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result) {
+    if (!dPsi || !A || !b || !x || !work || !counter || !sums_host || m < 1 || N < 1 || !(Ntotal > 0.0)) return TTM_E_ARG;
+    if (comm && !sums_dev) return TTM_E_ARG;
+    auto launch = [&](const double* cc, double* out, double* flag, double mark, void* st) {
+        return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
+    };
+    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result);
+}
+
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta, int32_t nthreads,
                                  void* stream, int32_t maxiter) {
     if (!tasks || ntasks < 1 || N < 1) return TTM_E_ARG;
     return run_batch(ntasks, nthreads, stream, [&](int t, void* st) {
         ttm_sep_task& q = tasks[t];
-        return q.rc = ttm_optimize_separable(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
-                                             q.sums_host, nullptr, st, maxiter, q.result);
+        if (q.dPsi)
+            return q.rc = ttm_optimize_separable(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter,
+                                                 nullptr, q.sums_host, nullptr, st, maxiter, q.result);
+        // derivative basis recomputed from the x_k column per evaluation
+        if (!q.xk || !q.kinds || !q.pars || !q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
+            return q.rc = TTM_E_ARG;
+        auto launch = [&](const double* cc, double* out, double* flag, double mark, void* s2) {
+            return ttm_objective_sep_direct_marked(q.xk, N, q.m, q.kinds, q.pars, cc, delta, q.work, q.counter, out, flag, mark, s2);
+        };
+        return q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
+                                              q.result);
     });
 }
 

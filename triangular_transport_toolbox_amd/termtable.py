@@ -175,6 +175,7 @@ class CompiledMap:
         self.dpar_sources = []     # per dpar entry: ('hf', value) | ('st', kc, cross, var, index, which)
         self.descriptors_mon = []  # canonical term descriptors (tests)
         self.descriptors_nonmon = []
+        self.sep_direct = []       # per component: (column of x_k, [(special-term kind, dpar offset) per coefficient]) or None
         self.bounds = []           # L-BFGS-B bounds per component (TM:1891-1892, 1925-1929)
         self.family = 0
         self.D = 0
@@ -595,6 +596,14 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
         n_mon_all.append(len(mon_terms))
+        # separable components whose monotone terms are all plain special terms of x_k: (kind, offset of the term's five
+        # constants in the component's dpar slice) per coefficient - the optimiser then recomputes the derivative basis
+        # from the x_k column instead of streaming a cached N x m matrix (ttm_objective_sep_direct_marked)
+        mon_records = terms[len(nm_terms):]
+        if separable and len(mon_records) and all(r[1] == 0 and r[2] >= 0 and bfuns[r[2]][0] in ST_KINDS.values() for r in mon_records):
+            cm.sep_direct.append((kc, [(bfuns[r[2]][0], bfuns[r[2]][2]) for r in sorted(mon_records, key=lambda r: r[3])]))
+        else:
+            cm.sep_direct.append(None)
         cm.descriptors_mon.append([_descriptor(t) for t in mon_terms])
         cm.descriptors_nonmon.append([_descriptor(t) for t in nm_terms] if len(nm_terms) else None)
         cm.bounds.append([[-np.inf, np.inf] if (not isinstance(e, str) and len(e) == 0) else [0., np.inf]

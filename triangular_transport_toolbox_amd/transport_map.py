@@ -1374,6 +1374,11 @@ class transport_map():
     optimizer_threads = 8
     # device memory the cached derivative bases of one batch may take (bytes)
     optimizer_batch_bytes = 8 << 30
+    # True: components whose monotone terms are plain special terms of x_k recompute the derivative basis from the x_k
+    # column in every evaluation instead of caching an N x m matrix (ttm_objective_sep_direct_marked).  Same bits and
+    # no N x m matrices (1.3 GB at C5), but the erf-table gathers cost more than the bytes they save: optimize() at
+    # C5 0.027 s against 0.021 s - the memory-lean variant, off by default
+    direct_objective = False
 
     def _optimize_separable_batch(self, K):
         """TM:2746-2845 for separable maps: the components of K are independent problems (the reference hands them to
@@ -1387,7 +1392,8 @@ class transport_map():
             return None
         torch = _torch()
         results = {}
-        per_k = [int(self._cm.n_mon[k]) * self._Xs.shape[1] * 8 for k in K]
+        direct = {k: self._cm.sep_direct[k] if self.direct_objective else None for k in K}
+        per_k = [0 if direct[k] is not None else int(self._cm.n_mon[k]) * self._Xs.shape[1] * 8 for k in K]
         start = 0
         while start < len(K):
             stop, used = start, 0
@@ -1404,12 +1410,25 @@ class transport_map():
             sums = torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
             tasks = (_capi.ttm_sep_task * n)()
             keep = []
+            # special-term kinds and constants of the components that recompute their basis: one upload for the batch
+            kinds_all, pars_all, where = [], [], {}
+            for k in batch:
+                if direct[k] is not None:
+                    base = int(self._cm.dpar_off[k])
+                    where[k] = (len(kinds_all), len(pars_all))
+                    for kind, p0 in direct[k][1]:
+                        kinds_all.append(kind)
+                        pars_all.extend(self._cm.dpar[base + p0:base + p0 + 5])
+            kinds_d = self._to_dev(np.asarray(kinds_all, dtype=np.int32), dtype=torch.int32) if kinds_all else None
+            pars_d = self._to_dev(np.asarray(pars_all, dtype=np.float64)) if pars_all else None
             for i, k in enumerate(batch):
                 A, solve_nonmon = self.separable_setup(k, G=grams[k])
                 m = int(self._cm.n_mon[k])
-                dpsi = self._cols(m, self._N)
-                _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
-                                                self._ptr(dpsi), dpsi.shape[1], self._stream()))
+                dpsi = None
+                if direct[k] is None:
+                    dpsi = self._cols(m, self._N)
+                    _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
+                                                    self._ptr(dpsi), dpsi.shape[1], self._stream()))
                 A = np.ascontiguousarray(A, dtype=float)
                 b = np.ascontiguousarray(self.delta * np.sum(A, axis=-1))
                 x = np.array(self.coeffs_mon[k], dtype=float, copy=True)
@@ -1417,7 +1436,14 @@ class transport_map():
                 ub = np.array([np.inf if v is None else v for v in self.optimization_constraints_ub[k]], dtype=float)
                 keep.append((A, b, x, lb, ub, dpsi, solve_nonmon))
                 t = tasks[i]
-                t.dPsi, t.ldp, t.m = dpsi.data_ptr(), dpsi.shape[1], m
+                t.m = m
+                if dpsi is not None:
+                    t.dPsi, t.ldp = dpsi.data_ptr(), dpsi.shape[1]
+                else:
+                    t.dPsi, t.ldp = None, 0
+                    t.xk = self._Xs.data_ptr() + 8 * int(direct[k][0]) * self._Xs.shape[1]
+                    t.kinds = kinds_d.data_ptr() + 4 * where[k][0]
+                    t.pars = pars_d.data_ptr() + 8 * where[k][1]
                 t.A, t.b, t.lb, t.ub, t.x = A.ctypes.data, b.ctypes.data, lb.ctypes.data, ub.ctypes.data, x.ctypes.data
                 t.work = work.data_ptr() + 8 * i * wsz
                 t.counter = counters.data_ptr() + 4 * 16 * i
