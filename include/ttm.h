@@ -121,8 +121,8 @@ extern "C" {
 #define TTM_HDR_OFF_FSLOT 23
 #define TTM_HDR_OFF_FSRC 24
 #define TTM_HDR_OFF_WB   25   /* offset of wB inside the folded array                          */
-#define TTM_HDR_RSV0     26
-#define TTM_HDR_RSV1     27
+#define TTM_HDR_N_XGRP   26   /* cross groups: weights of B functions as folded series in ONE conditioning variable */
+#define TTM_HDR_OFF_XGRP 27   /* records of 8 int32: {var, P, fold offset, has_hf, b, 0, 0, 0}                      */
 #define TTM_ST_NPAR       5   /* dpar doubles per special term                                 */
 /* fast-path descriptor of a component (components whose terms are all univariate: no table walking,
  * every record is at a known offset so the scalar loads can be issued ahead of use) */

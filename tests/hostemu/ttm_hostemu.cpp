@@ -41,6 +41,8 @@ struct XFake {
     int kc;
     double t;
     double operator()(int var) const { return var == kc ? t : 0.0; }
+    double get(int var) const { return var == kc ? t : 0.0; }
+    void get_e(int var, double& xv, double& e) const { xv = get(var); e = fast_exp(-0.25 * (xv * xv)); }
 };
 
 const double kErfTab[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };

@@ -76,11 +76,12 @@ struct Comp {            // one component block (pointers into staged tables)
     cint_p grp;
     cint_p gen;
     cint_p mnt;
+    cint_p xgrp;         // cross groups {var, P, fold offset, has_hf, b, 0, 0, 0}
     cdbl_p dpar;
     cdbl_p cnm;          // coefficients of the nonmonotone / monotone terms
     cdbl_p cmon;
     cdbl_p fold;         // folded coefficients (see include/ttm.h)
-    int kc, n_nm, n_mon, nB, nB_hf, nB_poly, nB_st, maxP_hf, maxP_poly, flags, n_grp, n_gen, n_mnt, off_wb;
+    int kc, n_nm, n_mon, nB, nB_hf, nB_poly, nB_st, maxP_hf, maxP_poly, flags, n_grp, n_gen, n_mnt, n_xgrp, off_wb;
 };
 
 TTM_HD Comp make_comp(cint_p cb, cdbl_p dpar, cdbl_p coef, cdbl_p fold) {
@@ -98,6 +99,8 @@ TTM_HD Comp make_comp(cint_p cb, cdbl_p dpar, cdbl_p coef, cdbl_p fold) {
     c.n_grp = TTM_UNI(cb[TTM_HDR_N_GRP]);
     c.n_gen = TTM_UNI(cb[TTM_HDR_N_GEN]);
     c.n_mnt = TTM_UNI(cb[TTM_HDR_N_MNT]);
+    c.n_xgrp = TTM_UNI(cb[TTM_HDR_N_XGRP]);
+    c.xgrp = cb + TTM_UNI(cb[TTM_HDR_OFF_XGRP]);
     c.off_wb = TTM_UNI(cb[TTM_HDR_OFF_WB]);
     c.nm_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_NM]);
     c.mon_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_MON]);
@@ -445,6 +448,29 @@ template <class R, class XA, class Slots>
 TTM_HD void mon_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
     cdbl_p wb = c.fold + c.off_wb;
     for (int b = 0; b <= c.nB; ++b) w.set(b, R(wb[b]));
+    // cross terms with one polynomial / Hermite-function factor: per (B function, variable) a folded series - one
+    // recurrence and the variable's cached exp(-x^2/4) instead of a walk through the term and factor records per term
+    for (int g = 0; g < c.n_xgrp; ++g) {
+        cint_p G = c.xgrp + 8 * g;
+        const int var = TTM_UNI(G[0]);
+        const int P = TTM_UNI(G[1]);
+        cdbl_p al = c.fold + TTM_UNI(G[2]);
+        cdbl_p be = al + P;
+        const int has_hf = TTM_UNI(G[3]);
+        const int b = TTM_UNI(G[4]);
+        R xv, e(0.0);
+        if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+        R pm(1.0), dpm(0.0), pn, dp, accp(0.0), acch(0.0);
+        poly_first(p.family, xv, pn, dp);
+        for (int n = 1; n <= P; ++n) {
+            accp = vfma(al[n - 1], pn, accp);
+            if (has_hf) acch = vfma(be[n - 1], pn, acch);
+            if (n < P) poly_next<false>(p.family, n, xv, pm, pn, dpm, dp);
+        }
+        R wv = w.get(b) + accp;
+        if (has_hf) wv = vfma(e, acch, wv);
+        w.set(b, wv);
+    }
     for (int j = 0; j < c.n_mnt; ++j) {
         cint_p T = c.mon_terms + 4 * TTM_UNI(c.mnt[j]);
         int b = TTM_UNI(T[2]);
@@ -677,7 +703,7 @@ TTM_HD void sample_forward(const Comp& c, const Prog& p, VarCache<XA, R>& x, Slo
         dense_weights<R>(c, p, x, w);
         const DenseSet<Slots> dw{w};
         mon_eval<MONO, DER>(c, p, xk, dw, m, dm);
-    } else if (c.n_mnt == 0) {
+    } else if (c.n_mnt == 0 && c.n_xgrp == 0) {
         const UniformW uw{c.fold + c.off_wb};
         mon_eval<MONO, DER>(c, p, xk, uw, m, dm);
     } else {
@@ -1271,7 +1297,7 @@ TTM_HD double sample_root(const Comp& c, const Prog& p, VarCache<XA, double>& x,
         const DenseSet<Slots> dw{w};
         return NEWTON ? sample_newton<MONO>(c, p, off, zk, dw, it) : sample_bisect<MONO>(c, p, off, zk, dw, cap, it);
     }
-    if (c.n_mnt == 0) {
+    if (c.n_mnt == 0 && c.n_xgrp == 0) {
         const UniformW uw{c.fold + c.off_wb};
         return NEWTON ? sample_newton<MONO>(c, p, off, zk, uw, it) : sample_bisect<MONO>(c, p, off, zk, uw, cap, it);
     }

@@ -131,6 +131,8 @@ struct XFake {               // TM:4050-4051: zeros except column kc
     int kc;
     double t;
     __device__ __forceinline__ double operator()(int var) const { return var == kc ? t : 0.0; }
+    __device__ __forceinline__ double get(int var) const { return var == kc ? t : 0.0; }
+    __device__ __forceinline__ void get_e(int var, double& xv, double& e) const { xv = get(var); e = fast_exp(-0.25 * (xv * xv)); }
 };
 
 __device__ const double g_erf_table[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
@@ -1676,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_table_build(DevProg P, int k0, const do
     if (i < T) {
         const double t = pts[i];
         double v, dv;
-        if (c.n_mnt == 0) {
+        if (c.n_mnt == 0 && c.n_xgrp == 0) {
             const UniformW uw{c.fold + c.off_wb};
             g_eval<false>(c, g, t, uw, v, dv);
         } else {

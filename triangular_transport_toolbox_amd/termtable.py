@@ -41,7 +41,7 @@ FAM_HERMITE_E, FAM_POWER, FAM_HERMITE, FAM_CHEBYSHEV, FAM_LAGUERRE, FAM_LEGENDRE
 HDR_LEN = 28
 (HDR_KC, HDR_N_NM, HDR_OFF_NM, HDR_N_MON, HDR_OFF_MON, HDR_OFF_FAC, HDR_NB, HDR_OFF_B, HDR_NB_HF, HDR_NB_POLY,
  HDR_NB_ST, HDR_MAXP_HF, HDR_MAXP_POLY, HDR_FLAGS, HDR_N_DPAR, HDR_LEN_BLK, HDR_N_GRP, HDR_OFF_GRP, HDR_N_GEN,
- HDR_OFF_GEN, HDR_N_MNT, HDR_OFF_MNT, HDR_N_FOLD, HDR_OFF_FSLOT, HDR_OFF_FSRC, HDR_OFF_WB, HDR_RSV0, HDR_RSV1) = range(28)
+ HDR_OFF_GEN, HDR_N_MNT, HDR_OFF_MNT, HDR_N_FOLD, HDR_OFF_FSLOT, HDR_OFF_FSRC, HDR_OFF_WB, HDR_N_XGRP, HDR_OFF_XGRP) = range(28)
 ST_NPAR = 5   # centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)
 
 # polynomial_type -> (family id, numpy class, unified name)   (TM:274-304)
@@ -489,11 +489,30 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         off_wb = len(fold_slots)
         fold_slots.extend([] for _ in range(len(bfuns) + 1))
         mnt_idx = []
+        xby = {}                   # cross terms with ONE factor, polynomial or Hermite function: (b, var) -> [(ci, factor)]
         for ci, tr in enumerate(terms[len(nm_terms):]):
+            cross = [f for f in mon_terms[ci] if (f[1] if f[0] == 'poly' else f[2]) != kc]
             if tr[1] == 0:
                 fold_slots[off_wb + (tr[2] if tr[2] >= 0 else len(bfuns))].append((len(nm_terms) + ci, -1))
+            elif tr[1] == 1 and cross[0][0] == 'poly':
+                xby.setdefault((tr[2] if tr[2] >= 0 else len(bfuns), cross[0][1]), []).append((ci, cross[0]))
             else:
                 mnt_idx.append(ci)
+        # cross groups: the weight of B function b gets, per conditioning variable, a polynomial + Hermite-function
+        # series in that variable whose coefficients are folded like the nonmonotone groups' (records {var, P, fold
+        # offset, has_hf, b, 0, 0, 0}; alpha_n at offset + n - 1, beta_n = a_n c at offset + P + n - 1)
+        xgroups = []
+        for (b_, var) in sorted(xby):
+            P = max(f[2] for _, f in xby[(b_, var)])
+            has_hf = any(f[3] for _, f in xby[(b_, var)])
+            off = len(fold_slots)
+            fold_slots.extend([] for _ in range(2 * P))
+            for ci, f in xby[(b_, var)]:
+                if f[3]:
+                    fold_slots[off + P + f[2] - 1].append((len(nm_terms) + ci, dp_hf(f[2])))
+                else:
+                    fold_slots[off + f[2] - 1].append((len(nm_terms) + ci, -1))
+            xgroups.append([var, P, off, 1 if has_hf else 0, b_, 0, 0, 0])
         # "stream" section for the fast path (components without cross / generic terms): weights indexed
         # densely by polynomial order and one 5-double record per special-term B function
         # {w_b, centre, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}; a source (-1, p) copies dpar[p]
@@ -520,7 +539,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
             fsrc.extend([list(e) for e in sl])
         # fast-path descriptor (TTM_FDESC_LEN int32) and int stream {per group: var, P, alpha offset, flags |
         # ST kinds | order of the unified ST records | planned-cache entry state}
-        complex_comp = 1 if (len(gen_idx) or len(mnt_idx) or maxP_hf > 16 or maxP_poly > 16) else 0
+        complex_comp = 1 if (len(gen_idx) or len(mnt_idx) or len(xgroups) or maxP_hf > 16 or maxP_poly > 16) else 0
         st_kinds = [bf[0] for bf in bfuns[len(b_hf) + len(b_poly):]]
         # unified special-term records: those whose VALUE needs the Gaussian (LET / RET / RBF) first
         st_order = ([i for i, kd in enumerate(st_kinds) if kd != KIND_IRBF] +
@@ -554,7 +573,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         off_grp = off_b + 4 * len(bfuns)
         off_gen = off_grp + 4 * len(groups)
         off_mnt = off_gen + len(gen_idx)
-        blk_len = off_mnt + len(mnt_idx)
+        off_xgrp = off_mnt + len(mnt_idx)
+        blk_len = off_xgrp + 8 * len(xgroups)
         off_fslot = 0                                       # fold recipes live in a separate table (ftab):
         off_fsrc = 2 * len(fslots)                          # they are read once at staging, not kept in LDS
         pad = (-blk_len) % 4                               # keep every block 16-byte aligned
@@ -573,10 +593,11 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         hdr[HDR_N_GRP], hdr[HDR_OFF_GRP] = len(groups), off_grp
         hdr[HDR_N_GEN], hdr[HDR_OFF_GEN] = len(gen_idx), off_gen
         hdr[HDR_N_MNT], hdr[HDR_OFF_MNT] = len(mnt_idx), off_mnt
+        hdr[HDR_N_XGRP], hdr[HDR_OFF_XGRP] = len(xgroups), off_xgrp
         hdr[HDR_N_FOLD], hdr[HDR_OFF_FSLOT], hdr[HDR_OFF_FSRC] = len(fslots), off_fslot, off_fsrc
         hdr[HDR_OFF_WB] = off_wb
         block = (hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b] +
-                 [v for g in groups for v in g] + gen_idx + mnt_idx + [0] * pad)
+                 [v for g in groups for v in g] + gen_idx + mnt_idx + [v for g in xgroups for v in g] + [0] * pad)
         assert len(block) == blk_len
         fold_off.append(fold_off[-1] + fold_len)
         ftab.extend([v for sl in fslots for v in sl] + [v for e in fsrc for v in e])
@@ -591,7 +612,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         # per-sample weight slots: components with monotone cross terms, and integrated components whose B functions are
         # the dense order sets 1..P (ttm_eval.h "dense B set": their weights are copied there with the constants folded in)
         dense_b = (not separable and len(b_st) == 0 and len(b_hf) == hdr[HDR_MAXP_HF] and len(b_poly) == hdr[HDR_MAXP_POLY])
-        nslots.append(len(bfuns) + 1 if (len(mnt_idx) or dense_b) else 0)
+        nslots.append(len(bfuns) + 1 if (len(mnt_idx) or len(xgroups) or dense_b) else 0)
         complex_all.append(int(complex_comp) | (2 if dense_b else 0))
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
