@@ -380,12 +380,30 @@ struct VarCache {
 // (all 'HF' factors of one term share a single exp(-sum x^2 / 4))
 // ---------------------------------------------------------------------------
 
+// exp(-x_var^2 / 4) of ONE column: from the column cache when the accessor has one
+template <class XA, class R>
+TTM_HD R hf_exp_of(XA&, int, const R& xv) { return fast_exp(-0.25 * (xv * xv)); }
+template <class XA2, class R>
+TTM_HD R hf_exp_of(VarCache<XA2, R>& x, int var, const R&) {
+    R xv, e;
+    x.get_e(var, xv, e);
+    return e;
+}
+
 template <class R, class XA>
 TTM_HD R eval_A(cint_p term, const Comp& c, const Prog& p, XA& x) {
     const int f0 = TTM_UNI(term[0]);
     const int nf = TTM_UNI(term[1]);
     R prod(1.0), ssq(0.0);
     bool hf = false;
+    if (nf == 1) {                                            // the usual cross / nonmonotone term: one factor
+        cint_p F = c.facs + 4 * f0;
+        const int var = TTM_UNI(F[0]), kind = TTM_UNI(F[1]);
+        if (kind == TTM_KIND_HF) {
+            const R xv = x(var);
+            return (c.dpar[TTM_UNI(F[3])] * poly_eval(p.family, TTM_UNI(F[2]), xv)) * hf_exp_of(x, var, xv);
+        }
+    }
     for (int f = 0; f < nf; ++f) {
         cint_p F = c.facs + 4 * (f0 + f);
         const int var = TTM_UNI(F[0]);
