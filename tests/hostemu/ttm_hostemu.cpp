@@ -71,6 +71,9 @@ void comp_of(const ttm_program* p, int k, const double* coef_k, HostComp& h, con
         fold_k = h.fold.data();
     }
     h.c = make_comp(cb, dp, coef_k, fold_k);
+    const int* fb = p->ftab + p->h_ftab_off[k];
+    h.c.fslot = fb + cb[TTM_HDR_OFF_FSLOT];
+    h.c.fsrc = fb + cb[TTM_HDR_OFF_FSRC];
 }
 
 // same dispatch rule as the library: planned-cache fast path when every component of the range is simple

@@ -77,6 +77,8 @@ struct Comp {            // one component block (pointers into staged tables)
     cint_p gen;
     cint_p mnt;
     cint_p xgrp;         // cross groups {var, P, fold offset, has_hf, b, 0, 0, 0}
+    cint_p fslot;        // fold recipe of the component (kernels that need the members of a folded sum set these):
+    cint_p fsrc;         // slot s sums fsrc[2 (fslot[2s] + j)] = coefficient index (< 0: a constant), [.. + 1] = dpar index or -1
     cdbl_p dpar;
     cdbl_p cnm;          // coefficients of the nonmonotone / monotone terms
     cdbl_p cmon;
@@ -101,6 +103,8 @@ TTM_HD Comp make_comp(cint_p cb, cdbl_p dpar, cdbl_p coef, cdbl_p fold) {
     c.n_mnt = TTM_UNI(cb[TTM_HDR_N_MNT]);
     c.n_xgrp = TTM_UNI(cb[TTM_HDR_N_XGRP]);
     c.xgrp = cb + TTM_UNI(cb[TTM_HDR_OFF_XGRP]);
+    c.fslot = nullptr;
+    c.fsrc = nullptr;
     c.off_wb = TTM_UNI(cb[TTM_HDR_OFF_WB]);
     c.nm_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_NM]);
     c.mon_terms = cb + TTM_UNI(cb[TTM_HDR_OFF_MON]);
@@ -759,6 +763,82 @@ TTM_HD void sample_basis(const Comp& c, const Prog& p, int which, XA& x, Out&& o
 // Objective + gradient contribution of one sample, integrated rectifier
 // (TM:3343-3376, 3475-3569).  acc layout: [0] J, [1..n_nm] d/dc_nonmon, then d/dc_mon.
 // scratch slots: w (nB+1) | Bv (nB+1) | I (nB+1)
+// Members of a folded series {var, P, fold offset, has_hf} (a nonmonotone group or a cross group): f(ci, value) for every
+// coefficient ci that the fold recipe sums into the series, with the value of its term - one recurrence and the cached
+// exp(-x^2/4) of the variable for the whole group instead of a walk through term and factor records per term.
+template <class XA, class F>
+TTM_HD void for_each_member(const Comp& c, const Prog& p, VarCache<XA, double>& x, int var, int P, int off, int has_hf, F&& f) {
+    double xv, e = 0.0;
+    if (has_hf) x.get_e(var, xv, e); else xv = x.get(var);
+    double pm = 1.0, dpm = 0.0, pn, dp;
+    poly_first(p.family, xv, pn, dp);
+    for (int n = 1; n <= P; ++n) {
+        int s0 = TTM_UNI(c.fslot[2 * (off + n - 1)]), ns = TTM_UNI(c.fslot[2 * (off + n - 1) + 1]);
+        for (int j = 0; j < ns; ++j) f(TTM_UNI(c.fsrc[2 * (s0 + j)]), pn);
+        if (has_hf) {
+            s0 = TTM_UNI(c.fslot[2 * (off + P + n - 1)]); ns = TTM_UNI(c.fslot[2 * (off + P + n - 1) + 1]);
+            for (int j = 0; j < ns; ++j)
+                f(TTM_UNI(c.fsrc[2 * (s0 + j)]), (c.dpar[TTM_UNI(c.fsrc[2 * (s0 + j) + 1])] * pn) * e);
+        }
+        if (n < P) poly_next<false>(p.family, n, xv, pm, pn, dpm, dp);
+    }
+}
+
+// gradient contributions of one sample once S, the integrals I_b, the values B_b(x_k) and r'/(r + delta) are known
+// (TM:3475-3569): d/dc_nonmon,i = S Psi_i ; d/dc_mon,i = A_i (S I_b - rinv B_b)
+template <class XA, class Slots, class Acc>
+TTM_HD void objective_gradient(const Comp& c, const Prog& p, VarCache<XA, double>& x, double S, double rinv, Slots& Bv, Slots& I, Acc& acc) {
+    if (c.fslot) {
+        // through the fold recipe: constants, nonmonotone groups, generic nonmonotone terms
+        const int s0 = TTM_UNI(c.fslot[0]), ns = TTM_UNI(c.fslot[1]);
+        for (int j = 0; j < ns; ++j) acc.add(1 + TTM_UNI(c.fsrc[2 * (s0 + j)]), S);
+        for (int g = 0; g < c.n_grp; ++g) {
+            cint_p G = c.grp + 4 * g;
+            for_each_member(c, p, x, TTM_UNI(G[0]), TTM_UNI(G[1]), TTM_UNI(G[2]), TTM_UNI(G[3]),
+                            [&](int ci, double v) { acc.add(1 + ci, S * v); });
+        }
+        for (int i = 0; i < c.n_gen; ++i) {
+            cint_p T = c.nm_terms + 4 * TTM_UNI(c.gen[i]);
+            acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
+        }
+        // monotone terms of x_k alone, cross groups, generic cross terms
+        for (int i = 0; i < c.n_mon; ++i) {
+            cint_p T = c.mon_terms + 4 * i;
+            if (TTM_UNI(T[1]) == 0) {
+                int b = TTM_UNI(T[2]);
+                if (b < 0) b = c.nB;
+                acc.add(1 + c.n_nm + TTM_UNI(T[3]), S * I.get(b) - rinv * Bv.get(b));
+            }
+        }
+        for (int g = 0; g < c.n_xgrp; ++g) {
+            cint_p G = c.xgrp + 8 * g;
+            const int b = TTM_UNI(G[4]);
+            const double fac = S * I.get(b) - rinv * Bv.get(b);
+            for_each_member(c, p, x, TTM_UNI(G[0]), TTM_UNI(G[1]), TTM_UNI(G[2]), TTM_UNI(G[3]),
+                            [&](int ci, double v) { acc.add(1 + ci, v * fac); });
+        }
+        for (int j = 0; j < c.n_mnt; ++j) {
+            cint_p T = c.mon_terms + 4 * TTM_UNI(c.mnt[j]);
+            int b = TTM_UNI(T[2]);
+            if (b < 0) b = c.nB;
+            acc.add(1 + c.n_nm + TTM_UNI(T[3]), eval_A<double>(T, c, p, x) * (S * I.get(b) - rinv * Bv.get(b)));
+        }
+        return;
+    }
+    for (int i = 0; i < c.n_nm; ++i) {
+        cint_p T = c.nm_terms + 4 * i;
+        acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
+    }
+    for (int i = 0; i < c.n_mon; ++i) {
+        cint_p T = c.mon_terms + 4 * i;
+        const int nf = TTM_UNI(T[1]);
+        int b = TTM_UNI(T[2]);
+        if (b < 0) b = c.nB;
+        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
+        acc.add(1 + c.n_nm + TTM_UNI(T[3]), a * (S * I.get(b) - rinv * Bv.get(b)));
+    }
+}
+
 // The same for a component with a dense B set: per group of TTM_DENSE_NODES quadrature nodes one pass of the
 // recurrence for g, one for the integrals of cq B_b (the polynomial values are cheaper to recompute than to keep);
 // sums over the nodes of a group are taken in node order.
@@ -842,19 +922,8 @@ TTM_HD void sample_objective_int_dense(const Comp& c, const Prog& p, VarCache<XA
     double r, dr, logr;
     rect_all(rect, p.delta, g, r, dr, logr);
     acc.add(0, 0.5 * S * S - logr);
-    for (int i = 0; i < c.n_nm; ++i) {
-        cint_p T = c.nm_terms + 4 * i;
-        acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
-    }
     const double rinv = dr * fast_rcp(r + p.delta);
-    for (int i = 0; i < c.n_mon; ++i) {
-        cint_p T = c.mon_terms + 4 * i;
-        const int nf = TTM_UNI(T[1]);
-        int b = TTM_UNI(T[2]);
-        if (b < 0) b = c.nB;
-        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
-        acc.add(1 + c.n_nm + TTM_UNI(T[3]), a * (S * I.get(b) - rinv * Bv.get(b)));
-    }
+    objective_gradient(c, p, x, S, rinv, Bv, I, acc);
 }
 
 template <class XA, class Slots, class Acc>
@@ -897,19 +966,8 @@ TTM_HD void sample_objective_int(const Comp& c, const Prog& p, VarCache<XA, doub
     double r, dr, logr;
     rect_all(p.rect, p.delta, g, r, dr, logr);
     acc.add(0, 0.5 * S * S - logr);
-    for (int i = 0; i < c.n_nm; ++i) {
-        cint_p T = c.nm_terms + 4 * i;
-        acc.add(1 + TTM_UNI(T[3]), S * eval_A<double>(T, c, p, x));
-    }
     const double rinv = dr * fast_rcp(r + p.delta);
-    for (int i = 0; i < c.n_mon; ++i) {
-        cint_p T = c.mon_terms + 4 * i;
-        const int nf = TTM_UNI(T[1]);
-        int b = TTM_UNI(T[2]);
-        if (b < 0) b = c.nB;
-        const double a = (nf == 0) ? 1.0 : eval_A<double>(T, c, p, x);
-        acc.add(1 + c.n_nm + TTM_UNI(T[3]), a * (S * I.get(b) - rinv * Bv.get(b)));
-    }
+    objective_gradient(c, p, x, S, rinv, Bv, I, acc);
 }
 
 // Separable objective pieces of one sample (TM:2990-3006):

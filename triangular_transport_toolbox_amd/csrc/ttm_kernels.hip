@@ -1931,7 +1931,14 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
     CacheStore<double> cst;
     const Prog g = make_prog_lds(P, cst, slots);
     const int bd = blockDim.x, tid = threadIdx.x;
-    const Comp c = comp_at(P, k, k, coef_k, fold_k);
+    Comp c = comp_at(P, k, k, coef_k, fold_k);
+    {   // the fold recipe of the component: the gradient walks the members of the folded sums (ttm_eval.h, objective_gradient)
+        cint_p off = (cint_p)P.off;
+        cint_p cb = (cint_p)P.itab + off[k];
+        cint_p fb = (cint_p)P.ftab + off[4 * (P.D + 1) + k];
+        c.fslot = fb + cb[TTM_HDR_OFF_FSLOT];
+        c.fsrc = fb + cb[TTM_HDR_OFF_FSRC];
+    }
     const int nb1 = c.nB + 1;
     double* accbase = slots + (size_t)nscr * bd;
     for (int i = 0; i < nacc; ++i) accbase[i * bd + tid] = 0.0;
