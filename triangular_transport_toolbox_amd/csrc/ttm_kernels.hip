@@ -2218,6 +2218,54 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, int k, const double* __
     }
 }
 
+// The Gram matrix G = Psi' Psi is the one dense contraction of the path: for m <= 16 basis functions it goes through the
+// fp64 matrix cores (v_mfma_f64_16x16x4f64: a 16 x 16 tile of G from 4 samples per instruction, A = B' = the basis values
+// themselves).  fp64 MFMA runs at the vector rate - what it saves is LDS traffic: a lane reads ONE basis value per 4-sample
+// step (32 KB per 256-sample tile) where the pairwise kernel above reads two per multiply-add (496 KB per tile at m = 11,
+// which made it LDS-bound).  Layout of a step: lane l holds Psi_i(sample) with i = l % 16 and sample = s + 16 (l / 16) of
+// the wave's 64 samples (row stride bd + 1: the 32 lanes of an LDS pass fall on distinct banks).
+typedef double ttm_v4f64 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                   int m, double* __restrict__ partial) {
+    double* rows;
+    CacheStore<double> cst;
+    const Prog g = make_prog_lds(P, cst, rows);
+    const int bd = blockDim.x, tid = threadIdx.x, rs = bd + 1;
+    const Comp c = comp_at(P, k, 0, nullptr, nullptr);
+    const int lane = tid & 63, wv = tid >> 6;
+    const int bi = lane & 15, kq = lane >> 4;
+    ttm_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
+        const int64_t n = n0 + tid;
+        if (n < N) {
+            XSoA x{X, ldx, n};
+            sample_basis(c, g, 0, x, [&](int i, double v) { rows[i * rs + tid] = v; });
+            sample_basis(c, g, 1, x, [&](int i, double v) { rows[(c.n_nm + i) * rs + tid] = v; });
+        } else {
+            for (int i = 0; i < m; ++i) rows[i * rs + tid] = 0.0;
+        }
+        __syncthreads();
+        const double* src = rows + bi * rs + wv * 64 + 16 * kq;
+#pragma unroll 4
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const double v = bi < m ? src[s2] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // the four waves' tiles: summed through LDS; element r of lane l is G[l / 16 + 4 r][l % 16] (measured; G is symmetric)
+    double* red = rows;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wv * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    {
+        const int r = tid >> 6;                          // thread (r, lane): one element of the 16 x 16 tile
+        const double v = (red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane]) + (red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane]);
+        const int gi = (lane >> 4) + 4 * r, gj = lane & 15;
+        if (gi < m && gj < m) partial[(int64_t)blockIdx.x * (m * m) + gi * m + gj] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Column utilities of the device-resident ensemble filter (entf.Filter: example_06.py:252-328 without a host copy of
 // the ensemble): everything is column-major, one thread per row.
@@ -2297,7 +2345,8 @@ static const DeviceInfo& device_info() {
     X(rt_block, -1)      /* components per block of k_inverse_rt                                                     */ \
     X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */ \
     X(rt_band, -1)       /* 0: banded maps through the LDS column cache instead of the register shift                */ \
-    X(rt_window, -1)     /* resident entries per table of k_inverse_rt: 0 whole tables, > 0 that many, -1 planned    */
+    X(rt_window, -1)     /* resident entries per table of k_inverse_rt: 0 whole tables, > 0 that many, -1 planned    */ \
+    X(gram_mfma, -1)     /* 0: Gram matrices by the pairwise kernel instead of the matrix cores                      */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -3076,6 +3125,12 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
     double* partial = work + TTM_OBJ_FOLD_MAX;
+    if (m <= 16 && bd == 256 && tuning().gram_mfma != 0 && lds_bytes(m, bd, m + 1024) <= (size_t)kLdsBudget) {
+        hipLaunchKernelGGL(k_gram_mfma, dim3(nb), dim3(bd), lds_bytes(m, bd, m + 1024), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m,
+                           partial);
+        hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
+        return check_launch("k_gram_mfma");
+    }
     hipLaunchKernelGGL(k_gram, dim3(nb), dim3(bd), lds_bytes(m, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
     hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
     return check_launch("k_gram");
