@@ -259,3 +259,29 @@ def test_c_abi_reports_bad_arguments_instead_of_launching():
         _capi.check(lib.ttm_forward(p, c, f, None, ldx, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st))
     # ... and a valid call still works afterwards
     _capi.check(lib.ttm_forward(p, c, f, X, ldx, N, 0, tm.D, tm._ptr(Z), Z.shape[1], None, None, None, st))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['c5_sep', 'c3_sep', 'c2b_sep', 'c2a_int'])
+def test_gram_on_the_matrix_cores_equals_the_pairwise_kernel(name, ttm_opt):
+    """G = Psi' Psi (TM:2966-2975) by v_mfma_f64_16x16x4f64 - one tile for up to 16 basis functions, three for up to 32 -
+    against the pairwise FMA kernel and against NumPy on the basis matrices: the same sums up to their order."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case(name)
+    X = case_X(name, npz)
+    X = np.concatenate([X + 0.01 * i for i in range(5)])[:4099]          # several tiles and a ragged last one
+    tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
+    seen = set()
+    for k in range(tm.D):
+        ttm_opt('gram_mfma', 0)
+        G0 = tm._gram(k)
+        assert tm._lib.ttm_last_kernel().decode() == 'k_gram'
+        ttm_opt('gram_mfma', 1)
+        G1 = tm._gram(k)
+        m = G0.shape[0]
+        if m <= 32:
+            assert tm._lib.ttm_last_kernel().decode() == 'k_gram_mfma'
+            seen.add(m > 16)
+        assert np.array_equal(G1, G1.T)
+        assert np.max(np.abs(G1 - G0)) <= 1e-14 * np.max(np.abs(G0))             # (entries that cancel to ~0 differ by rounding only)
+    assert seen                                                          # (the matrix-core kernel ran)

@@ -2225,16 +2225,22 @@ __global__ __launch_bounds__(256) void k_gram(DevProg P, int k, const double* __
 // which made it LDS-bound).  Layout of a step: lane l holds Psi_i(sample) with i = l % 16 and sample = s + 16 (l / 16) of
 // the wave's 64 samples (row stride bd + 1: the 32 lanes of an LDS pass fall on distinct banks).
 typedef double ttm_v4f64 __attribute__((ext_vector_type(4)));
+// WIDE = false: m <= 16, one tile.  WIDE = true: 16 < m <= 32 - three tiles (G_lo,lo | G_lo,hi | G_hi,hi; the fourth is
+// the transpose of the second), a lane holds Psi_i and Psi_{16 + i} of its sample.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
                                                    int m, double* __restrict__ partial) {
     double* rows;
     CacheStore<double> cst;
     const Prog g = make_prog_lds(P, cst, rows);
-    const int bd = blockDim.x, tid = threadIdx.x, rs = bd + 1;
+    const int bd = blockDim.x, tid = threadIdx.x, rs = bd + 1, nw = bd >> 6;
     const Comp c = comp_at(P, k, 0, nullptr, nullptr);
     const int lane = tid & 63, wv = tid >> 6;
     const int bi = lane & 15, kq = lane >> 4;
-    ttm_v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NT = WIDE ? 3 : 1;
+    ttm_v4f64 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { ttm_v4f64 z = {0.0, 0.0, 0.0, 0.0}; acc[t] = z; }
     for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
         const int64_t n = n0 + tid;
         if (n < N) {
@@ -2248,21 +2254,37 @@ __global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const doubl
         const double* src = rows + bi * rs + wv * 64 + 16 * kq;
 #pragma unroll 4
         for (int s2 = 0; s2 < 16; ++s2) {
-            const double v = bi < m ? src[s2] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+            const double lo = bi < m ? src[s2] : 0.0;
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, lo, acc[0], 0, 0, 0);
+            if (WIDE) {
+                const double hi = 16 + bi < m ? src[16 * rs + s2] : 0.0;
+                acc[NT > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(lo, hi, acc[NT > 1 ? 1 : 0], 0, 0, 0);
+                acc[NT > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, hi, acc[NT > 2 ? 2 : 0], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
-    // the four waves' tiles: summed through LDS; element r of lane l is G[l / 16 + 4 r][l % 16] (measured; G is symmetric)
+    // the waves' tiles: summed through LDS in wave order; element r of lane l of a tile is row l / 16 + 4 r, column l % 16
+    // of that tile (measured; rows are the A operand's basis index)
     double* red = rows;
+    const int mm = m * m;
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wv * 4 + r) * 64 + lane] = acc[r];
-    __syncthreads();
-    {
-        const int r = tid >> 6;                          // thread (r, lane): one element of the 16 x 16 tile
-        const double v = (red[(0 * 4 + r) * 64 + lane] + red[(1 * 4 + r) * 64 + lane]) + (red[(2 * 4 + r) * 64 + lane] + red[(3 * 4 + r) * 64 + lane]);
-        const int gi = (lane >> 4) + 4 * r, gj = lane & 15;
-        if (gi < m && gj < m) partial[(int64_t)blockIdx.x * (m * m) + gi * m + gj] = v;
+        for (int r = 0; r < 4; ++r) red[(wv * 4 + r) * 64 + lane] = acc[t][r];
+        __syncthreads();
+        for (int e = tid; e < 256; e += bd) {
+            const int r = e >> 6, l = e & 63;
+            double v = 0.0;
+            for (int w = 0; w < nw; ++w) v += red[(w * 4 + r) * 64 + l];
+            int gi = (l >> 4) + 4 * r, gj = l & 15;
+            if (t == 1) gj += 16;
+            if (t == 2) { gi += 16; gj += 16; }
+            if (gi < m && gj < m) {
+                partial[(int64_t)blockIdx.x * mm + gi * m + gj] = v;
+                if (t == 1) partial[(int64_t)blockIdx.x * mm + gj * m + gi] = v;
+            }
+        }
     }
 }
 
@@ -3125,9 +3147,11 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
     double* partial = work + TTM_OBJ_FOLD_MAX;
-    if (m <= 16 && bd == 256 && tuning().gram_mfma != 0 && lds_bytes(m, bd, m + 1024) <= (size_t)kLdsBudget) {
-        hipLaunchKernelGGL(k_gram_mfma, dim3(nb), dim3(bd), lds_bytes(m, bd, m + 1024), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m,
-                           partial);
+    // rows of bd + 1 doubles; the final sum of the waves' tiles reuses them (1024 doubles)
+    const int gx = m * (bd + 1) >= 1024 ? m : 1024 - m * bd;
+    if (m <= 32 && bd >= 64 && tuning().gram_mfma != 0 && lds_bytes(m, bd, gx) <= (size_t)kLdsBudget) {
+        hipLaunchKernelGGL(m <= 16 ? k_gram_mfma<false> : k_gram_mfma<true>, dim3(nb), dim3(bd), lds_bytes(m, bd, gx), (hipStream_t)stream,
+                           dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
         hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
         return check_launch("k_gram_mfma");
     }
