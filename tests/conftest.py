@@ -32,16 +32,16 @@ def ttm_opt():
             libs.append(dev)
     except Exception:                                   # noqa: BLE001  (no device library here: the double alone)
         pass
-    try:
-        from tests.hostemu import emu
-        libs.append(emu.lib())
-    except Exception:                                   # noqa: BLE001
-        pass
+    from tests.hostemu import emu
+
+    def targets():
+        # the host test double only when a test has put it in place (emu.install()): a GPU run never loads it
+        return libs + ([emu._lib] if emu._lib is not None else [])
 
     def opt(name, value):
-        for lib in libs:
+        for lib in targets():
             rc = lib.ttm_set_option(name.encode(), int(value))
             assert rc == 0, name
     yield opt
-    for lib in libs:
+    for lib in targets():
         lib.ttm_reset_options()
