@@ -114,10 +114,18 @@ struct XSoAN {
     }
 };
 
-struct LdsAcc {
-    double* base;
-    int stride;
-    __device__ __forceinline__ void add(int i, double v) { base[i * stride] += v; }
+__device__ __forceinline__ double wave_sum(double v);
+// accumulators of a WAVE: every add sums its argument over the lanes at once (all 64 lanes call, lanes without a sample
+// contribute zero) and lane 0 keeps the running sums in one LDS row per wave.  Per-thread accumulator columns would
+// be nacc x blockDim doubles of LDS - 22 of the 48 doubles per thread that capped the integrated objective kernel at
+// three workgroups (1.5 waves per SIMD) per CU.
+struct WaveAcc {
+    double* row;
+    bool active, first;
+    __device__ __forceinline__ void add(int i, double v) {
+        const double s = wave_sum(active ? v : 0.0);
+        if (first) row[i] += s;
+    }
 };
 
 struct XSoA {
@@ -1940,26 +1948,29 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
         c.fsrc = fb + cb[TTM_HDR_OFF_FSRC];
     }
     const int nb1 = c.nB + 1;
-    double* accbase = slots + (size_t)nscr * bd;
-    for (int i = 0; i < nacc; ++i) accbase[i * bd + tid] = 0.0;
-    LdsAcc acc{accbase + tid, bd};
+    const int lane = tid & 63, wv = tid >> 6, nw = bd >> 6;
+    double* accbase = slots + (size_t)nscr * bd;                         // nw rows of nacc running sums
+    for (int i = tid; i < nw * nacc; i += bd) accbase[i] = 0.0;
+    __syncthreads();
+    WaveAcc acc{accbase + wv * nacc, true, lane == 0};
     LdsSlots w{slots + tid, bd};
     LdsSlots Bv{slots + (size_t)nb1 * bd + tid, bd};
     LdsSlots I{slots + (size_t)2 * nb1 * bd + tid, bd};
-    for (int64_t n = (int64_t)blockIdx.x * bd + tid; n < N; n += (int64_t)gridDim.x * bd) {
-        const XSoA xa{X, ldx, n};
+    // (uniform trip count: the lanes of a wave add together; a lane beyond the ensemble repeats the last sample and adds zero)
+    for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
+        const int64_t n = n0 + tid;
+        acc.active = n < N;
+        const XSoA xa{X, ldx, acc.active ? n : N - 1};
         VarCache<XSoA, double> x(xa, cst);
         if (g.mono == TTM_MONO_SEPARABLE) sample_objective_sep(c, g, x, w, acc);
         else sample_objective_int(c, g, x, w, Bv, I, acc);
     }
     __syncthreads();
-    // block reduction: wave wv takes accumulators wv, wv+nw, ... ; lanes stride over threads
-    const int lane = tid & 63, wv = tid >> 6, nw = bd >> 6;
-    for (int i = wv; i < nacc; i += nw) {
+    // block sums: the waves' rows in wave order
+    for (int i = tid; i < nacc; i += bd) {
         double v = 0.0;
-        for (int t = lane; t < bd; t += 64) v += accbase[i * bd + t];
-        v = wave_sum(v);
-        if (lane == 0) partial[(int64_t)blockIdx.x * nacc + i] = v;
+        for (int wq = 0; wq < nw; ++wq) v += accbase[wq * nacc + i];
+        partial[(int64_t)blockIdx.x * nacc + i] = v;
     }
     if (out) {
         // single-launch variant: the workgroup that draws the last ticket adds the partials up, in the very order
@@ -3010,7 +3021,7 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
     const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
     if (nfold > TTM_OBJ_FOLD_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
-    const int bd = pick_block(nscr + nacc, 0);
+    const int bd = pick_block(nscr, 4 * nacc);                  // per-thread scratch columns + one row of sums per wave
     if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", k);
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
@@ -3018,7 +3029,7 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     double* fold_k = work;
     double* partial = work + TTM_OBJ_FOLD_MAX;
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, (int)k, coef_k, fold_k);
-    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k, coef_k,
+    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr, bd, 4 * nacc), (hipStream_t)stream, P, (int)k, coef_k,
                        (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)nullptr, (double*)nullptr,
                        (double*)nullptr, 0.0);
     hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
@@ -3047,7 +3058,7 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
     const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
     if (nfold > TTM_OBJ_FOLD_MAX - TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
-    const int bd = pick_block(nscr + nacc, 0);
+    const int bd = pick_block(nscr, 4 * nacc);                  // per-thread scratch columns + one row of sums per wave
     if (!bd) return set_err(TTM_E_LIMIT, "component %s%lld does not fit the LDS budget", "", k);
     int nb = grid_for(N, bd);
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
@@ -3059,7 +3070,7 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = i < ncoef ? h_coef_k[i] : 0.0;
     hipLaunchKernelGGL(k_fold_host, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, hc, ncoef, coef_dev, fold_k);
     const bool ticket = nb <= 64;                    // (see ttm_objective_sep_cached)
-    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr + nacc, bd, 0), (hipStream_t)stream, P, (int)k,
+    hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr, bd, 4 * nacc), (hipStream_t)stream, P, (int)k,
                        (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial,
                        ticket ? (unsigned int*)counter : (unsigned int*)nullptr, ticket ? out : (double*)nullptr, flag, mark);
     if (!ticket) {
