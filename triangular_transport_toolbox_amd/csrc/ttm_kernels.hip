@@ -2243,7 +2243,8 @@ __global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const doubl
                                                    int m, double* __restrict__ partial) {
     double* rows;
     CacheStore<double> cst;
-    const Prog g = make_prog_lds(P, cst, rows);
+    Prog g = make_prog_lds(P, cst, rows);
+    rows = g_smem + TTM_ERF_TABLE_LEN;                     // (no column cache in this kernel: its LDS goes to more workgroups per CU)
     const int bd = blockDim.x, tid = threadIdx.x, rs = bd + 1, nw = bd >> 6;
     const Comp c = comp_at(P, k, 0, nullptr, nullptr);
     const int lane = tid & 63, wv = tid >> 6;
@@ -3159,9 +3160,9 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
     double* partial = work + TTM_OBJ_FOLD_MAX;
     // rows of bd + 1 doubles; the final sum of the waves' tiles reuses them (1024 doubles)
-    const int gx = m * (bd + 1) >= 1024 ? m : 1024 - m * bd;
-    if (m <= 32 && bd >= 64 && tuning().gram_mfma != 0 && lds_bytes(m, bd, gx) <= (size_t)kLdsBudget) {
-        hipLaunchKernelGGL(m <= 16 ? k_gram_mfma<false> : k_gram_mfma<true>, dim3(nb), dim3(bd), lds_bytes(m, bd, gx), (hipStream_t)stream,
+    const size_t glds = ((size_t)TTM_ERF_TABLE_LEN + (m * (bd + 1) >= 1024 ? (size_t)m * (bd + 1) : 1024)) * 8;
+    if (m <= 32 && bd >= 64 && tuning().gram_mfma != 0 && glds <= (size_t)kLdsBudget) {
+        hipLaunchKernelGGL(m <= 16 ? k_gram_mfma<false> : k_gram_mfma<true>, dim3(nb), dim3(bd), glds, (hipStream_t)stream,
                            dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
         hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
         return check_launch("k_gram_mfma");
