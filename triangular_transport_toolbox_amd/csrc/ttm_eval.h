@@ -914,7 +914,8 @@ TTM_HD void sample_objective_int_dense(const Comp& c, const Prog& p, VarCache<XA
     // the Hermite-function integrals carry their normalisation constants from here on
     for (int b = 0; b < c.nB_hf; ++b) I.set(b, c.dpar[TTM_UNI(c.bfuns[4 * b + 2])] * I.get(b));
     const double S = nonmon_sum<double>(c, p, x) + mono;
-    // values at x_k for the log term
+    // values at x_k for the log term (the weights are not needed after g: Bv may be the very columns of w - k_objective
+    // passes them so and saves a third of the scratch)
     double g, dg;
     g_eval_dense<FAM, false>(p.family, Ph, Pp, xk, w, w.get(Ph + Pp), g, dg);
     for_each_B<false>(c, p, xk, [&](int b, double v, double) { Bv.set(b, v); });

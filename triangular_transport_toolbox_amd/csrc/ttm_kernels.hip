@@ -1953,9 +1953,10 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
     for (int i = tid; i < nw * nacc; i += bd) accbase[i] = 0.0;
     __syncthreads();
     WaveAcc acc{accbase + wv * nacc, true, lane == 0};
+    const bool shared_bv = g.mono == TTM_MONO_INTEGRATED && dense_B(c);      // (the host sized the scratch by the same rule)
     LdsSlots w{slots + tid, bd};
-    LdsSlots Bv{slots + (size_t)nb1 * bd + tid, bd};
-    LdsSlots I{slots + (size_t)2 * nb1 * bd + tid, bd};
+    LdsSlots Bv{slots + (shared_bv ? (size_t)0 : (size_t)nb1 * bd) + tid, bd};
+    LdsSlots I{slots + (size_t)(shared_bv ? 1 : 2) * nb1 * bd + tid, bd};
     // (uniform trip count: the lanes of a wave add together; a lane beyond the ensemble repeats the last sample and adds zero)
     for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
         const int64_t n = n0 + tid;
@@ -3019,7 +3020,9 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     const int n_nm = p->h_n_nm[k];
     const int n_mon = p->h_coef_off[k + 1] - p->h_coef_off[k] - n_nm;
     const int nacc = sep ? 1 + n_mon : 1 + n_nm + n_mon;
-    const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
+    // scratch columns per thread: separable dB | integrated w, B values, integrals - a dense B set keeps its B values in the
+    // weights' columns (they are dead by then): two sets instead of three
+    const int nscr = (sep ? 1 : ((p->h_complex[k] & 2) ? 2 : 3)) * p->h_nb1[k];
     const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
     if (nfold > TTM_OBJ_FOLD_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
     const int bd = pick_block(nscr, 4 * nacc);                  // per-thread scratch columns + one row of sums per wave
@@ -3056,7 +3059,9 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     const int n_mon = ncoef - n_nm;
     if (ncoef > TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "ttm_objective_host: component %s%lld has more than 64 coefficients", "", k);
     const int nacc = sep ? 1 + n_mon : 1 + n_nm + n_mon;
-    const int nscr = (sep ? 1 : 3) * p->h_nb1[k];
+    // scratch columns per thread: separable dB | integrated w, B values, integrals - a dense B set keeps its B values in the
+    // weights' columns (they are dead by then): two sets instead of three
+    const int nscr = (sep ? 1 : ((p->h_complex[k] & 2) ? 2 : 3)) * p->h_nb1[k];
     const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
     if (nfold > TTM_OBJ_FOLD_MAX - TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "component %s%lld has too many folded coefficients", "", k);
     const int bd = pick_block(nscr, 4 * nacc);                  // per-thread scratch columns + one row of sums per wave
