@@ -2893,7 +2893,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         }
         const int wgs = 1;                                               // the tables (+ the column cache) fill the LDS of a CU
         // banded maps: four rows per thread when the chunk of a workgroup then is ONE tile - the register columns survive
-        // the block boundaries and nothing is re-read (0.1755 against 0.1781 ms with two at C5)
+        // the block boundaries and nothing is re-read (0.1755 against 0.1781 ms with two at C5; on the final kernel two rows
+        // per thread are 0.7 % faster, but a tile that re-reads its columns at a block boundary takes exp(-x^2/4) from the
+        // series there instead of the interval: the last bits then depend on where the boundaries fall, i.e. on the window)
         if (band && tn.rt_ns <= 0 && (N + di.cus - 1) / di.cus <= 4 * 1024) NS = 4;
         int CT = tn.rt_threads >= 64 && tn.rt_threads <= 1024 ? (tn.rt_threads & ~63) : 1024;
         const size_t budget = di.lds_per_cu / wgs;
