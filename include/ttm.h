@@ -217,6 +217,27 @@ extern "C" {
 #define TTM_H_HDR         8
 #define TTM_H_NG_MAX      4
 
+/* "push" records of a BANDED U-form map (P section, behind the H section; written by ttm_fold when u_p_lag > 0).
+ * Banded: the components' columns are consecutive (kc_k = kc_0 + k), every nonmonotone group of component k reads a
+ * column kc_k - 1 .. kc_k - u_p_lag, every component has a special-term spline and hot records exist (u_h_cls > 0).
+ * The band kernels (csrc/ttm_band.hip) walk the columns and add what a column contributes to the components that
+ * read it as soon as the column is known, so the records are indexed by COLUMN: record r (0 <= r < D + u_p_lag)
+ * belongs to column kc_0 - u_p_lag + r, i.e. to component k = r - u_p_lag when that is >= 0 (the first u_p_lag records
+ * stand for the columns in front of the first component: conditioning columns, or nothing - all coefficients zero).
+ * u_p_stride doubles per record:
+ *   [0] constant the running sum of the component u_p_lag columns on starts from, forward map: c0 (nonmonotone +
+ *       monotone constants) + the constant terms of its groups' plain polynomials; 0 when there is no such component
+ *   [1] the same for the inverse (nonmonotone constant + the groups' constant terms: the offset TM:4039 subtracts)
+ *   [2] 1 - t_lo/h   [3] 1/h   [4] 2/h      spline geometry of the record's own component: column = trunc(x [3] + [2])
+ *   [5] int32 {NI, TAB_OFF}   [6] int32 {k (-1: none), 0}   [7] 0
+ *   [8 + l GP ...], l = 0..u_p_lag-1: the group of component k + l + 1 that reads this column (zeros if none):
+ *       B[0..DB] (Hermite-function part, monomial coefficients), A[1..DA] (plain part without its constant term);
+ *       GP = DB + 1 + DA, (DB, DA) as in the hot records.
+ * ttm_fold also writes, into padding slot 12 of every spline column c of such a map, the offset s0 of its local
+ * coordinate: s = x [4] + s0.                                                                                     */
+#define TTM_P_HDR         8
+#define TTM_P_LAG_MAX     2
+
 typedef struct ttm_program {
     /* device tables */
     const int32_t* itab;        /* all component blocks, back to back              */
@@ -266,6 +287,9 @@ typedef struct ttm_program {
     int64_t u_h_off;            /* offset (within the U section) of the hot records  */
     int32_t u_h_cls;            /* 0: no hot records; 1..3: degree class             */
     int32_t u_h_ng;             /* group records per component                       */
+    int64_t u_p_off;            /* offset (within the U section) of the push records */
+    int32_t u_p_lag;            /* 0: not a banded map; else the largest lag of a group (<= TTM_P_LAG_MAX) */
+    int32_t u_p_stride;         /* doubles per push record                           */
 } ttm_program;
 
 const char* ttm_last_error_string(void);

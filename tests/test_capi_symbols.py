@@ -26,8 +26,8 @@ def test_library_builds_and_exports_all_symbols():
 
 
 def test_struct_layout_matches_header():
-    # 17 + 6 pointers, 8 + 2 int32, 1 double, 3 int64 on LP64 - and what the library itself was compiled with
-    assert ctypes.sizeof(_capi.ttm_program) == 23 * 8 + 10 * 4 + 8 + 3 * 8
+    # 17 + 6 pointers, 8 + 2 + 2 int32, 1 double, 3 + 1 int64 on LP64 - and what the library itself was compiled with
+    assert ctypes.sizeof(_capi.ttm_program) == 23 * 8 + 12 * 4 + 8 + 4 * 8
     assert _capi.load().ttm_program_sizeof() == ctypes.sizeof(_capi.ttm_program)
     from tests.hostemu import emu
     assert emu.lib().ttm_program_sizeof() == ctypes.sizeof(_capi.ttm_program)

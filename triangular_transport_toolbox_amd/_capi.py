@@ -38,7 +38,8 @@ class ttm_program(ctypes.Structure):
                 ('D', c_i32), ('d_cols', c_i32), ('family', c_i32), ('monotonicity', c_i32), ('rectifier', c_i32),
                 ('Q', c_i32), ('plan_ways', c_i32), ('u_enabled', c_i32), ('delta', c_dbl),
                 ('ucomp', c_vp), ('ugrp', c_vp), ('umono', c_vp), ('ugeo', c_vp), ('h_ucomp', c_vp), ('h_ugrp', c_vp),
-                ('u_size', c_i64), ('u_err_off', c_i64), ('u_h_off', c_i64), ('u_h_cls', c_i32), ('u_h_ng', c_i32)]
+                ('u_size', c_i64), ('u_err_off', c_i64), ('u_h_off', c_i64), ('u_h_cls', c_i32), ('u_h_ng', c_i32),
+                ('u_p_off', c_i64), ('u_p_lag', c_i32), ('u_p_stride', c_i32)]
 
 
 MONO = {'integrated rectifier': 0, 'separable monotonicity': 1}
@@ -206,5 +207,7 @@ def set_uform(p, cm, ucomp_ptr, ugrp_ptr, umono_ptr, ugeo_ptr):
     p.h_ugrp = p._keep_g.ctypes.data
     p.u_size, p.u_err_off = int(cm.u_size), int(cm.u_err_off)
     p.u_h_off, p.u_h_cls, p.u_h_ng = int(cm.u_h_off), int(cm.u_h_cls if cm.u_enabled else 0), int(cm.u_h_ng)
+    p.u_p_off, p.u_p_stride = int(cm.u_p_off), int(cm.u_p_stride)
+    p.u_p_lag = int(cm.u_p_lag if (cm.u_enabled and cm.u_h_cls) else 0)
     p.u_enabled = 1 if cm.u_enabled else 0
     return p

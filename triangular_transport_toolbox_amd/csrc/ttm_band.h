@@ -1,0 +1,39 @@
+// ttm_band.h - internal interface of csrc/ttm_band.hip (the kernels of banded U-form maps) to csrc/ttm_kernels.hip.
+//
+// A BANDED map (BASELINE config 5, Markov-type maps): the columns of the components are consecutive and every
+// nonmonotone group of component k reads a column kc-1 .. kc-LAG (LAG <= TTM_P_LAG_MAX), every component has a
+// special-term spline and no polynomial terms of its own variable.  Such a map is evaluated in PUSH form: walking the
+// columns in order, the value x_c of a column is used at once for everything that depends on it -
+//
+//     S at column c          = pend[0] + G_c(x_c)                      (G_c: the component's spline)
+//     pend[l], l = 0..LAG-2  = pend[l+1] + f_{c+l+1, c}(x_c)           (contribution to the component l+1 columns on)
+//     pend[LAG-1]            = c0_{c+LAG} + f_{c+LAG, c}(x_c)
+//
+// so a row carries LAG running sums instead of LAG cached columns with their exp(-x^2/4), and one step is straight-line
+// code.  The push records ("P section" of the U section, include/ttm.h) hold, per column, the coefficients of the
+// groups that READ the column; ttm_fold builds them behind the hot records.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/ttm.h"
+
+namespace ttm_band {
+
+// build the P section from the H section (device, on `stream`); also writes the local-coordinate offset of every spline
+// column into its padding slot.  U: the U section of the folded-coefficient buffer.
+int build_records(const ttm_program* p, double* U, void* stream);
+
+// can [k0, k1) of this program run through the band kernels?
+bool usable(const ttm_program* p, int k0, int k1);
+
+// forward map of columns [k0, k1) (Z != nullptr, plain map: no log-determinant / sum of squares)
+int forward(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa,
+            int64_t ldz, double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, void* stream, const char** kernel_name);
+
+// table inverse (resident windowed tables, as k_inverse_rt) in push form
+int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx,
+            int64_t N, const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt,
+            int nb, int cus, size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name);
+
+}  // namespace ttm_band

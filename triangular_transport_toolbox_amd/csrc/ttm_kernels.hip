@@ -28,6 +28,7 @@
 #include "ttm_eval.h"
 #include "ttm_rng.h"
 #include "ttm_uform.h"
+#include "ttm_band.h"
 
 using namespace ttm;
 
@@ -2381,7 +2382,9 @@ static const DeviceInfo& device_info() {
     X(rt_etab, -1)       /* 0: exp(-x^2/4) of the put from the series instead of the interval table                  */ \
     X(rt_band, -1)       /* 0: banded maps through the LDS column cache instead of the register shift                */ \
     X(rt_window, -1)     /* resident entries per table of k_inverse_rt: 0 whole tables, > 0 that many, -1 planned    */ \
-    X(gram_mfma, -1)     /* 0: Gram matrices by the pairwise kernel instead of the matrix cores                      */
+    X(gram_mfma, -1)     /* 0: Gram matrices by the pairwise kernel instead of the matrix cores                      */ \
+    X(band_fwd, -1)      /* 0: banded maps through k_forward_hl instead of the push-form kernel (csrc/ttm_band.hip)   */ \
+    X(band_inv, -1)      /* 0: banded maps through k_inverse_rt instead of the push-form kernel                      */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2623,6 +2626,7 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* strea
         const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
         hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(256), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
                            fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng);
+        if (p->u_p_lag > 0 && p->u_h_cls > 0) ttm_band::build_records(p, fold + fold_base_size(p), stream);       // push records of banded maps
     }
     return check_launch("k_fold");
 }
@@ -2659,6 +2663,14 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         }
         int ways = p->plan_ways;
         if (ways < 1 || ways > TTM_PLAN_WAYS) ways = TTM_PLAN_WAYS;
+        // banded maps, large ensembles: push-form kernel with every spline resident in LDS (csrc/ttm_band.hip)
+        if (tuning().band_fwd != 0 && !tuning().u_no_hot && Zsoa && !logdet && !sumsq && (N >= 64 * 1024 || tuning().band_fwd == 1) &&
+            ttm_band::usable(p, k0, k1)) {
+            const char* name = nullptr;
+            if (ttm_band::forward(p, fold + fold_base_size(p), k0, k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, device_info().cus,
+                                  device_info().lds_per_cu, stream, &name) == 0)
+                return check_launch(name);
+        }
         // large ensembles with aligned columns: loader-wave kernel
         {
             int nimax = 0, nchmax = 0;

@@ -654,6 +654,8 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 # ---- univariate form (include/ttm.h "U-form", csrc/ttm_uform.h) -----------------------------------------
 U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
 H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24)
+H_DB, H_DA = (0, 3, 5, 7), (0, 1, 5, 7)
+P_HDR, P_LAG_MAX = 8, 2
 UCF_OWN, UGF_POLY = 1, 1 << 20
 U_KAPPA = 0.75                # spline interval width / smallest special-term scale (degree 11: fit error < 1e-14;
                               # 0.5: 3e-15, 0.9: 5e-14 - wider intervals = smaller tables to stream per sweep step)
@@ -673,6 +675,7 @@ def _compile_uform(cm, u_info, polyclass, separable):
     cm.ugeo = np.zeros(2 * max(1, cm.D))
     cm.u_size, cm.u_err_off = 0, 0
     cm.u_h_off, cm.u_h_cls, cm.u_h_ng = 0, 0, 0
+    cm.u_p_off, cm.u_p_lag, cm.u_p_stride = 0, 0, 0
     if not separable or any(u['complex'] for u in u_info):
         return
     if any(g[1] > U_PMAX for u in u_info for g in u['groups']) or \
@@ -718,6 +721,15 @@ def _compile_uform(cm, u_info, polyclass, separable):
     if all_hit and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
         cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
         cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
+        # banded map (include/ttm.h "push records"): consecutive columns, every group reads one of the P_LAG_MAX columns
+        # in front of its component, a spline in every component -> csrc/ttm_band.hip
+        kc0 = int(ucomp[0, 0]) if cm.D else 0
+        lags = [int(ucomp[k, 0]) - int(ugrp[int(ucomp[k, 3]) + g, 0]) for k in range(cm.D) for g in range(int(ucomp[k, 2]))]
+        if cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(1 <= lag <= P_LAG_MAX for lag in lags) and \
+                all(len(u['st_p0']) > 0 for u in u_info):
+            cm.u_p_lag = P_LAG_MAX
+            gp = H_DB[cm.u_h_cls] + 1 + H_DA[cm.u_h_cls]
+            cm.u_p_stride = -(-(P_HDR + cm.u_p_lag * gp) // 8) * 8        # whole 64-byte lines
     uform_geometry(cm)
 
 
@@ -828,6 +840,10 @@ def uform_geometry(cm, kappa=None):
     cm.u_h_off = off
     if cm.u_h_cls:
         off += cm.D * (H_HDR + cm.u_h_ng * H_GS[cm.u_h_cls])
+    off += (-off) % 8
+    cm.u_p_off = off
+    if cm.u_p_lag:
+        off += (cm.D + cm.u_p_lag) * cm.u_p_stride
     cm.u_size = off + (off % 2)
     cm.ugeo = geo.ravel().copy()
     cm.u_enabled = bool(ok)
