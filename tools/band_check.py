@@ -31,7 +31,11 @@ def opt(name, v):
     assert lib.ttm_set_option(name.encode(), int(v)) == 0
 
 
+FAST = bool(os.environ.get('TTM_BAND_CHECK_FAST'))      # (under the profiler: a few launches only)
+
+
 def timed(fn, n=200):
+    n = 5 if FAST else n
     for _ in range(20):
         fn()
     torch.cuda.synchronize()
@@ -53,7 +57,7 @@ for mode in (0, -1):
     name = lib.ttm_last_kernel().decode()
     res[mode] = Z[:, :Nn].clone()
     # keep the clock up, then time
-    t_end = time.time() + 1.0
+    t_end = time.time() + (0.0 if FAST else 1.0)
     while time.time() < t_end:
         for _ in range(50):
             tm.forward_device(Xs, Nn, Z=Z)
@@ -76,5 +80,37 @@ if '--no-oracle' not in sys.argv:
         e = np.max(np.abs(Zk - Zo) / (np.abs(Zo) + 1.0))
         print('mode', mode, 'vs oracle: max rel %.3e' % e)
         out['fwd_vs_oracle_%d' % mode] = float(e)
+# ---- inverse --------------------------------------------------------------------------------------------------------
+Zs = res[-1] if res[-1].shape[1] == Xs.shape[1] else None
+Zin = tm._cols(tm.D, Nn)
+Zin[:, :Nn] = res[0]
+ires = {}
+for mode in (0, -1):
+    opt('band_inv', mode)
+    Xi = tm.inverse_device(Zin, Nn)
+    torch.cuda.synchronize()
+    name = lib.ttm_last_kernel().decode()
+    ires[mode] = Xi[:, :Nn].clone()
+    t_end = time.time() + (0.0 if FAST else 1.0)
+    while time.time() < t_end:
+        for _ in range(50):
+            tm.inverse_device(Zin, Nn, X=Xi)
+        torch.cuda.synchronize()
+    ms = timed(lambda: tm.inverse_device(Zin, Nn, X=Xi))
+    out['inv_%s' % name] = ms
+    print('inverse', name, '%.4f ms' % ms, ' frac of 8 TB/s: %.3f' % (8.0 * Nn * 2 * tm.D / (ms * 1e-3) / 8e12))
+d = (ires[0] - ires[-1]).abs()
+rel = (d / (ires[0].abs() + 1.0)).max().item()
+print('band vs k_inverse_rt: max abs %.3e  max rel %.3e' % (d.max().item(), rel))
+print('round trip (band): max abs %.3e' % (ires[-1] - Xs[:, :Nn]).abs().max().item())
+out['inv_band_vs_rt_rel'] = rel
+if '--no-oracle' not in sys.argv:
+    Zh = res[0][:, idx].T.cpu().numpy()
+    Xo = om.inverse_map(Zh)
+    for mode in (0, -1):
+        Xk = ires[mode][:, idx].T.cpu().numpy() * tm.X_std[None, :] + tm.X_mean[None, :]
+        e = np.max(np.abs(Xk - Xo) / (np.abs(Xo) + 1.0))
+        print('inverse mode', mode, 'vs oracle: max rel %.3e' % e)
+        out['inv_vs_oracle_%d' % mode] = float(e)
 os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'band_check.json'), 'w'), indent=1)

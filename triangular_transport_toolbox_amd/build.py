@@ -70,25 +70,48 @@ def can_build():
         return False
 
 
+def _obj_deps(dpath):
+    deps = []
+    if os.path.exists(dpath):
+        txt = open(dpath).read().replace('\\\n', ' ')
+        deps = [tok for tok in txt.split() if not tok.endswith(':') and not tok.startswith(('/opt/', '/usr/'))]
+    return deps
+
+
 def build_lib(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared ... -> triangular_transport_toolbox_amd/libttm.so"""
+    """hipcc --offload-arch=gfx950 -shared ... -> triangular_transport_toolbox_amd/libttm.so
+    Objects are kept per source file under _obj/ (keyed by the flag stamp) and recompiled only when the source or a
+    header the compiler reported for it is newer: a change to one translation unit does not rebuild the others."""
     if not force and not is_stale():
         return LIB
     tmp = '%s.tmp.%d' % (LIB, os.getpid())        # atomic replace: several ranks may build at the same time
+    objdir = os.path.join(PKG, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    stamp = _stamp()[:12]
     objs, deptxt = [], []
     try:
         for src in _sources():
-            obj = '%s.%s.o' % (tmp, os.path.basename(src))
-            cflags = [f for f in FLAGS if f != '-shared']
-            cmd = [hipcc_path()] + cflags + ['-x', 'hip', '-c', src, '-MD', '-MF', obj + '.d', '-o', obj]
-            if verbose:
-                print(' '.join(cmd))
-            res = subprocess.run(cmd, capture_output=True, text=True)
-            if res.returncode != 0:
-                raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+            obj = os.path.join(objdir, '%s.%s.o' % (os.path.basename(src), stamp))
+            dpath = obj + '.d'
+            fresh = (not force) and os.path.exists(obj) and os.path.exists(dpath) and \
+                all(os.path.exists(d) and os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + _obj_deps(dpath))
+            if not fresh:
+                otmp = '%s.tmp.%d' % (obj, os.getpid())
+                cflags = [f for f in FLAGS if f != '-shared']
+                cmd = [hipcc_path()] + cflags + ['-x', 'hip', '-c', src, '-MD', '-MF', otmp + '.d', '-o', otmp]
+                if verbose:
+                    print(' '.join(cmd))
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode != 0:
+                    for path in (otmp, otmp + '.d'):
+                        if os.path.exists(path):
+                            os.remove(path)
+                    raise RuntimeError('hipcc failed:\n' + res.stdout + res.stderr)
+                os.replace(otmp, obj)
+                os.replace(otmp + '.d', dpath)
             objs.append(obj)
-            if os.path.exists(obj + '.d'):
-                deptxt.append(open(obj + '.d').read())
+            if os.path.exists(dpath):
+                deptxt.append(open(dpath).read())
         cmd = [hipcc_path(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs + LINK
         if verbose:
             print(' '.join(cmd))
@@ -101,10 +124,8 @@ def build_lib(force=False, verbose=False):
         with open(LIB + '.stamp', 'w') as f:
             f.write(_stamp() + '\n')
     finally:
-        for o in objs + [tmp]:
-            for path in (o, o + '.d'):
-                if os.path.exists(path):
-                    os.remove(path)
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

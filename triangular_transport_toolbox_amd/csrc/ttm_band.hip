@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "ttm_band.h"
 #include "ttm_band_etab.h"
@@ -301,6 +302,348 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// table inverse (TM:3987-4084) in push form
+// ---------------------------------------------------------------------------
+// The resident-table machinery is that of k_inverse_rt (csrc/ttm_kernels.hip: blocks of components, windowed tables,
+// 16-bit bucket index, the index kernel's bucket function bit for bit, outliers redone from the table in memory); the
+// step is new: the nonmonotone offset of a component is the running sum pend[0] its predecessors pushed, the solved
+// x_k is pushed on at once (exp(-x_k^2/4) from the located interval), and a step whose rows all lie inside the
+// resident window - all but a handful per million - is ONE basic block.
+// LDS (doubles): [tables: B x tab_slot | {E_i, y_i}: 2 x Weven]
+// table slot: [wl, wh, bucket scale, bucket bias, int32 {entries per bucket at most, 0}, int32 {degenerate, 0} | xs: W
+//              entries + 4 sentinels (+inf), rounded up to even | bucket index: nb + 1 uint16]
+#define BAND_RT_HDR 6
+
+__device__ __forceinline__ void band_bucket_params(double lo, double hi, int nb, double& scale, double& bias) {
+    scale = (double)nb / (hi - lo);                                           // (k_table_index: the same IEEE division)
+    if (!(scale > 0.0 && scale < 1.0e300)) scale = 0.0;
+    bias = -lo * scale;
+}
+
+// exp(-x^2/4) by the series (block boundaries, outliers): Cody-Waite reduction + degree-12 Taylor, <= 2 ulp
+__device__ __forceinline__ double band_expq_series(double x) {
+    const double y = fmax(-0.25 * (x * x), -800.0);
+    const double k = rint(y * 1.4426950408889634);
+    double r = fma(-k, 6.93147180369123816490e-01, y);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878681e-09;
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return fma(x, 0.0, ldexp(p, (int)k));
+}
+
+// LDS addresses as 32-bit pointers (a laundered generic pointer would be read through the flat path)
+typedef const __attribute__((address_space(3))) char* lds_p;
+__device__ __forceinline__ lds_p band_lds(const void* p) { return (lds_p)p; }
+__device__ __forceinline__ double band_lds_f64(lds_p p) { return *(const __attribute__((address_space(3))) double*)p; }
+// ... an 8-byte read the load/store optimiser cannot pair with its neighbour (ds_read2_b64 is served at a quarter of the
+// rate of two ds_read_b64 and banks modulo 32)
+__device__ __forceinline__ double band_lds_f64_single(lds_p p) {
+    asm volatile("" : "+v"(p));
+    return *(const __attribute__((address_space(3))) double*)p;
+}
+typedef double band_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ D2 band_lds_pair(lds_p p) {
+    const band_v2 v = *(const __attribute__((address_space(3))) band_v2*)p;
+    const D2 r = {v.x, v.y};
+    return r;
+}
+
+// everything a tile needs to walk the columns [kb, ke) of a block
+struct BandInvCtx {
+    cdbl_p P, kt;
+    const double* tabs;            // resident tables of the block
+    lds_p etab1;                   // pairs {E_i, y_i}: entry i - 1 of the whole table at etab1 + 16 i
+    const double* tab_x; const double* tmin; const double* tmax;
+    int T, nb, tab_slot, w0, Weven, k0;
+    double y0, ystep, y0m;
+    int64_t ldzb, ldxb;
+    unsigned int c1_32;
+};
+
+template <int CLS, int LAG>
+__device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool full, int kb, int ke, const char* zcol, char* xcol, unsigned int tbase,
+                                                  const unsigned int (&roff)[BAND_NS / 2], double (&pend)[BAND_NS][LAG]) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
+    constexpr int NS = BAND_NS, NP = NS / 2, HALF = 2 * BAND_CT;
+    cdbl_p rec = cx.P + (int64_t)(kb + LAG) * PS;
+    cdbl_p kt = cx.kt;
+    const double* slot = cx.tabs;
+    const double ystep = cx.ystep;
+    const int nb1 = cx.nb - 1;
+    D2 za[NP], zb[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) za[q] = *(const D2*)(zcol + roff[q]);
+    // interp1d slope form (TM:4062-4065) in the located interval and exp(-x^2/4) = E[i-1] exp(w), w = -delta (y_lo + x) / 4
+    auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
+        const double dx = fmax(x_hi - x_lo, 1e-300);                          // (tie at a flat start: k_inverse_rt)
+        double rc = __builtin_amdgcn_rcp(dx);
+        rc = fma(fma(-dx, rc, 1.0), rc, rc);
+        const double delta = (ystep * rc) * (tgt - x_lo);
+        rr = delta + y_lo;
+        const double w = (delta * -0.25) * (y_lo + rr);
+        double p = fma(kt[0], w, kt[1]);
+        p = fma(p, w, kt[2]);
+        p = fma(p, w, kt[3]);
+        p = fma(p, w, kt[4]);
+        p = fma(p, w, kt[5]);
+        p = fma(p, w, 1.0);
+        p = fma(p, w, 1.0);
+        ee = e_lo * p;
+    };
+    auto step = [&](int j, const D2 (&zc)[NP], D2 (&zn)[NP]) {
+        {
+            const char* znext = j + 1 < ke ? zcol + cx.ldzb : zcol;           // (past the block: a harmless re-read)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) zn[q] = *(const D2*)(znext + roff[q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const double start = rec[1];
+        double wl, wh, scale, bias;
+        { const D2 a = *(const D2*)slot; wl = a.x; wh = a.y; const D2 b = *(const D2*)(slot + 2); scale = b.x; bias = b.y; }
+        const lds_p xsl = band_lds(slot + BAND_RT_HDR) - 8 * cx.w0;           // xs indexed by the entry's number in the whole table
+        const lds_p bkl = band_lds(slot + BAND_RT_HDR + cx.Weven);
+        const bool deg = __builtin_amdgcn_readfirstlane(((const int*)slot)[10]) != 0;
+        const int per = __builtin_amdgcn_readfirstlane(((const int*)slot)[8]);
+        double traw[NS], tg[NS], r[NS], E[NS];
+        unsigned long long outl = deg ? ~0ull : 0ull;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) {
+            const double z = (e & 1) ? zc[e >> 1].y : zc[e >> 1].x;
+            traw[e] = z - pend[e][0];
+            tg[e] = fmin(fmax(traw[e], wl), wh);
+            outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
+        }
+        // the four rows in phases, so that their dependent LDS reads travel together: bucket -> the bucket's entries ->
+        // the interval.  np.searchsorted(xs, target) (left) = entries in lower buckets + entries of the target's own
+        // bucket that are below it (the bucket function is monotone: k_table_index); NC = entries compared (>= the most
+        // any bucket of this table holds).  The target is clipped to the window's value range, so every read is resident
+        // whatever the row (an outlier's result is replaced below).
+        auto search = [&](auto nc) {
+            constexpr int NC = decltype(nc)::value;
+            int pos[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                const int bi = min((int)fma(tg[e], scale, bias), nb1);
+                pos[e] = (int)*(const __attribute__((address_space(3))) unsigned short*)(bkl + 2 * bi);
+            }
+            double qv[NS][NC];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                const lds_p q4 = xsl + 8 * pos[e];
+                qv[e][0] = band_lds_f64(q4);
+#pragma unroll
+                for (int i = 1; i < NC; ++i) qv[e][i] = band_lds_f64_single(q4 + 8 * i);
+            }
+            D2 ey[NS];
+            double xlo[NS], xhi[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) pos[e] += qv[e][i] < tg[e] ? 1 : 0;
+                ey[e] = band_lds_pair(cx.etab1 + 16 * pos[e]);
+                const lds_p xp = xsl + 8 * pos[e];
+                xlo[e] = band_lds_f64(xp - 8);
+                xhi[e] = band_lds_f64_single(xp);
+            }
+#pragma unroll
+            for (int e = 0; e < NS; ++e) interp(ey[e].y, xlo[e], xhi[e], ey[e].x, tg[e], r[e], E[e]);
+        };
+        if (per <= 2) search(std::integral_constant<int, 2>());
+        else search(std::integral_constant<int, 4>());
+        if (outl != 0) {
+            // outliers (the tails of the table, beyond the window, NaN; every row of a degenerate table): clip as
+            // TM:4074-4076, np.searchsorted (left) over the whole row in memory, the same interpolation
+            const double* xg = cx.tab_x + (int64_t)(j - cx.k0) * cx.T;
+            const double lo = cx.tmin[j - cx.k0], hi = cx.tmax[j - cx.k0];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) {
+                if (deg || traw[e] != tg[e]) {
+                    double t = traw[e];
+                    const double cl = fmin(fmax(t, lo), hi);
+                    t = t != t ? t : cl;                                      // a NaN target stays NaN
+                    int a = 0, b = cx.T;
+                    while (a < b) {
+                        const int mid = (a + b) >> 1;
+                        if (xg[mid] < t) a = mid + 1; else b = mid;
+                    }
+                    const int i = min(max(a, 1), cx.T - 1);
+                    interp(fma((double)i, ystep, cx.y0m), xg[i - 1], xg[i], band_expq_series((double)(i - 1) * ystep + cx.y0), t, r[e], E[e]);
+                }
+            }
+        }
+        // x_k is pushed on to the components that read it, and stored
+#pragma unroll
+        for (int e = 0; e < NS; ++e) band_push<DB, DA, LAG>(rec + TTM_P_HDR, start, r[e], E[e], pend[e]);
+        if (full) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const D2 o = {r[2 * q], r[2 * q + 1]};
+                *(D2*)(xcol + (size_t)((tbase + (unsigned int)(q * HALF)) * 8u)) = o;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const unsigned int n = tbase + (unsigned int)(q * HALF);
+                const D2 o = {r[2 * q], r[2 * q + 1]};
+                char* xp = xcol + (size_t)(n * 8u);
+                if (n + 1 < cx.c1_32) *(D2*)xp = o;
+                else if (n < cx.c1_32) *(double*)xp = o.x;
+            }
+        }
+        rec += PS; slot += cx.tab_slot; zcol += cx.ldzb; xcol += cx.ldxb;
+    };
+    int j = kb;
+    for (; j + 1 < ke; j += 2) {
+        step(j, za, zb);
+        step(j + 1, zb, za);
+    }
+    if (j < ke) step(j, za, zb);
+}
+
+template <int CLS, int LAG>
+__global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                          const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
+                                                          const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
+                                                          const double* __restrict__ tmin, const double* __restrict__ tmax,
+                                                          const int* __restrict__ bkt, int nb, int tab_slot, int B, int64_t rows_per_wg,
+                                                          int w0, int W) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
+    constexpr int NS = BAND_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT;
+    extern __shared__ __align__(16) double g_lds[];
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
+    const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
+    const int Weven = (W + 4 + 1) & ~1;
+    double* tabs = g_lds;
+    double* etab = tabs + (size_t)B * tab_slot;
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
+    const double y0m = y0 - ystep;
+    BandInvCtx cx;
+    cx.P = P; cx.kt = (cdbl_p)g_band_taylor; cx.tabs = tabs;
+    cx.etab1 = band_lds(etab) - 16 * w0 - 16;
+    cx.tab_x = tab_x; cx.tmin = tmin; cx.tmax = tmax;
+    cx.T = T; cx.nb = nb; cx.tab_slot = tab_slot; cx.w0 = w0; cx.Weven = Weven; cx.k0 = k0;
+    cx.y0 = y0; cx.ystep = ystep; cx.y0m = y0m; cx.ldzb = ldzb; cx.ldxb = ldxb; cx.c1_32 = (unsigned int)c1;
+    for (int i = tid; i < W; i += CT) {
+        // E of grid point w0 + i and, next to it, that point's abscissa exactly as the interpolation forms it from the
+        // interval number (fma(i + 1, step, y0 - step))
+        etab[2 * i] = band_expq_series(w0 + i == T - 1 ? ylast : (double)(w0 + i) * ystep + y0);
+        etab[2 * i + 1] = fma((double)(w0 + i + 1), ystep, y0m);
+    }
+    double pend[NS][LAG];
+#pragma unroll
+    for (int e = 0; e < NS; ++e)
+#pragma unroll
+        for (int l = 0; l < LAG; ++l) pend[e][l] = 0.0;
+
+    for (int kb = k0; kb < k1; kb += B) {
+        const int ke = kb + B < k1 ? kb + B : k1;
+        const int nk = ke - kb;
+        __syncthreads();                                      // every wave is done with the previous block's tables
+        if (tid < nk) {
+            const int c = kb + tid;
+            double* slot = tabs + (size_t)tid * tab_slot;
+            double scale, bias;
+            band_bucket_params(tmin[c - k0], tmax[c - k0], nb, scale, bias);
+            slot[2] = scale; slot[3] = bias;
+            ((int*)slot)[8] = 0; ((int*)slot)[9] = 0;
+            slot[5] = 0.0;
+        }
+        __syncthreads();
+        // the tables of the block, sixteen components' loads in flight per thread
+        for (int cg = 0; cg < nk; cg += 16) {
+            for (int i = tid; i < Weven; i += CT) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tab_x[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * T + w0 + min(i, W - 1)];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (cg + u < nk) tabs[(size_t)(cg + u) * tab_slot + BAND_RT_HDR + i] = i < W ? v[u] : INFINITY;
+            }
+            for (int i = tid; i <= nb; i += CT) {
+                int v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = bkt[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * (nb + 1) + i];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (cg + u < nk) ((unsigned short*)(tabs + (size_t)(cg + u) * tab_slot + BAND_RT_HDR + Weven))[i] = (unsigned short)v[u];
+            }
+        }
+        __syncthreads();
+        // entries per bucket, at most; the value range [wl, wh] whose search stays inside the window (k_inverse_rt)
+        for (int c = tid >> 6; c < nk; c += CT >> 6) {
+            const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + BAND_RT_HDR + Weven);
+            int per = 0;
+            for (int i = tid & 63; i < nb; i += 64) {
+                const int b0 = bs[i], b1 = bs[i + 1];
+                if (b1 > w0 && b0 < w0 + W) per = max(per, b1 - b0);
+            }
+            for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+            double* slot = tabs + (size_t)c * tab_slot;
+            const int pm = max(per, 1);
+            const bool deg = pm + 3 >= W || per > 4;                           // (more entries in a bucket than the resident search compares: every row by the outlier path)
+            if ((tid & 63) == 0) {
+                const double* xw = slot + BAND_RT_HDR;
+                ((int*)slot)[8] = per;
+                ((int*)slot)[10] = deg ? 1 : 0;
+                slot[0] = deg ? xw[1] : xw[pm];
+                slot[1] = deg ? xw[1] : xw[W - 2];
+            }
+            if (deg)
+                for (int i = tid & 63; i <= nb; i += 64) const_cast<unsigned short*>(bs)[i] = (unsigned short)(w0 + 1);
+        }
+        __syncthreads();
+
+        const int colb = kcol0 + (kb - k0);                   // column of component kb
+        for (int tile = 0; tile < ntile; ++tile) {
+            const unsigned int tbase = (unsigned int)c0 + (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+            const bool full = c0 + (int64_t)(tile + 1) * ROWS <= c1;
+            unsigned int roff[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                unsigned int n = tbase + (unsigned int)(q * HALF);
+                n = n < last_pair ? n : last_pair;
+                roff[q] = n * 8u;
+            }
+            if (!(ntile == 1 && kb > k0)) {
+                // running sums at the block's first column from the LAG columns in front of it (conditioning columns, or
+                // what the same thread stored in the block before); a chunk of ONE tile keeps them in registers instead
+                for (int i = 0; i < LAG; ++i) {
+                    const int cc = colb - LAG + i;
+                    cdbl_p rec = P + (int64_t)(kb + i) * PS;
+                    const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        D2 xv = {0.0, 0.0};
+                        if (cc >= 0) xv = *(const D2*)(col + roff[q]);
+                        band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[1], xv.x, cc >= 0 ? band_expq_series(xv.x) : 1.0, pend[2 * q]);
+                        band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[1], xv.y, cc >= 0 ? band_expq_series(xv.y) : 1.0, pend[2 * q + 1]);
+                    }
+                }
+            }
+            const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;
+            char* xcol = (char*)X + (int64_t)colb * ldxb;
+            band_inverse_tile<CLS, LAG>(cx, full, kb, ke, zcol, xcol, tbase, roff, pend);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static void allow_lds(const void* kern, size_t bytes) {
@@ -383,9 +726,54 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     return 0;
 }
 
-int inverse(const ttm_program*, const double*, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int, const double*,
-            const double*, const double*, const int32_t*, int, int, size_t, int, int, void*, const char**) {
-    return 1;
+int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
+            const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int nb, int cus,
+            size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name) {
+    if (!usable(p, k0, k1) || !y_affine || T < 64 || T > 4096 || nb < 4 || nb > 65535 || N >= ((int64_t)1 << 28)) return 1;
+    const double ymax = fabs(y_affine[0]) > fabs(y_affine[2]) ? fabs(y_affine[0]) : fabs(y_affine[2]);
+    if (!(y_affine[1] > 0.0 && y_affine[1] * ymax * 0.5 <= 0.1)) return 1;                 // (exp(w) by its Taylor polynomial)
+    const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) && ((uintptr_t)Xsoa % 16 == 0) &&
+                         (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1);
+    if (!aligned) return 1;
+    const int ncomp = k1 - k0;
+    int W = T, w0 = 0, Weven = 0, tab_slot = 0, Bc = 0, nblk = 0;
+    size_t lds = 0;
+    auto plan = [&]() {
+        Weven = (W + 4 + 1) & ~1;
+        tab_slot = BAND_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);
+        const size_t fixed = (size_t)2 * Weven * 8;
+        Bc = 0;
+        if (fixed + (size_t)tab_slot * 8 > lds_per_cu) return;
+        Bc = (int)((lds_per_cu - fixed) / ((size_t)tab_slot * 8));
+        if (Bc > ncomp) Bc = ncomp;
+        if (block > 0 && block < Bc) Bc = block;
+        nblk = (ncomp + Bc - 1) / Bc;
+        Bc = (ncomp + nblk - 1) / nblk;
+        lds = fixed + (size_t)Bc * tab_slot * 8;
+    };
+    plan();
+    // windowed tables when that saves a pass over the chunk (k_inverse_rt)
+    if (window != 0 && (window > 0 || (Bc > 0 && nblk > 1))) {
+        const int Bfull = Bc, nfull = nblk;
+        W = window > 0 ? (window < 16 ? 16 : window) : (int)(0.65 * T);
+        if (W >= T) W = T - 1;
+        w0 = (T - W) / 2;
+        plan();
+        if (Bc == 0 || (window < 0 && !(Bfull > 0 && nblk < nfull))) { W = T; w0 = 0; plan(); }
+    }
+    if (Bc <= 0) return 1;
+    typedef void (*kern_t)(const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int, double,
+                           double, double, const double*, const double*, const int*, int, int, int, int64_t, int, int);
+    kern_t kern = p->u_h_cls == 1 ? k_band_inverse<1, 2> : p->u_h_cls == 2 ? k_band_inverse<2, 2> : k_band_inverse<3, 2>;
+    int64_t rows = (N + cus - 1) / cus;
+    rows = (rows + 1) & ~(int64_t)1;
+    const int64_t grid = (N + rows - 1) / rows;
+    allow_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                       (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Zsoa, ldz, Xsoa, ldx, N, tab_x, T, y_affine[0], y_affine[1], y_affine[2], tmin,
+                       tmax, bkt, nb, tab_slot, Bc, rows, w0, W);
+    if (kernel_name) *kernel_name = "k_band_inverse";
+    return 0;
 }
 
 }  // namespace ttm_band

@@ -2881,6 +2881,13 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                                                                             // table load per workgroup does not pay; option u_loader = 1 forces it)
         const DeviceInfo& di = device_info();
         const Tuning& tn = tuning();
+        // banded maps: push-form kernel (csrc/ttm_band.hip); clipped searches only (exp(-x^2/4) from the located interval)
+        if (tn.band_inv != 0 && truncate && ttm_band::usable(p, k0, k1)) {
+            const char* name = nullptr;
+            if (ttm_band::inverse(p, fold + fold_base_size(p), k0, k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine, tmin, tmax, bkt, (int)nb,
+                                  di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
+                return check_launch(name);
+        }
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
         int NS = tn.rt_ns == 4 ? 4 : 2;
