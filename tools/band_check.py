@@ -80,6 +80,10 @@ if '--no-oracle' not in sys.argv:
         e = np.max(np.abs(Zk - Zo) / (np.abs(Zo) + 1.0))
         print('mode', mode, 'vs oracle: max rel %.3e' % e)
         out['fwd_vs_oracle_%d' % mode] = float(e)
+ONLY = os.environ.get('TTM_BAND_CHECK_ONLY', '')
+if ONLY == 'fwd':
+    json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'band_check.json'), 'w'), indent=1)
+    sys.exit(0)
 # ---- inverse --------------------------------------------------------------------------------------------------------
 Zs = res[-1] if res[-1].shape[1] == Xs.shape[1] else None
 Zin = tm._cols(tm.D, Nn)

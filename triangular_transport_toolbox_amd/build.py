@@ -21,6 +21,8 @@ HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', 'ttm_ufor
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
          '-DNDEBUG'] + shlex.split(os.environ.get('TTM_BUILD_FLAGS', ''))
 LINK = ['-ldl', '-pthread']                   # (RCCL is bound at run time, csrc/ttm_comm.cpp)
+# tuning builds: extra flags for ONE translation unit (only that object is recompiled), e.g. TTM_BAND_FLAGS=-DBAND_X=1
+EXTRA = {'ttm_band.hip': shlex.split(os.environ.get('TTM_BAND_FLAGS', ''))}
 
 
 def hipcc_path():
@@ -35,7 +37,8 @@ def _sources():
 
 
 def _stamp():
-    return hashlib.sha256(' '.join(FLAGS + LINK + [os.path.basename(s) for s in _sources()]).encode()).hexdigest()
+    extra = [k + ':' + ' '.join(v) for k, v in sorted(EXTRA.items()) if v]
+    return hashlib.sha256(' '.join(FLAGS + LINK + [os.path.basename(s) for s in _sources()] + extra).encode()).hexdigest()
 
 
 def _deps():
@@ -87,17 +90,19 @@ def build_lib(force=False, verbose=False):
     tmp = '%s.tmp.%d' % (LIB, os.getpid())        # atomic replace: several ranks may build at the same time
     objdir = os.path.join(PKG, '_obj')
     os.makedirs(objdir, exist_ok=True)
-    stamp = _stamp()[:12]
+    base_stamp = hashlib.sha256(' '.join(FLAGS).encode()).hexdigest()[:12]
     objs, deptxt = [], []
     try:
         for src in _sources():
+            extra = EXTRA.get(os.path.basename(src), [])
+            stamp = base_stamp if not extra else hashlib.sha256(' '.join(FLAGS + extra).encode()).hexdigest()[:12]
             obj = os.path.join(objdir, '%s.%s.o' % (os.path.basename(src), stamp))
             dpath = obj + '.d'
             fresh = (not force) and os.path.exists(obj) and os.path.exists(dpath) and \
                 all(os.path.exists(d) and os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + _obj_deps(dpath))
             if not fresh:
                 otmp = '%s.tmp.%d' % (obj, os.getpid())
-                cflags = [f for f in FLAGS if f != '-shared']
+                cflags = [f for f in FLAGS if f != '-shared'] + extra
                 cmd = [hipcc_path()] + cflags + ['-x', 'hip', '-c', src, '-MD', '-MF', otmp + '.d', '-o', otmp]
                 if verbose:
                     print(' '.join(cmd))

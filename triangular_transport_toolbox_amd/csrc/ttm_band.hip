@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "ttm_band.h"
@@ -42,6 +43,15 @@ __host__ __device__ constexpr int rec_stride(int cls, int lag) { return (TTM_P_H
 #define BAND_ET_DOUBLES (2 * TTM_BAND_ET_N)          /* 12 816 bytes: a multiple of 16 */
 #define BAND_CT 1024                                 /* threads per workgroup */
 #define BAND_NS 4                                    /* rows per thread: pairs (2t, 2t+1) of the two halves of a tile */
+#ifndef BAND_ROWS_TOGETHER
+#define BAND_ROWS_TOGETHER 2                         /* rows of a thread whose instructions the scheduler may interleave (1, 2, 4) */
+#endif
+#ifndef BAND_FWD_NT
+#define BAND_FWD_NT 1                                /* non-temporal stores of the forward map's columns */
+#endif
+#ifndef BAND_PF
+#define BAND_PF 1                                    /* columns requested ahead of the one being evaluated */
+#endif
 
 // ---------------------------------------------------------------------------
 // push records from the hot records (one workgroup of 64 threads per record)
@@ -101,6 +111,26 @@ __global__ __launch_bounds__(64) void k_band_records(const int* __restrict__ uco
     }
 }
 
+// column stream accesses: 16 bytes per lane.  The forward map's stores are non-temporal (written once, 320 MB: -6 % launch
+// time against plain stores, profiles/r03_*; for the loads and for the inverse's stores the hint changes nothing)
+template <bool NT>
+__device__ __forceinline__ void band_store2(char* p, double a, double b) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 v = {a, b};
+    if (NT) __builtin_nontemporal_store(v, (v2*)p);
+    else *(v2*)p = v;
+}
+__device__ __forceinline__ D2 band_load2(const char* p) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+#ifdef BAND_NT_LOAD
+    const v2 v = __builtin_nontemporal_load((const v2*)p);
+#else
+    const v2 v = *(const v2*)p;
+#endif
+    const D2 r = {v.x, v.y};
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // per-row pieces of a step
 // ---------------------------------------------------------------------------
@@ -135,12 +165,12 @@ __device__ __forceinline__ double band_expq(const double* etab, double x, cdbl_p
 
 // pushes of one column value: pend[l] <- pend[l+1] (or the chain start) + group l of the record; g: the LAG group
 // blocks of the record (uniform), E = exp(-x^2/4)
-template <int DB, int DA, int LAG>
-__device__ __forceinline__ void band_push(cdbl_p g, double start, double x, double E, double (&pend)[LAG]) {
+template <int DB, int DA, int LAG, class G>
+__device__ __forceinline__ void band_push(const G& g, double start, double x, double E, double (&pend)[LAG]) {
     constexpr int GP = DB + 1 + DA;
 #pragma unroll
     for (int l = 0; l < LAG; ++l) {
-        cdbl_p c = g + l * GP;
+        const auto c = &g[l * GP];
         double b = c[DB];
 #pragma unroll
         for (int i = DB - 1; i >= 0; --i) b = fma(b, x, c[i]);
@@ -177,17 +207,23 @@ __device__ __forceinline__ void band_forward_tile(cdbl_p P, cdbl_p kt, const dou
                                                   double (&pend)[BAND_NS][LAG]) {
     constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
     constexpr int NS = BAND_NS, NP = NS / 2, HALF = 2 * BAND_CT;
-    D2 xa[NP], xb[NP];
+    // The column stream is latency bound (a step is shorter than a loaded memory round trip: profiles/r03_*): the column
+    // of step j + PF is requested at the top of step j, PF + 1 register sets take turns (steps are issued PF + 1 at a time
+    // with the roles rotated, so no set is ever copied).
+    constexpr int PF = BAND_PF, RING = PF + 1;
+    D2 xr[RING][NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) xa[q] = *(const D2*)(xcol + roff[q]);
+    for (int i = 0; i < PF; ++i) {
+        const char* xc0 = xcol + (int64_t)(kb + i < ke ? i : 0) * ldxb;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) xr[i][q] = band_load2(xc0 + roff[q]);
+    }
     cdbl_p rec = P + (int64_t)(kb + LAG) * PS;
-    // one step = one column for the four rows of the thread: xc holds the column (requested a step ahead), xn takes the
-    // next one - requested before anything else is done.  Steps are issued in pairs with the two register sets exchanged.
     auto step = [&](int j, const D2 (&xc)[NP], D2 (&xn)[NP]) {
         {
-            const char* xnext = j + 1 < ke ? xcol + ldxb : xcol;              // (past the block: a harmless re-read)
+            const char* xnext = j + PF < ke ? xcol + PF * ldxb : xcol;        // (past the block: a harmless re-read)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) xn[q] = *(const D2*)(xnext + roff[q]);
+            for (int q = 0; q < NP; ++q) xn[q] = band_load2(xnext + roff[q]);
         }
         __builtin_amdgcn_sched_barrier(0);                    // (the scheduler would sink the loads to the end of the step)
         // ---- uniform data of the step ------------------------------------------------------------------------
@@ -195,7 +231,8 @@ __device__ __forceinline__ void band_forward_tile(cdbl_p P, cdbl_p kt, const dou
         cint_p ri = (cint_p)rec;
         const int nI = ri[10];
         const double* tab = tabs + (ri[11] - tab0);
-        // ---- per row pair (two rows' chains interleave; all four would need 96 registers for the coefficients) -----------
+        // ---- row by row (BAND_ROWS_TOGETHER of them scheduled together: each needs 24 registers for its coefficients; the
+        // waves of the SIMD, not the rows of a thread, fill each other's latencies) ------------------------------------
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             double zv[2];
@@ -203,26 +240,45 @@ __device__ __forceinline__ void band_forward_tile(cdbl_p P, cdbl_p kt, const dou
             for (int h = 0; h < 2; ++h) {
                 const int e = 2 * q + h;
                 const double x = h ? xc[q].y : xc[q].x;
+#ifdef BAND_X_NOSPLINE                                       /* (timing experiments: results wrong by construction) */
+                const double m = x;
+#else
                 const double m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
+#endif
+#ifdef BAND_X_NOEXP
+                const double E = x;
+#else
                 const double E = band_expq(etab, x, kt);
+#endif
                 zv[h] = pend[e][0] + m;
+#ifdef BAND_X_NOPUSH
+                pend[e][0] = E;
+#else
                 band_push<DB, DA, LAG>(rec + TTM_P_HDR, start, x, E, pend[e]);
+#endif
+                if (BAND_ROWS_TOGETHER == 1) __builtin_amdgcn_sched_barrier(0);
             }
             const unsigned int n = tbase + (unsigned int)(q * HALF);
             const D2 o = {zv[0], zv[1]};
             char* zp = zcol + (size_t)(n * 8u);
-            if (FULL || n + 1 < c1_32) *(D2*)zp = o;
+#ifdef BAND_X_NOSTORE
+            if (o.x == 1.2345e300) *(D2*)zp = o;
+#else
+            if (FULL || n + 1 < c1_32) band_store2<BAND_FWD_NT != 0>(zp, o.x, o.y);
             else if (n < c1_32) *(double*)zp = o.x;
-            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (BAND_ROWS_TOGETHER <= 2) __builtin_amdgcn_sched_barrier(0);
         }
         rec += PS; xcol += ldxb; zcol += ldzb;
     };
     int j = kb;
-    for (; j + 1 < ke; j += 2) {
-        step(j, xa, xb);
-        step(j + 1, xb, xa);
+    for (; j + RING <= ke; j += RING) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) step(j + i, xr[i], xr[(i + PF) % RING]);
     }
-    if (j < ke) step(j, xa, xb);
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (j + i < ke) step(j + i, xr[i], xr[(i + PF) % RING]);
 }
 
 // LDS: [E table: 2 x 801 | splines of the block's components, as they stand in the U section]
@@ -383,7 +439,7 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
     const int nb1 = cx.nb - 1;
     D2 za[NP], zb[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) za[q] = *(const D2*)(zcol + roff[q]);
+    for (int q = 0; q < NP; ++q) za[q] = band_load2(zcol + roff[q]);
     // interp1d slope form (TM:4062-4065) in the located interval and exp(-x^2/4) = E[i-1] exp(w), w = -delta (y_lo + x) / 4
     auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
         const double dx = fmax(x_hi - x_lo, 1e-300);                          // (tie at a flat start: k_inverse_rt)
@@ -405,10 +461,18 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
         {
             const char* znext = j + 1 < ke ? zcol + cx.ldzb : zcol;           // (past the block: a harmless re-read)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) zn[q] = *(const D2*)(znext + roff[q]);
+            for (int q = 0; q < NP; ++q) zn[q] = band_load2(znext + roff[q]);
         }
+        // the record of the step, requested NOW (left to itself the compiler loads the group coefficients where the pushes
+        // use them - at the end of the step's dependent chain, a scalar-cache round trip on the critical path)
+        double start = rec[1];
+        double gc[LAG * (DB + 1 + DA)];
+#pragma unroll
+        for (int i = 0; i < LAG * (DB + 1 + DA); ++i) gc[i] = rec[TTM_P_HDR + i];
+        asm volatile("" : "+s"(start));
+#pragma unroll
+        for (int i = 0; i < LAG * (DB + 1 + DA); ++i) asm volatile("" : "+s"(gc[i]));
         __builtin_amdgcn_sched_barrier(0);
-        const double start = rec[1];
         double wl, wh, scale, bias;
         { const D2 a = *(const D2*)slot; wl = a.x; wh = a.y; const D2 b = *(const D2*)(slot + 2); scale = b.x; bias = b.y; }
         const lds_p xsl = band_lds(slot + BAND_RT_HDR) - 8 * cx.w0;           // xs indexed by the entry's number in the whole table
@@ -484,12 +548,11 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
         }
         // x_k is pushed on to the components that read it, and stored
 #pragma unroll
-        for (int e = 0; e < NS; ++e) band_push<DB, DA, LAG>(rec + TTM_P_HDR, start, r[e], E[e], pend[e]);
+        for (int e = 0; e < NS; ++e) band_push<DB, DA, LAG>(gc, start, r[e], E[e], pend[e]);
         if (full) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const D2 o = {r[2 * q], r[2 * q + 1]};
-                *(D2*)(xcol + (size_t)((tbase + (unsigned int)(q * HALF)) * 8u)) = o;
+                band_store2<false>(xcol + (size_t)((tbase + (unsigned int)(q * HALF)) * 8u), r[2 * q], r[2 * q + 1]);
             }
         } else {
 #pragma unroll
@@ -661,6 +724,16 @@ static void allow_lds(const void* kern, size_t bytes) {
     if (n < 16) { seen[n] = kern; granted[n] = bytes; ++n; }
 }
 
+// rows of a workgroup's chunk: N / #CUs rounded up to whole 128-byte lines of a column, so that every wave's 1 KB
+// accesses are line-aligned (a chunk that starts inside a line makes every wave's store touch nine lines, two of them
+// partially: the column stream then runs at 72 % of the copy rate instead of ...: profiles/r03_*)
+static int64_t chunk_rows(int64_t N, int cus) {
+    static const int align = [] { const char* e = getenv("TTM_BAND_ROWALIGN"); int a = e ? atoi(e) : 32; return a < 2 ? 2 : a; }();
+    int64_t rows = (N + cus - 1) / cus;
+    rows = (rows + align - 1) / align * align;
+    return rows;
+}
+
 bool usable(const ttm_program* p, int k0, int k1) {
     return p && p->u_enabled && p->u_p_lag == 2 && p->u_h_cls >= 1 && p->u_h_cls <= 3 && p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 &&
            p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);
@@ -716,8 +789,7 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     lds += fixed;
     typedef void (*kern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, int64_t, int);
     kern_t kern = p->u_h_cls == 1 ? k_band_forward<1, 2> : p->u_h_cls == 2 ? k_band_forward<2, 2> : k_band_forward<3, 2>;
-    int64_t rows = (N + cus - 1) / cus;
-    rows = (rows + 1) & ~(int64_t)1;
+    const int64_t rows = chunk_rows(N, cus);
     const int64_t grid = (N + rows - 1) / rows;
     allow_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
@@ -765,8 +837,7 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
     typedef void (*kern_t)(const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int, double,
                            double, double, const double*, const double*, const int*, int, int, int, int64_t, int, int);
     kern_t kern = p->u_h_cls == 1 ? k_band_inverse<1, 2> : p->u_h_cls == 2 ? k_band_inverse<2, 2> : k_band_inverse<3, 2>;
-    int64_t rows = (N + cus - 1) / cus;
-    rows = (rows + 1) & ~(int64_t)1;
+    const int64_t rows = chunk_rows(N, cus);
     const int64_t grid = (N + rows - 1) / rows;
     allow_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
