@@ -47,7 +47,10 @@ __host__ __device__ constexpr int rec_stride(int cls, int lag) { return (TTM_P_H
 #define BAND_ROWS_TOGETHER 2                         /* rows of a thread whose instructions the scheduler may interleave (1, 2, 4) */
 #endif
 #ifndef BAND_FWD_NT
-#define BAND_FWD_NT 1                                /* non-temporal stores of the forward map's columns */
+#define BAND_FWD_NT 0                                /* non-temporal stores of the forward map's columns */
+#endif
+#ifndef BAND_INV_NT
+#define BAND_INV_NT 0
 #endif
 #ifndef BAND_PF
 #define BAND_PF 1                                    /* columns requested ahead of the one being evaluated */
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
 // table slot: [wl, wh, bucket scale, bucket bias, int32 {entries per bucket at most, 0}, int32 {degenerate, 0} | xs: W
 //              entries + 4 sentinels (+inf), rounded up to even | bucket index: nb + 1 uint16]
 #define BAND_RT_HDR 6
+#define BAND_RT_KMAX 24                                /* components per block, at most */
 
 __device__ __forceinline__ void band_bucket_params(double lo, double hi, int nb, double& scale, double& bias) {
     scale = (double)nb / (hi - lo);                                           // (k_table_index: the same IEEE division)
@@ -429,7 +433,8 @@ struct BandInvCtx {
 
 template <int CLS, int LAG>
 __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool full, int kb, int ke, const char* zcol, char* xcol, unsigned int tbase,
-                                                  const unsigned int (&roff)[BAND_NS / 2], double (&pend)[BAND_NS][LAG]) {
+                                                  const unsigned int (&roff)[BAND_NS / 2], double (&pend)[BAND_NS][LAG],
+                                                  const D2 (&zfirst)[BAND_NS / 2], bool have_first) {
     constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
     constexpr int NS = BAND_NS, NP = NS / 2, HALF = 2 * BAND_CT;
     cdbl_p rec = cx.P + (int64_t)(kb + LAG) * PS;
@@ -438,8 +443,13 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
     const double ystep = cx.ystep;
     const int nb1 = cx.nb - 1;
     D2 za[NP], zb[NP];
+    if (have_first) {                                         // (the chunk's first tile: requested before the block's tables)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) za[q] = band_load2(zcol + roff[q]);
+        for (int q = 0; q < NP; ++q) za[q] = zfirst[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) za[q] = band_load2(zcol + roff[q]);
+    }
     // interp1d slope form (TM:4062-4065) in the located interval and exp(-x^2/4) = E[i-1] exp(w), w = -delta (y_lo + x) / 4
     auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
         const double dx = fmax(x_hi - x_lo, 1e-300);                          // (tie at a flat start: k_inverse_rt)
@@ -523,8 +533,17 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
 #pragma unroll
             for (int e = 0; e < NS; ++e) interp(ey[e].y, xlo[e], xhi[e], ey[e].x, tg[e], r[e], E[e]);
         };
+#if defined(BAND_XI_NOSEARCH)                                /* (timing experiments: results wrong by construction) */
+#pragma unroll
+        for (int e = 0; e < NS; ++e) interp(tg[e], wl, wh, scale, tg[e], r[e], E[e]);
+#elif defined(BAND_XI_NOSOLVE)
+#pragma unroll
+        for (int e = 0; e < NS; ++e) { r[e] = tg[e]; E[e] = traw[e]; }
+#else
         if (per <= 2) search(std::integral_constant<int, 2>());
         else search(std::integral_constant<int, 4>());
+#endif
+#ifndef BAND_XI_NOOUTL
         if (outl != 0) {
             // outliers (the tails of the table, beyond the window, NaN; every row of a degenerate table): clip as
             // TM:4074-4076, np.searchsorted (left) over the whole row in memory, the same interpolation
@@ -546,13 +565,22 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
                 }
             }
         }
+#endif
         // x_k is pushed on to the components that read it, and stored
+#ifdef BAND_XI_NOPUSH
+#pragma unroll
+        for (int e = 0; e < NS; ++e) pend[e][0] = E[e] * start;
+#else
 #pragma unroll
         for (int e = 0; e < NS; ++e) band_push<DB, DA, LAG>(gc, start, r[e], E[e], pend[e]);
+#endif
+#ifdef BAND_XI_NOSTORE
+        if (r[0] == 1.2345e300)
+#endif
         if (full) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                band_store2<false>(xcol + (size_t)((tbase + (unsigned int)(q * HALF)) * 8u), r[2 * q], r[2 * q + 1]);
+                band_store2<BAND_INV_NT != 0>(xcol + (size_t)((tbase + (unsigned int)(q * HALF)) * 8u), r[2 * q], r[2 * q + 1]);
             }
         } else {
 #pragma unroll
@@ -614,37 +642,68 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
 #pragma unroll
         for (int l = 0; l < LAG; ++l) pend[e][l] = 0.0;
 
-    for (int kb = k0; kb < k1; kb += B) {
-        const int ke = kb + B < k1 ? kb + B : k1;
+    // Blocks of at most B components; odd workgroups take the short block first, so that neighbouring CUs reload their
+    // tables at different times (a block switch stalls a CU for ~6 us; out of phase, the others use the bandwidth)
+    int kfirst = B;
+    if ((blockIdx.x & 1) && (k1 - k0) % B) kfirst = (k1 - k0) % B;
+    for (int kb = k0, ke; kb < k1; kb = ke) {
+        ke = kb + (kb == k0 ? kfirst : B);
+        ke = ke < k1 ? ke : k1;
         const int nk = ke - kb;
-        __syncthreads();                                      // every wave is done with the previous block's tables
-        if (tid < nk) {
-            const int c = kb + tid;
-            double* slot = tabs + (size_t)tid * tab_slot;
-            double scale, bias;
-            band_bucket_params(tmin[c - k0], tmax[c - k0], nb, scale, bias);
-            slot[2] = scale; slot[3] = bias;
-            ((int*)slot)[8] = 0; ((int*)slot)[9] = 0;
-            slot[5] = 0.0;
-        }
-        __syncthreads();
-        // the tables of the block, sixteen components' loads in flight per thread
-        for (int cg = 0; cg < nk; cg += 16) {
-            for (int i = tid; i < Weven; i += CT) {
-                double v[16];
+        // the first column of z of the chunk's first tile is requested before the tables: one memory round trip instead of two
+        // in a row (a block switch is a string of them; 8 us each before: profiles/r03_*)
+        D2 zfirst[NP];
+        {
+            const char* zc0 = (const char*)Z + (int64_t)(kb - k0) * ldzb;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tab_x[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * T + w0 + min(i, W - 1)];
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (cg + u < nk) tabs[(size_t)(cg + u) * tab_slot + BAND_RT_HDR + i] = i < W ? v[u] : INFINITY;
+            for (int q = 0; q < NP; ++q) {
+                unsigned int n = (unsigned int)c0 + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
+                n = n < last_pair ? n : last_pair;
+                zfirst[q] = band_load2(zc0 + (size_t)(n * 8u));
             }
-            for (int i = tid; i <= nb; i += CT) {
-                int v[16];
+        }
+        __syncthreads();                                      // every wave is done with the previous block's tables
+        // the tables of the block: every load of the block in flight at once (element i of every table by thread i; the
+        // bucket indices sixteen bytes at a time), the search parameters next to them
+        {
+            constexpr int KMAX = BAND_RT_KMAX;                // components per block, at most (the host plans for it)
+            double lo = 0.0, hi = 0.0;
+            if (tid < nk) { lo = tmin[kb - k0 + tid]; hi = tmax[kb - k0 + tid]; }
+            {
+                double v[KMAX];
+                const int i = tid < Weven ? tid : Weven - 1;  // (clamped, unconditional: all loads in flight together)
+                const double* src = tab_x + (int64_t)(kb - k0) * T + w0 + min(i, W - 1);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = bkt[(int64_t)(kb - k0 + min(cg + u, nk - 1)) * (nb + 1) + i];
+                for (int u = 0; u < KMAX; ++u) v[u] = src[(int64_t)min(u, nk - 1) * T];
+                // (stores unconditional too: a slot beyond the block's last table repeats that table's value - the clamped
+                // load - into that table's slot; branches here would spill the values in flight)
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (cg + u < nk) ((unsigned short*)(tabs + (size_t)(cg + u) * tab_slot + BAND_RT_HDR + Weven))[i] = (unsigned short)v[u];
+                for (int u = 0; u < KMAX; ++u) tabs[(size_t)min(u, nk - 1) * tab_slot + BAND_RT_HDR + i] = i < W ? v[u] : INFINITY;
+            }
+            {
+                constexpr int BR = (KMAX * 256 + CT - 1) / CT; // rounds of the bucket copy: a component's nb + 1 = 1024 int32 = 256 x 16 bytes
+                int4 bv[BR];
+#pragma unroll
+                for (int rd = 0; rd < BR; ++rd) {
+                    const int idx = rd * CT + tid, c = min(idx >> 8, nk - 1), w = idx & 255;
+                    bv[rd] = *(const int4*)(bkt + (int64_t)(kb - k0 + c) * (nb + 1) + 4 * w);
+                }
+#pragma unroll
+                for (int rd = 0; rd < BR; ++rd) {
+                    const int idx = rd * CT + tid, c = min(idx >> 8, nk - 1), w = idx & 255;
+                    unsigned short* bs = (unsigned short*)(tabs + (size_t)c * tab_slot + BAND_RT_HDR + Weven) + 4 * w;
+                    const uint2 pk = {(unsigned int)(bv[rd].x & 0xffff) | ((unsigned int)bv[rd].y << 16),
+                                      (unsigned int)(bv[rd].z & 0xffff) | ((unsigned int)bv[rd].w << 16)};
+                    *(uint2*)bs = pk;
+                }
+            }
+            if (tid < nk) {
+                double* slot = tabs + (size_t)tid * tab_slot;
+                double scale, bias;
+                band_bucket_params(lo, hi, nb, scale, bias);
+                slot[2] = scale; slot[3] = bias;
+                ((int*)slot)[8] = 0; ((int*)slot)[9] = 0;
+                slot[5] = 0.0;
             }
         }
         __syncthreads();
@@ -652,9 +711,17 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
         for (int c = tid >> 6; c < nk; c += CT >> 6) {
             const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + BAND_RT_HDR + Weven);
             int per = 0;
-            for (int i = tid & 63; i < nb; i += 64) {
-                const int b0 = bs[i], b1 = bs[i + 1];
-                if (b1 > w0 && b0 < w0 + W) per = max(per, b1 - b0);
+            {                                                 // lane l: buckets 16 l .. 16 l + 15 from two 16-byte reads (nb + 1 = 1024 entries)
+                const int l = tid & 63;
+                const uint4 qa = *(const uint4*)(bs + 16 * l), qb = *(const uint4*)(bs + 16 * l + 8);
+                const unsigned int nxt = l < 63 ? bs[16 * l + 16] : 0u;
+                const unsigned int w[9] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, nxt};
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int b0 = (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                    const int b1 = (int)((w[(i + 1) >> 1] >> (16 * ((i + 1) & 1))) & 0xffffu);
+                    if (16 * l + i < nb && b1 > w0 && b0 < w0 + W) per = max(per, b1 - b0);
+                }
             }
             for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
             double* slot = tabs + (size_t)c * tab_slot;
@@ -701,7 +768,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
             }
             const char* zcol = (const char*)Z + (int64_t)(kb - k0) * ldzb;
             char* xcol = (char*)X + (int64_t)colb * ldxb;
-            band_inverse_tile<CLS, LAG>(cx, full, kb, ke, zcol, xcol, tbase, roff, pend);
+            band_inverse_tile<CLS, LAG>(cx, full, kb, ke, zcol, xcol, tbase, roff, pend, zfirst, tile == 0);
         }
     }
 }
@@ -729,8 +796,10 @@ static void allow_lds(const void* kern, size_t bytes) {
 // partially: the column stream then runs at 72 % of the copy rate instead of ...: profiles/r03_*)
 static int64_t chunk_rows(int64_t N, int cus) {
     static const int align = [] { const char* e = getenv("TTM_BAND_ROWALIGN"); int a = e ? atoi(e) : 32; return a < 2 ? 2 : a; }();
+    static const int forced = [] { const char* e = getenv("TTM_BAND_ROWS"); return e ? atoi(e) : 0; }();      // (tuning)
     int64_t rows = (N + cus - 1) / cus;
     rows = (rows + align - 1) / align * align;
+    if (forced > 0 && forced >= rows) rows = forced;
     return rows;
 }
 
@@ -801,13 +870,16 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
 int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
             const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int nb, int cus,
             size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name) {
-    if (!usable(p, k0, k1) || !y_affine || T < 64 || T > 4096 || nb < 4 || nb > 65535 || N >= ((int64_t)1 << 28)) return 1;
+    if (!usable(p, k0, k1) || !y_affine || T < 64 || T > 4096 || nb + 1 != 1024 || N >= ((int64_t)1 << 28)) return 1;      // (bucket rows copied 16 bytes at a time, 256 units per row)
+    if ((uintptr_t)bkt % 16 != 0) return 1;
     const double ymax = fabs(y_affine[0]) > fabs(y_affine[2]) ? fabs(y_affine[0]) : fabs(y_affine[2]);
     if (!(y_affine[1] > 0.0 && y_affine[1] * ymax * 0.5 <= 0.1)) return 1;                 // (exp(w) by its Taylor polynomial)
     const bool aligned = ((uintptr_t)Zsoa % 16 == 0) && (ldz % 2 == 0) && ldz >= ((N + 1) & ~(int64_t)1) && ((uintptr_t)Xsoa % 16 == 0) &&
                          (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1);
     if (!aligned) return 1;
     const int ncomp = k1 - k0;
+    static const int stagger = [] { const char* e = getenv("TTM_BAND_STAGGER"); return e ? atoi(e) : 1; }();
+    static const double wfrac = [] { const char* e = getenv("TTM_BAND_WFRAC"); return e ? atof(e) : 0.52; }();
     int W = T, w0 = 0, Weven = 0, tab_slot = 0, Bc = 0, nblk = 0;
     size_t lds = 0;
     auto plan = [&]() {
@@ -818,16 +890,17 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
         if (fixed + (size_t)tab_slot * 8 > lds_per_cu) return;
         Bc = (int)((lds_per_cu - fixed) / ((size_t)tab_slot * 8));
         if (Bc > ncomp) Bc = ncomp;
+        if (Bc > BAND_RT_KMAX) Bc = BAND_RT_KMAX;
         if (block > 0 && block < Bc) Bc = block;
         nblk = (ncomp + Bc - 1) / Bc;
-        Bc = (ncomp + nblk - 1) / nblk;
+        if (!stagger) Bc = (ncomp + nblk - 1) / nblk;                     // even blocks (staggered: full blocks + a short one)
         lds = fixed + (size_t)Bc * tab_slot * 8;
     };
     plan();
     // windowed tables when that saves a pass over the chunk (k_inverse_rt)
     if (window != 0 && (window > 0 || (Bc > 0 && nblk > 1))) {
         const int Bfull = Bc, nfull = nblk;
-        W = window > 0 ? (window < 16 ? 16 : window) : (int)(0.65 * T);
+        W = window > 0 ? (window < 16 ? 16 : window) : (int)(wfrac * T);
         if (W >= T) W = T - 1;
         w0 = (T - W) / 2;
         plan();
