@@ -80,6 +80,27 @@ if '--no-oracle' not in sys.argv:
         e = np.max(np.abs(Zk - Zo) / (np.abs(Zo) + 1.0))
         print('mode', mode, 'vs oracle: max rel %.3e' % e)
         out['fwd_vs_oracle_%d' % mode] = float(e)
+# ---- fused density pass (S, log det, sum of squares) ---------------------------------------------------------------
+dres = {}
+sigma = tm._to_dev(np.asarray(tm.X_std[:tm.D], dtype=float))
+for mode in (0, -1):
+    opt('band_fwd', mode)
+    for withz in (True, False):
+        ld, ss = tm._empty(Nn), tm._empty(Nn)
+        Zd = tm._cols(tm.D, Nn) if withz else None
+        call = (lambda: tm.forward_device(Xs, Nn, Z=Zd, logdet=ld, sigma=sigma, sumsq=ss)) if withz else \
+            (lambda: _capi.check(lib.ttm_forward(tm._pp, tm._ptr(tm._pack_coeffs()), tm._ptr(tm._pack_coeffs()._ttm_fold), tm._ptr(Xs), Xs.shape[1], Nn,
+                                                 0, tm.D, None, Nn, tm._ptr(ld), tm._ptr(sigma), tm._ptr(ss), tm._stream())))
+        call(); torch.cuda.synchronize()
+        name = lib.ttm_last_kernel().decode()
+        dres[(mode, withz)] = (ld.clone(), ss.clone())
+        ms = timed(call, 50)
+        out['density_%s_%s' % (name, 'z' if withz else 'noz')] = ms
+        print('density', name, 'with Z' if withz else 'no Z  ', '%.4f ms' % ms, ' frac of 8 TB/s on 8N(d+1): %.3f' % (8.0 * Nn * (tm.D + 1) / (ms * 1e-3) / 8e12))
+for withz in (True, False):
+    a, b = dres[(0, withz)], dres[(-1, withz)]
+    print('density band vs hl (Z %s): logdet max abs %.3e  sumsq max rel %.3e' % (withz, (a[0] - b[0]).abs().max().item(),
+                                                                             ((a[1] - b[1]).abs() / (a[1].abs() + 1)).max().item()))
 ONLY = os.environ.get('TTM_BAND_CHECK_ONLY', '')
 if ONLY == 'fwd':
     json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'band_check.json'), 'w'), indent=1)

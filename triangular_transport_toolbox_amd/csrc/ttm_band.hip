@@ -284,6 +284,251 @@ __device__ __forceinline__ void band_forward_tile(cdbl_p P, cdbl_p kt, const dou
         if (j + i < ke) step(j + i, xr[i], xr[(i + PF) % RING]);
 }
 
+// ---------------------------------------------------------------------------
+// fused density pass: S (optional), sum_k log(dS_k/dx_k / sigma_k) and sum_k S_k^2 per row (TM:2569-2712)
+// ---------------------------------------------------------------------------
+// log(x): fdlibm's polynomial on the reduced argument, division by a Newton reciprocal (<= 2 ulp)
+__device__ __forceinline__ double band_log(double x) {
+    int e;
+    double m = frexp(x, &e);                                  // [0.5, 1)
+    const bool small = m < 0.70710678118654752440;
+    m = small ? m * 2.0 : m;
+    e = small ? e - 1 : e;
+    const double f = m - 1.0;
+    const double den = 2.0 + f;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    rc = fma(fma(-den, rc, 1.0), rc, rc);
+    const double q = f * rc;
+    const double sq = fma(fma(-den, q, f), rc, q);
+    const double z = sq * sq;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    double res = dk * 6.93147180369123816490e-01 - ((hfsq - (sq * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    // (0, negative, NaN, inf by selects - the library call here would be inlined into the column loop; denormals are
+    // handled by frexp itself: the kernels run with fp64 denormals on)
+    res = x == 0.0 ? -INFINITY : res;
+    res = x < 0.0 ? NAN : res;
+    res = (x != x || x == INFINITY) ? x : res;
+    return res;
+}
+
+// the spline and its derivative with respect to the local coordinate
+__device__ __forceinline__ void band_spline_d(const double* tab, int nI, double sp_a, double sp_b, double sp_ds, double x, double& m, double& dm) {
+    const int col = band_med3((int)fma(x, sp_b, sp_a), 0, nI - 1);
+    const double* cp = (const double*)((const char*)tab + __umul24((unsigned int)col, TTM_U_TSTRIDE * 8));
+    double c[12];
+#pragma unroll
+    for (int i = 0; i < 12; i += 2) { const D2 v = *(const D2*)(cp + i); c[i] = v.x; c[i + 1] = v.y; }
+    const double s = fma(x, sp_ds, cp[12]);
+    double a = c[11], da = 0.0;
+#pragma unroll
+    for (int i = 10; i >= 0; --i) {
+        da = fma(da, s, a);
+        a = fma(a, s, c[i]);
+    }
+    m = a; dm = da;
+}
+
+// The log-determinant is taken as the log of PRODUCTS of BAND_LD_CHUNK derivatives (one log per chunk instead of one per
+// evaluation: a third of the pass's arithmetic); the uniform factors of the derivatives (2/h of every spline, 1/sigma_k)
+// enter as one number per launch.  A product of four derivatives cannot leave the fp64 range unless one of them does.
+#define BAND_LD_CHUNK 4
+#define BAND_UNI 256                                  /* components of a density pass, at most */
+#ifndef BAND_DENS_RT
+#define BAND_DENS_RT 2
+#endif
+#ifndef BAND_DENS_NS
+#define BAND_DENS_NS 4
+#endif
+template <int CLS, int LAG, bool WRITE_Z>
+__global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                          const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                          double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
+                                                          const double* __restrict__ sigma, double* __restrict__ sumsq,
+                                                          int64_t rows_per_wg, int Bc) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
+    // (two rows per thread: the pass carries three more running values per row than the plain map and is bound by its
+    // arithmetic, not by the column stream)
+    // (four rows per thread without Z; with it the masked stores of every step copy leave registers for two)
+    constexpr int NS = WRITE_Z ? 2 : BAND_DENS_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT;
+    extern __shared__ __align__(16) double g_lds[];
+    double* etab = g_lds;
+    double* tabs = g_lds + BAND_ET_DOUBLES;
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
+    const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
+    for (int i = tid; i < TTM_BAND_ET_N; i += CT) *(D2*)(etab + 2 * i) = *(const D2*)(g_band_etab + 2 * i);
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    cdbl_p kt = (cdbl_p)g_band_taylor;
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const unsigned int c1_32 = (unsigned int)c1;
+    const int64_t ldxb = ldx * 8, ldzb = ldz * 8;
+    // uniform part of the log-determinant: sum_k log(2 / h_k) - sum_k log(sigma_k): one logarithm per thread, summed in
+    // component order by thread 0 (every thread taking all of them was a fifth of the launch)
+    __shared__ double s_uni[BAND_UNI];
+    double luni;
+    {
+        const int ncomp = k1 - k0;
+        for (int k = tid; k < ncomp; k += CT) {
+            double v = band_log(P[(int64_t)(k0 + k + LAG) * PS + 4]);
+            if (sigma) v -= band_log(sigma[k]);
+            s_uni[k] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int k = 0; k < ncomp; ++k) acc += s_uni[k];
+            s_uni[0] = acc;
+        }
+        __syncthreads();
+        luni = s_uni[0];
+    }
+    for (int tile = 0; tile < ntile; ++tile) {
+        const unsigned int tbase = (unsigned int)c0 + (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+        unsigned int roff[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned int n = tbase + (unsigned int)(q * HALF);
+            n = n < last_pair ? n : last_pair;
+            roff[q] = n * 8u;
+        }
+        double ld[NS], ss[NS], prod[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) { ld[e] = 0.0; ss[e] = 0.0; prod[e] = 1.0; }
+        double pend[NS][LAG];
+        for (int kb = k0; kb < k1; kb += Bc) {
+            const int ke = kb + Bc < k1 ? kb + Bc : k1;
+            __syncthreads();
+            int tab0;
+            {
+                cint_p rb = (cint_p)(P + (int64_t)(kb + LAG) * PS), re = (cint_p)(P + (int64_t)(ke - 1 + LAG) * PS);
+                tab0 = rb[11];
+                const int n = re[11] + TTM_U_TSTRIDE * re[10] - tab0;
+                for (int i = 2 * tid; i < n; i += 2 * CT) *(D2*)(tabs + i) = *(const D2*)(U_ + tab0 + i);
+            }
+            __syncthreads();
+            const int colb = kcol0 + (kb - k0);
+            if (kb == k0 || true) {
+#pragma unroll
+                for (int l = 0; l < LAG; ++l) {
+                    const double s0 = P[(int64_t)(kb + l) * PS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) pend[e][l] = s0;
+                }
+                if (colb > 0) {
+                    for (int i = 0; i < LAG; ++i) {
+                        const int cc = colb - LAG + i;
+                        cdbl_p rec = P + (int64_t)(kb + i) * PS;
+                        const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            D2 xv = *(const D2*)(col + roff[q]);
+                            if (cc < 0) { xv.x = 0.0; xv.y = 0.0; }
+                            band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[0], xv.x, band_expq(etab, xv.x, kt), pend[2 * q]);
+                            band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[0], xv.y, band_expq(etab, xv.y, kt), pend[2 * q + 1]);
+                        }
+                    }
+                }
+            }
+            const char* xcol = (const char*)X + (int64_t)colb * ldxb;
+            char* zcol = WRITE_Z ? (char*)Z + (int64_t)(kb - k0) * ldzb : nullptr;
+            cdbl_p rec = P + (int64_t)(kb + LAG) * PS;
+            D2 xa[NP], xb[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xa[q] = band_load2(xcol + roff[q]);
+            auto step = [&](int j, const D2 (&xc)[NP], D2 (&xn)[NP]) {
+                {
+                    const char* xnext = j + 1 < ke ? xcol + ldxb : xcol;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) xn[q] = band_load2(xnext + roff[q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double start = rec[0], sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4];
+                cint_p ri = (cint_p)rec;
+                const int nI = ri[10];
+                const double* tab = tabs + (ri[11] - tab0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    double zv[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = 2 * q + h;
+                        const double x = h ? xc[q].y : xc[q].x;
+                        double m, dm;
+                        band_spline_d(tab, nI, sp_a, sp_b, sp_ds, x, m, dm);
+                        const double E = band_expq(etab, x, kt);
+                        zv[h] = pend[e][0] + m;
+                        ss[e] = fma(zv[h], zv[h], ss[e]);
+                        prod[e] *= dm;
+                        band_push<DB, DA, LAG>(rec + TTM_P_HDR, start, x, E, pend[e]);
+                        if (BAND_DENS_RT == 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (BAND_DENS_RT == 2) __builtin_amdgcn_sched_barrier(0);
+                    if (WRITE_Z) {
+                        const unsigned int n = tbase + (unsigned int)(q * HALF);
+                        char* zp = zcol + (size_t)(n * 8u);
+                        if (n + 1 < c1_32) band_store2<false>(zp, zv[0], zv[1]);
+                        else if (n < c1_32) *(double*)zp = zv[0];
+                    }
+                }
+                if (WRITE_Z && (((j - k0) & (BAND_LD_CHUNK - 1)) == BAND_LD_CHUNK - 1)) {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) { ld[e] += band_log(prod[e]); prod[e] = 1.0; }
+                }
+                rec += PS; xcol += ldxb;
+                if (WRITE_Z) zcol += ldzb;
+            };
+            // four columns at a time, then ONE place where the chunk's products go through the logarithm (inside the step the
+            // four inlined logarithms of every step copy cost the registers of two rows)
+            auto flush_ld = [&]() {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) { ld[e] += band_log(prod[e]); prod[e] = 1.0; }
+            };
+            int j = kb;
+            if (WRITE_Z) {                                    // (fewer step copies: two columns at a time)
+                for (; j + 1 < ke; j += 2) {
+                    step(j, xa, xb);
+                    step(j + 1, xb, xa);
+                }
+            } else {
+                for (; j + 3 < ke; j += 4) {
+                    step(j, xa, xb);
+                    step(j + 1, xb, xa);
+                    step(j + 2, xa, xb);
+                    step(j + 3, xb, xa);
+                    flush_ld();                               // (a flush every other round costs 200 spilled registers)
+                }
+                for (; j + 1 < ke; j += 2) {
+                    step(j, xa, xb);
+                    step(j + 1, xb, xa);
+                }
+            }
+            if (j < ke) step(j, xa, xb);
+            flush_ld();
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const unsigned int n = tbase + (unsigned int)(q * HALF);
+            if (logdet) {
+                if (n + 1 < c1_32) band_store2<false>((char*)(logdet + n), ld[2 * q] + luni, ld[2 * q + 1] + luni);
+                else if (n < c1_32) logdet[n] = ld[2 * q] + luni;
+            }
+            if (sumsq) {
+                if (n + 1 < c1_32) band_store2<false>((char*)(sumsq + n), ss[2 * q], ss[2 * q + 1]);
+                else if (n < c1_32) sumsq[n] = ss[2 * q];
+            }
+        }
+    }
+}
+
 // LDS: [E table: 2 x 801 | splines of the block's components, as they stand in the U section]
 template <int CLS, int LAG>
 __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
@@ -839,12 +1084,14 @@ static int plan_blocks(const ttm_program* p, int k0, int k1, size_t budget, int*
 
 int forward(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa, int64_t ldz,
             double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, void* stream, const char** kernel_name) {
-    (void)sigma;
-    if (!usable(p, k0, k1) || !Zsoa || logdet || sumsq || N >= ((int64_t)1 << 28)) return 1;
-    const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) && ((uintptr_t)Zsoa % 16 == 0) &&
-                         (ldz % 2 == 0) && ((uintptr_t)U % 16 == 0);
+    if (!usable(p, k0, k1) || (!Zsoa && !logdet && !sumsq) || N >= ((int64_t)1 << 28)) return 1;
+    const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
+                         (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) && ((uintptr_t)U % 16 == 0) &&
+                         (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0);
     if (!aligned) return 1;
-    const size_t fixed = (size_t)BAND_ET_DOUBLES * 8;
+    const size_t stat = (logdet || sumsq) ? (size_t)BAND_UNI * 8 : 0;                    // (static array of the density pass)
+    if ((logdet || sumsq) && k1 - k0 > BAND_UNI) return 1;
+    const size_t fixed = (size_t)BAND_ET_DOUBLES * 8 + stat;
     if (lds_per_cu <= fixed) return 1;
     int nblk = 0;
     const int Bc = plan_blocks(p, k0, k1, lds_per_cu - fixed, &nblk);
@@ -855,7 +1102,20 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
         for (int k = kb; k < kb + Bc && k < k1; ++k) s += (size_t)p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] * TTM_U_TSTRIDE * 8;
         lds = s > lds ? s : lds;
     }
-    lds += fixed;
+    lds += fixed - stat;                                      // (dynamic part)
+    if (logdet || sumsq) {
+        typedef void (*dkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
+                                double*, int64_t, int);
+        dkern_t dk = Zsoa ? (p->u_h_cls == 1 ? k_band_density<1, 2, true> : p->u_h_cls == 2 ? k_band_density<2, 2, true> : k_band_density<3, 2, true>)
+                          : (p->u_h_cls == 1 ? k_band_density<1, 2, false> : p->u_h_cls == 2 ? k_band_density<2, 2, false> : k_band_density<3, 2, false>);
+        const int64_t rows = chunk_rows(N, cus);
+        const int64_t grid = (N + rows - 1) / rows;
+        allow_lds((const void*)dk, lds);
+        hipLaunchKernelGGL(dk, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                           (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, rows, Bc);
+        if (kernel_name) *kernel_name = "k_band_density";
+        return 0;
+    }
     typedef void (*kern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, int64_t, int);
     kern_t kern = p->u_h_cls == 1 ? k_band_forward<1, 2> : p->u_h_cls == 2 ? k_band_forward<2, 2> : k_band_forward<3, 2>;
     const int64_t rows = chunk_rows(N, cus);

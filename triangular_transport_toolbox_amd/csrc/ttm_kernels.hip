@@ -2664,8 +2664,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         int ways = p->plan_ways;
         if (ways < 1 || ways > TTM_PLAN_WAYS) ways = TTM_PLAN_WAYS;
         // banded maps, large ensembles: push-form kernel with every spline resident in LDS (csrc/ttm_band.hip)
-        if (tuning().band_fwd != 0 && !tuning().u_no_hot && Zsoa && !logdet && !sumsq && (N >= 64 * 1024 || tuning().band_fwd == 1) &&
-            ttm_band::usable(p, k0, k1)) {
+        if (tuning().band_fwd != 0 && !tuning().u_no_hot && (N >= 64 * 1024 || tuning().band_fwd == 1) && ttm_band::usable(p, k0, k1)) {
             const char* name = nullptr;
             if (ttm_band::forward(p, fold + fold_base_size(p), k0, k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, device_info().cus,
                                   device_info().lds_per_cu, stream, &name) == 0)
