@@ -1,0 +1,163 @@
+"""
+Push-form kernels of banded U-form maps (csrc/ttm_band.hip: k_band_forward, k_band_density, k_band_inverse) against the
+oracle and against the kernels they replace (k_forward_hl, k_inverse_rt), at sizes the oracle finishes in seconds:
+every degree class, sweeps that start inside the map (the columns in front are pushed first), chunks of
+several tiles, several blocks of resident tables, rows the resident paths hand to their exact fall-backs.
+The host side of it (band detection, push-record geometry) runs on CPU.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tests.test_uform import _synthetic_separable
+from tests.util import relerr
+
+
+def _banded_with_conditioning(D, skip, band=2):
+    """D components behind `skip` conditioning columns: component k lives on column k + skip and reads the `band` columns
+    in front of it, conditioning columns included."""
+    mon, non = [], []
+    for k in range(D):
+        kc = k + skip
+        nm = [[]]
+        for j in range(max(0, kc - band), kc):
+            nm += [[j], [j, j, 'HF'], [j, j, j, 'HF']]
+        non.append(nm)
+        mon.append(['LET %d' % kc, 'iRBF %d' % kc, 'iRBF %d' % kc, 'RET %d' % kc])
+    return mon, non
+
+
+CASES = {
+    'c5_shape': dict(D=6, d=6, spec=lambda: _synthetic_separable(6, 2, 3, 1, 2), cls=1),
+    'class_55': dict(D=5, d=5, spec=lambda: _synthetic_separable(5, 2, 5, 3, 3), cls=2),
+    'class_77': dict(D=5, d=5, spec=lambda: _synthetic_separable(5, 2, 7, 6, 2), cls=3),
+    'lag_one': dict(D=5, d=5, spec=lambda: _synthetic_separable(5, 1, 4, 1, 0), cls=2),
+}
+
+
+def _build(case, n=5003, seed=0):
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    c = CASES[case]
+    rng = np.random.default_rng(seed + 17 * c['D'])
+    d = c['d']
+    X = rng.standard_normal((n, d)) @ (np.tril(rng.standard_normal((d, d)) * 0.4) + np.eye(d)).T + 0.3 * rng.standard_normal((n, d)) ** 2
+    mon, non = c['spec']()
+    kw = dict(monotonicity='separable monotonicity')
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(c['D']):
+        cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
+    return tm, om, X, rng
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_band_detection_and_push_record_geometry(case):
+    """Host side: which maps are banded, and where their push records live in the U section."""
+    from tests.hostemu import emu
+    from triangular_transport_toolbox_amd import termtable
+    with emu.install():
+        tm, om, X, rng = _build(case, n=400)
+        cm = tm._cm
+        assert cm.u_enabled and cm.u_h_cls == CASES[case]['cls']
+        assert cm.u_p_lag == termtable.P_LAG_MAX == 2
+        gp = termtable.H_DB[cm.u_h_cls] + 1 + termtable.H_DA[cm.u_h_cls]
+        assert cm.u_p_stride % 8 == 0 and cm.u_p_stride >= termtable.P_HDR + 2 * gp
+        assert cm.u_p_off % 8 == 0 and cm.u_p_off >= cm.u_h_off + cm.D * (termtable.H_HDR + cm.u_h_ng * termtable.H_GS[cm.u_h_cls])
+        assert cm.u_size >= cm.u_p_off + (cm.D + 2) * cm.u_p_stride
+
+
+def test_maps_that_are_not_banded_have_no_push_records():
+    from tests.hostemu import emu
+    from triangular_transport_toolbox_amd import specs
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    with emu.install():
+        rng = np.random.default_rng(2)
+        for mon, non, d in (_synthetic_separable(6, 3, 3, 1, 2) + (6,),          # a group three columns back
+                            specs.dense_separable_spec(5, 3) + (5,),
+                            _banded_with_conditioning(4, 2) + (6,)):             # conditioning columns: no hot records (cache misses)
+            X = rng.standard_normal((300, d))
+            tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, monotonicity='separable monotonicity')
+            assert tm._cm.u_p_lag == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_band_kernels_against_the_oracle_and_the_kernels_they_replace(case, ttm_opt):
+    tm, om, X, rng = _build(case)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    D, d = CASES[case]['D'], CASES[case]['d']
+    E = d - D
+    N = len(X)
+    Zo = om.map(X)
+    with np.errstate(all='ignore'):
+        pref = om.evaluate_pullback_density(X[:400])
+    ok = np.isfinite(pref)
+    Zin = rng.standard_normal((N, D))
+    Zin[:40] *= 3.5                                         # (targets beyond the resident window and beyond the tables)
+    Xstar = X[:, :E] if E else None
+    Xo = om.inverse_map(Zin, X_star=Xstar)
+    Xs = (X - om.X_mean) / om.X_std
+    # the kernels the band kernels replace, forced onto their large-ensemble paths
+    ttm_opt('u_loader', 1); ttm_opt('band_fwd', 0); ttm_opt('band_inv', 0)
+    Zh = tm.map(X)
+    Xh = tm.inverse_map(Zin, X_star=Xstar)
+    ph = tm.evaluate_pullback_density(X[:400])
+    for cus, block in ((-1, -1), (1, -1), (3, 2), (2, 1)):    # one tile per chunk | several tiles | several blocks
+        ttm_opt('band_fwd', 1); ttm_opt('band_inv', 1); ttm_opt('band_cus', cus); ttm_opt('rt_block', block)
+        Z = tm.map(X)
+        tm.forward_device(tm._Xs, tm._N)
+        assert lib.ttm_last_kernel().decode() == 'k_band_forward'
+        assert relerr(Z, Zo) < 1e-11, (cus, block)
+        assert relerr(Z, Zh) < 1e-13
+        pgot = tm.evaluate_pullback_density(X[:400])
+        assert np.array_equal(np.isfinite(pgot), ok) and relerr(pgot[ok], pref[ok]) < 1e-10 and relerr(pgot[ok], ph[ok]) < 1e-12
+        for k in sorted({0, D // 2, D - 1}):                  # sweeps that start inside the map: the columns in front are pushed first
+            assert relerr(tm.s(Xs, k), om.s(Xs, k)) < 1e-12
+        Xi = tm.inverse_map(Zin, X_star=Xstar)
+        assert relerr(Xi, Xo) < 1e-11, (cus, block)
+        assert relerr(Xi, Xh) < 1e-13                         # (k_inverse_rt: another summation order of the offsets)
+        tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N)
+        if case != 'class_55':                                # (its RBF term makes the tables non-monotone: sorted on the host, generic lookup)
+            assert lib.ttm_last_kernel().decode() == 'k_band_inverse'
+    # the bits do not depend on how the rows are cut into chunks and tiles or the components into blocks
+    ttm_opt('band_cus', -1); ttm_opt('rt_block', -1)
+    Z0, X0 = tm.map(X), tm.inverse_map(Zin, X_star=Xstar)
+    for cus, block in ((1, -1), (3, 2), (2, 1)):
+        ttm_opt('band_cus', cus); ttm_opt('rt_block', block)
+        assert np.array_equal(tm.map(X), Z0)
+        Xi = tm.inverse_map(Zin, X_star=Xstar)
+        # (a tile that re-reads its columns at a block boundary takes exp(-x^2/4) there from the series, not the interval)
+        assert relerr(Xi, X0) < 1e-14
+
+
+@pytest.mark.gpu
+def test_band_kernels_on_rows_outside_their_resident_paths(ttm_opt):
+    """NaN, infinities and |x| far beyond the E table / the table windows: the forward map holds exp(-x^2/4) at 1.6e-28
+    beyond 16 standard deviations, the inverse hands the row to the search in memory."""
+    tm, om, X, rng = _build('c5_shape', n=3001)
+    ttm_opt('u_loader', 1); ttm_opt('band_fwd', 1); ttm_opt('band_inv', 1)
+    Xb = X.copy()
+    Xb[5] = X[5] + 40.0 * om.X_std                          # 40 standard deviations out
+    Xb[6, 2] = np.nan
+    Xb[7, 1] = np.inf
+    with np.errstate(all='ignore'):
+        Zo = om.map(Xb)
+    Z = tm.map(Xb)
+    fin = np.isfinite(Zo)
+    assert np.array_equal(np.isfinite(Z), fin)              # a NaN / inf reaches exactly the components that read its column
+    assert relerr(Z[fin], Zo[fin]) < 1e-11
+    assert np.all(np.isnan(Z[6, 2:5])) and np.all(np.isfinite(Z[6, :2])) and np.isfinite(Z[6, 5])
+    Zin = rng.standard_normal((len(X), tm.D))
+    Zin[3] = 50.0; Zin[4] = -50.0; Zin[8, 0] = np.nan
+    with np.errstate(all='ignore'):
+        Xo = om.inverse_map(Zin)
+    Xi = tm.inverse_map(Zin)
+    keep = np.ones(len(X), bool); keep[8] = False
+    assert relerr(Xi[keep], Xo[keep]) < 1e-11
+    assert np.all(np.isnan(Xi[8]))

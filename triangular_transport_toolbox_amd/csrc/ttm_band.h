@@ -27,9 +27,10 @@ int build_records(const ttm_program* p, double* U, void* stream);
 // can [k0, k1) of this program run through the band kernels?
 bool usable(const ttm_program* p, int k0, int k1);
 
-// forward map of columns [k0, k1) (Z != nullptr, plain map: no log-determinant / sum of squares)
+// forward map of the components [k0, k1): Z and / or the fused log-determinant and sum of squares (`block` > 0: at most that
+// many components' splines resident at a time)
 int forward(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa,
-            int64_t ldz, double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, void* stream, const char** kernel_name);
+            int64_t ldz, double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, int block, void* stream, const char** kernel_name);
 
 // table inverse (resident windowed tables, as k_inverse_rt) in push form
 int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx,

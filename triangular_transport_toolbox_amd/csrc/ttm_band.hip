@@ -1083,7 +1083,7 @@ static int plan_blocks(const ttm_program* p, int k0, int k1, size_t budget, int*
 }
 
 int forward(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa, int64_t ldz,
-            double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, void* stream, const char** kernel_name) {
+            double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, int block, void* stream, const char** kernel_name) {
     if (!usable(p, k0, k1) || (!Zsoa && !logdet && !sumsq) || N >= ((int64_t)1 << 28)) return 1;
     const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1) &&
                          (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0)) && ((uintptr_t)U % 16 == 0) &&
@@ -1094,8 +1094,9 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     const size_t fixed = (size_t)BAND_ET_DOUBLES * 8 + stat;
     if (lds_per_cu <= fixed) return 1;
     int nblk = 0;
-    const int Bc = plan_blocks(p, k0, k1, lds_per_cu - fixed, &nblk);
+    int Bc = plan_blocks(p, k0, k1, lds_per_cu - fixed, &nblk);
     if (Bc <= 0) return 1;
+    if (block > 0 && block < Bc) Bc = block;
     size_t lds = 0;
     for (int kb = k0; kb < k1; kb += Bc) {
         size_t s = 0;

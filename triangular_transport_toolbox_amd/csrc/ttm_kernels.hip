@@ -2384,7 +2384,8 @@ static const DeviceInfo& device_info() {
     X(rt_window, -1)     /* resident entries per table of k_inverse_rt: 0 whole tables, > 0 that many, -1 planned    */ \
     X(gram_mfma, -1)     /* 0: Gram matrices by the pairwise kernel instead of the matrix cores                      */ \
     X(band_fwd, -1)      /* 0: banded maps through k_forward_hl instead of the push-form kernel (csrc/ttm_band.hip)   */ \
-    X(band_inv, -1)      /* 0: banded maps through k_inverse_rt instead of the push-form kernel                      */
+    X(band_inv, -1)      /* 0: banded maps through k_inverse_rt instead of the push-form kernel                      */ \
+    X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2666,8 +2667,9 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         // banded maps, large ensembles: push-form kernel with every spline resident in LDS (csrc/ttm_band.hip)
         if (tuning().band_fwd != 0 && !tuning().u_no_hot && (N >= 64 * 1024 || tuning().band_fwd == 1) && ttm_band::usable(p, k0, k1)) {
             const char* name = nullptr;
-            if (ttm_band::forward(p, fold + fold_base_size(p), k0, k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, device_info().cus,
-                                  device_info().lds_per_cu, stream, &name) == 0)
+            if (ttm_band::forward(p, fold + fold_base_size(p), k0, k1, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq,
+                                  tuning().band_cus > 0 ? tuning().band_cus : device_info().cus, device_info().lds_per_cu, tuning().rt_block,
+                                  stream, &name) == 0)
                 return check_launch(name);
         }
         // large ensembles with aligned columns: loader-wave kernel
@@ -2884,7 +2886,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         if (tn.band_inv != 0 && truncate && ttm_band::usable(p, k0, k1)) {
             const char* name = nullptr;
             if (ttm_band::inverse(p, fold + fold_base_size(p), k0, k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine, tmin, tmax, bkt, (int)nb,
-                                  di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
+                                  tn.band_cus > 0 ? tn.band_cus : di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
                 return check_launch(name);
         }
         const int ways = plan_ways_of(p);
