@@ -293,6 +293,9 @@ typedef struct ttm_program {
 } ttm_program;
 
 const char* ttm_last_error_string(void);
+/* sets the calling thread's error text: entry points that run tasks on worker threads of their own (the *_batch
+ * optimisers) republish a worker's failure on the thread that made the call */
+int ttm_set_error_string(const char* text);
 int  ttm_version(void);
 /* name of the (last) kernel the most recent launching entry point of this thread dispatched, e.g. "k_inverse_hl":
  * lets a benchmark name the kernel its timings belong to (which variant runs is decided inside the library) */
@@ -581,7 +584,10 @@ int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const do
  * coefficient exchange) are spread over the GPUs of a node.  One communicator per process (= per GPU):
  *   ttm_comm_unique_id : rank 0 draws the 128-byte rendezvous id; the host distributes it to the other ranks
  *                        (any side channel: the Python class uses torch.distributed's store / broadcast);
- *   ttm_comm_create    : every rank, on its current HIP device; collective;
+ *   ttm_comm_create    : every rank, on its current HIP device; collective.  Returns within TTM_COMM_TIMEOUT_S
+ *                        seconds (environment, default 120) whatever the other ranks do: a rank missing from the
+ *                        rendezvous is an error (TTM_E_HIP), not a hang;
+ *   ttm_comm_size      : rank and number of ranks of a communicator (what a benchmark reports as its RCCL width);
  *   ttm_allreduce_f64 / _i32 : in place on a device buffer, op TTM_OP_SUM / TTM_OP_MAX, enqueued on `stream`
  *                        (no host synchronisation; results are valid in stream order);
  *   ttm_comm_destroy.
@@ -593,6 +599,7 @@ const char* ttm_comm_last_error(void);
 int ttm_comm_unique_id(void* id128);
 int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** out);
 int ttm_comm_destroy(ttm_comm* comm);
+int ttm_comm_size(const ttm_comm* comm, int32_t* rank, int32_t* nranks);
 int ttm_allreduce_f64(ttm_comm* comm, double* buf, int64_t count, int32_t op, void* stream);
 int ttm_allreduce_i32(ttm_comm* comm, int32_t* buf, int64_t count, int32_t op, void* stream);
 

@@ -182,6 +182,7 @@ bool forward_h_dispatch(const ttm_program* p, const double* fold, const XA& xa, 
 extern "C" {
 
 const char* ttm_last_error_string(void) { return "hostemu"; }
+int ttm_set_error_string(const char*) { return TTM_OK; }
 int ttm_version(void) { return TTM_VERSION; }
 const char* ttm_last_kernel(void) { return "hostemu"; }
 // options of the test double: the three it knows live in its environment variables (read per call)
@@ -210,6 +211,12 @@ int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** 
     return TTM_OK;
 }
 int ttm_comm_destroy(ttm_comm* c) { delete[] (int32_t*)c; return TTM_OK; }
+int ttm_comm_size(const ttm_comm* c, int32_t* rank, int32_t* nranks) {
+    if (!c) return TTM_E_ARG;
+    if (rank) *rank = ((const int32_t*)c)[0];
+    if (nranks) *nranks = ((const int32_t*)c)[1];
+    return TTM_OK;
+}
 int ttm_allreduce_f64(ttm_comm* c, double* buf, int64_t count, int32_t op, void*) {
     if (!c || !buf || count < 1) return TTM_E_ARG;
     if (!g_allreduce_cb) return TTM_E_UNSUPPORTED;

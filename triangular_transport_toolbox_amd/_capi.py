@@ -47,6 +47,7 @@ RECT = {'exponential': 0, 'softplus': 1, 'squared': 2, 'expneg': 3, 'explinearun
 
 _SIGNATURES = {
     'ttm_last_error_string': (ctypes.c_char_p, []),
+    'ttm_set_error_string': (ctypes.c_int, [ctypes.c_char_p]),
     'ttm_version': (ctypes.c_int, []),
     'ttm_last_kernel': (ctypes.c_char_p, []),
     'ttm_set_option': (ctypes.c_int, [ctypes.c_char_p, c_i32]),
@@ -99,6 +100,7 @@ _SIGNATURES = {
     'ttm_comm_unique_id': (ctypes.c_int, [c_vp]),
     'ttm_comm_create': (ctypes.c_int, [c_vp, c_i32, c_i32, ctypes.POINTER(c_vp)]),
     'ttm_comm_destroy': (ctypes.c_int, [c_vp]),
+    'ttm_comm_size': (ctypes.c_int, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     'ttm_allreduce_f64': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
     'ttm_allreduce_i32': (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp]),
 }

@@ -14,7 +14,13 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 
@@ -34,35 +40,57 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     char why[256] = "";
 };
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
+// which shared object holds `sym` (nullptr: unknown)
+const char* object_of(void* sym) {
+    Dl_info info;
+    return (sym && dladdr(sym, &info) && info.dli_fname) ? info.dli_fname : nullptr;
+}
+
+void load_rccl(Rccl& r) {
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names)                       // already in the process (PyTorch's copy)?
         if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-    const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : paths)
-        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     if (!r.handle) {
-        snprintf(r.why, sizeof(r.why), "RCCL not found (%s)", dlerror());
-        return &r;
+        // Not resident.  Loading one now is only safe when it binds to the HIP runtime this library itself runs on: a
+        // librccl that brings a second libamdhip64 into the process cannot use the caller's streams.  So: load, then
+        // compare the runtime RCCL resolved hipStreamSynchronize to with ours, and refuse a mismatch.
+        const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : paths)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) {
+            snprintf(r.why, sizeof(r.why), "RCCL not found (%s)", dlerror());
+            return;
+        }
+        const char* ours = object_of((void*)&hipStreamSynchronize);
+        const char* theirs = object_of(dlsym(r.handle, "hipStreamSynchronize"));      // (resolved through RCCL's own dependencies)
+        if (ours && theirs && strcmp(ours, theirs) != 0) {
+            snprintf(r.why, sizeof(r.why), "librccl binds another HIP runtime (%s) than this process runs on (%s)", theirs, ours);
+            r.handle = nullptr;                       // (left loaded: unloading a HIP runtime is not safe either)
+            return;
+        }
     }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.handle, "ncclCommAbort");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
         snprintf(r.why, sizeof(r.why), "RCCL library lacks the NCCL 2 entry points");
         r.handle = nullptr;
     }
+}
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { load_rccl(r); });
     return &r;
 }
 
@@ -103,10 +131,53 @@ int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** 
     if (!r->handle) return fail(TTM_E_UNSUPPORTED, "ttm_comm_create");
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    ncclComm_t c = nullptr;
-    ncclResult_t rc = r->CommInitRank(&c, nranks, id, rank);          // on the calling thread's current HIP device
+    // ncclCommInitRank blocks until every rank has called it: one rank that failed earlier (or died) would leave the
+    // others there for good.  It runs on a helper thread (same HIP device) and is given TTM_COMM_TIMEOUT_S seconds
+    // (default 120); past that the call is reported as failed - the ranks then agree on "no communicator" (comm.py) -
+    // and the helper is left to finish or not on its own (a blocked ncclCommInitRank cannot be cancelled from outside).
+    struct Pending { std::atomic<int> done{0}; ncclComm_t comm = nullptr; ncclResult_t rc = 0; };
+    Pending* pend = new Pending;                       // (shared with the helper: freed by whoever finishes last)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { delete pend; return fail(TTM_E_HIP, "ttm_comm_create: hipGetDevice"); }
+    std::atomic<int>* owners = new std::atomic<int>(2);
+    auto release = [](Pending* p, std::atomic<int>* o) { if (o->fetch_sub(1) == 1) { delete p; delete o; } };
+    try {
+        std::thread([=] {
+            (void)hipSetDevice(dev);
+            ncclComm_t c2 = nullptr;
+            pend->rc = r->CommInitRank(&c2, nranks, id, rank);
+            pend->comm = c2;
+            pend->done.store(1, std::memory_order_release);
+            if (owners->load() == 1 && c2 && !pend->rc && r->CommDestroy) r->CommDestroy(c2);     // (nobody waits any more)
+            release(pend, owners);
+        }).detach();
+    } catch (...) {
+        delete pend; delete owners;
+        return fail(TTM_E_HIP, "ttm_comm_create: no thread for ncclCommInitRank");
+    }
+    double limit = 120.0;
+    if (const char* e = getenv("TTM_COMM_TIMEOUT_S")) limit = atof(e) > 0.0 ? atof(e) : limit;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!pend->done.load(std::memory_order_acquire)) {
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            release(pend, owners);
+            snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank did not return within %.0f s (a rank missing from the rendezvous?)", limit);
+            return TTM_E_HIP;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    const ncclResult_t rc = pend->rc;
+    ncclComm_t c = pend->comm;
+    release(pend, owners);
     if (rc) return fail(TTM_E_HIP, "ncclCommInitRank", rc);
     *out = new ttm_comm{c, rank, nranks};
+    return TTM_OK;
+}
+
+int ttm_comm_size(const ttm_comm* c, int32_t* rank, int32_t* nranks) {
+    if (!c) return fail(TTM_E_ARG, "ttm_comm_size: null communicator");
+    if (rank) *rank = c->rank;
+    if (nranks) *nranks = c->nranks;
     return TTM_OK;
 }
 

@@ -1921,9 +1921,15 @@ __device__ __forceinline__ void publish(const double* fin, int n, double* out, d
         // the mark - written through - is already visible: the host then reads the results of the evaluation before)
         for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(out + i, fin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (flag) {
+            // the mark behind the results: the ONE wave that wrote them drains its stores (gfx9 s_waitcnt encoding:
+            // vmcnt(0), the other counters untouched - this library is built for gfx950 only) and releases the mark at
+            // system scope; the host acquires it (csrc/ttm_optim.cpp: poll_mark)
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "publish(): the raw s_waitcnt immediate below is the gfx9 encoding"
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (compiler ordering)
             __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
-            if (threadIdx.x == 0) *(volatile double*)flag = mark;
+            if (threadIdx.x == 0) __hip_atomic_store(flag, mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -2473,9 +2479,10 @@ static int pick_block(int nslots, int extra_doubles, int ns = 1) {
 static int select_passes(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, SelState* st, unsigned int* hist,
                          ttm_comm* comm, hipStream_t s) {
     hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
-    const int nb = grid_for(N, 256 * 8);
+    const int nb = N > 0 ? grid_for(N, 256 * 8) : 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
+        // (a rank whose shard is empty has nothing to count but still joins the all-reduce of the pass)
+        if (nb > 0) hipLaunchKernelGGL(k_select_hist, dim3(nb), dim3(256), 0, s, col, N, (int)nr, shift, (const SelState*)st, hist);
         if (comm) {
             const int rc = ttm_allreduce_i32(comm, (int32_t*)hist, (int64_t)nr * 256, TTM_OP_SUM, (void*)s);
             if (rc) return rc;
@@ -2492,6 +2499,11 @@ static int select_passes(const double* col, int64_t N, const int64_t* ranks, int
 extern "C" {
 
 const char* ttm_last_error_string(void) { return g_err; }
+
+int ttm_set_error_string(const char* text) {
+    snprintf(g_err, sizeof(g_err), "%s", text ? text : "");
+    return TTM_OK;
+}
 
 int ttm_version(void) { return TTM_VERSION; }
 
@@ -2575,7 +2587,9 @@ int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int
 // whole column without any of its elements having moved.  N: local elements (may be 0 < N on every rank).
 int ttm_order_statistics_dist(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void* work,
                               ttm_comm* comm, void* stream) {
-    if (!col || !ranks || !out || !work || N < 1 || nr < 1 || nr > TTM_SEL_MAX)
+    // N = 0 is a valid (empty) shard when there is a communicator.  The bin counts travel as int32 sums: the caller keeps
+    // the GLOBAL ensemble below 2^31 samples (transport_map._order_statistics checks it)
+    if ((!col && N > 0) || !ranks || !out || !work || N < 0 || (N < 1 && !comm) || N >= ((int64_t)1 << 31) || nr < 1 || nr > TTM_SEL_MAX)
         return set_err(TTM_E_ARG, "ttm_order_statistics_dist: bad arguments%s");
     SelState* st = (SelState*)work;
     unsigned int* hist = (unsigned int*)((char*)work + sizeof(SelState));

@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -26,26 +28,39 @@
 
 namespace {
 
+#ifndef TTM_HOST_ONLY
+// Poll *flag (pinned host memory, written by the device behind the results it announces) until it holds `mark`.
+// Every status of the stream other than "not ready" ends the wait: an idle stream without the mark means the launch
+// behind it failed, an error status (sticky launch failure, lost or reset device) that it never will arrive - results that
+// were not written are never read.  The loads of the results that follow are ordered behind the load that saw the mark.
+int poll_mark(const double* flag_, double mark, void* stream) {
+    const std::atomic<double>* flag = reinterpret_cast<const std::atomic<double>*>(flag_);
+    static_assert(sizeof(std::atomic<double>) == sizeof(double), "lock-free fp64 atomics expected");
+    for (long spins = 0; flag->load(std::memory_order_acquire) != mark; ++spins) {
+        if ((spins & 0xfffff) != 0xfffff) continue;
+        const hipError_t st = hipStreamQuery((hipStream_t)stream);
+        if (st == hipErrorNotReady) continue;
+        if (st == hipSuccess) (void)hipStreamSynchronize((hipStream_t)stream);   // (idle: anything queued has been executed)
+        if (flag->load(std::memory_order_acquire) != mark) return TTM_E_HIP;
+        break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return TTM_OK;
+}
+#endif
+
 // Completion of the work queued on `stream` so far: a mark written behind it into pinned host memory (*flag), polled
 // here - a hipStreamSynchronize per evaluation costs ~12 us of host / driver latency on top of the ~13 us of device work.
 int wait_for_mark(double* flag_, long& seq, void* stream) {
 #ifndef TTM_HOST_ONLY
     const double mark = (double)(++seq);
-    volatile double* flag = flag_;
-    const int rc = ttm_signal((double*)flag, mark, stream);
+    const int rc = ttm_signal(flag_, mark, stream);
     if (rc) return rc;
-    for (long spins = 0; *flag != mark; ++spins) {
-        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)stream) == hipSuccess && *flag != mark) {
-            // the stream is idle and the mark is not there: the launch behind it failed - never read results that were not written
-            (void)hipStreamSynchronize((hipStream_t)stream);
-            if (*flag != mark) return TTM_E_HIP;
-            break;
-        }
-    }
+    return poll_mark(flag_, mark, stream);
 #else
     (void)flag_; (void)seq; (void)stream;
-#endif
     return TTM_OK;
+#endif
 }
 
 // Independent component problems side by side (the reference's process pool over components, TM:2789-2845): worker
@@ -57,6 +72,15 @@ int run_batch(int ntasks, int nthreads, void* stream, Run run) {
     if (nthreads > ntasks) nthreads = ntasks;
     if (nthreads > 64) nthreads = 64;
     std::vector<int> rcs(ntasks, TTM_OK);
+    // the error text of a failing task lives in the worker thread's own buffer (thread-local): the first failure's text is
+    // copied here under a lock and republished on the calling thread before run_batch returns
+    std::mutex err_lock;
+    std::string err_text;
+    auto note_failure = [&](int rc) {
+        if (!rc) return;
+        std::lock_guard<std::mutex> g(err_lock);
+        if (err_text.empty()) err_text = ttm_last_error_string();
+    };
     if (nthreads == 1) {
         for (int t = 0; t < ntasks; ++t) rcs[t] = run(t, stream);
     } else {
@@ -88,7 +112,10 @@ int run_batch(int ntasks, int nthreads, void* stream, Run run) {
             void* st = stream;
             (void)w;
 #endif
-            for (int t; (t = next.fetch_add(1)) < ntasks;) rcs[t] = on_device ? run(t, st) : (int)TTM_E_HIP;
+            for (int t; (t = next.fetch_add(1)) < ntasks;) {
+                rcs[t] = on_device ? run(t, st) : (int)TTM_E_HIP;
+                note_failure(rcs[t]);
+            }
         };
         std::vector<std::thread> threads;
         for (int w = 1; w < nthreads; ++w) {
@@ -102,7 +129,10 @@ int run_batch(int ntasks, int nthreads, void* stream, Run run) {
         for (auto& th : threads) th.join();
     }
     for (int t = 0; t < ntasks; ++t)
-        if (rcs[t]) return rcs[t];
+        if (rcs[t]) {
+            if (!err_text.empty()) ttm_set_error_string(err_text.c_str());
+            return rcs[t];
+        }
     return TTM_OK;
 }
 
@@ -113,19 +143,11 @@ int objective_and_wait(double* flag_, long& seq, void* stream, Launch launch) {
     const int rc = launch(flag_, mark);
     if (rc) return rc;
 #ifndef TTM_HOST_ONLY
-    volatile double* flag = flag_;
-    for (long spins = 0; *flag != mark; ++spins) {
-        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery((hipStream_t)stream) == hipSuccess && *flag != mark) {
-            // the stream is idle and the mark is not there: the launch behind it failed - never read results that were not written
-            (void)hipStreamSynchronize((hipStream_t)stream);
-            if (*flag != mark) return TTM_E_HIP;
-            break;
-        }
-    }
+    return poll_mark(flag_, mark, stream);
 #else
     (void)stream;
-#endif
     return TTM_OK;
+#endif
 }
 
 }  // namespace

@@ -429,6 +429,9 @@ class transport_map():
             t = torch.tensor([n_total], dtype=torch.int64, device=self._dev)
             dist.all_reduce(t)
             n_total = int(t.item())
+            if n_total >= 2 ** 31:
+                # (the distributed select sums its 256 bin counts per pass as int32)
+                raise ValueError('order statistics of a sharded column: the global ensemble must stay below 2^31 samples')
             handle = comm.get(self._lib, force=self._dev.type != 'cuda')
             if handle is None:
                 sizes = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=self._dev)
