@@ -329,6 +329,97 @@ def spawn_ranks(args):
         raise SystemExit('bench.py: rank exit codes %s' % rcs)
 
 
+def multi_gpu_extras(torch, dist, args, rank, world, backend):
+    """What north_star asks of the node beside the weak-scaling headline, every rank taking part:
+    (a) STRONG scaling of the fixed ensemble of the workload (C5: N = 1e6) split over the ranks - no collective on the
+        data path, `value` = N_total D steps / the slowest rank's time;
+    (b) BASELINE configs[3]: the Lorenz-63 EnTF (N = 1e5) with the ensemble SAMPLE-SHARDED over the ranks - column moments,
+        order statistics and, per L-BFGS-B evaluation, ONE fused objective + gradient all-reduce (ttm_allreduce_f64 over
+        RCCL inside ttm_optimize_separable; torch.distributed under `--backend gloo`) - ms per cycle and the latency of
+        that all-reduce alone;
+    (c) the width of the RCCL communicator the class created (`rccl_ranks`; None when the process group is not RCCL).
+    Never fatal for the headline line."""
+    import ctypes
+    from triangular_transport_toolbox_amd import comm, entf
+    out = {}
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def tmax(x):
+        t = torch.tensor([x], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    try:
+        n_total = args.n or WORKLOADS[args.workload][1]
+        n_loc = n_total // world + (1 if rank < n_total % world else 0)
+        tm, _, _ = build_map(args.workload, rank, n_loc)
+        N, D, d = tm._N, tm.D, tm._cm.d_cols
+        coef = tm._pack_coeffs()
+        Xs, Z, Xinv = tm._Xs, tm._cols(D, N), tm._cols(d, N, zero=True)
+
+        def step():
+            tm.forward_device(Xs, N, coef=coef, Z=Z)
+            tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < min(1.0, args.prewarm_seconds):
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+        sync()
+        for _ in range(150 + args.warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        el = tmax(time.perf_counter() - t0)
+        out['strong_scaling'] = {'workload': args.workload, 'N_total': n_total, 'N_per_gpu': n_loc, 'steps': args.steps,
+                                 'ms_per_step': 1e3 * el / args.steps, 'value': n_total * D * args.steps / el,
+                                 'what': 'the fixed ensemble split over the ranks; no data-path collective'}
+        del tm, Xs, Z, Xinv
+    except Exception as exc:                           # noqa: BLE001
+        out['strong_scaling_error'] = repr(exc)
+    try:
+        n_total = 100000
+        base, rem = divmod(n_total, world)
+        n_loc = base + (1 if rank < rem else 0)
+        row0 = rank * base + min(rank, rem)
+        rng = np.random.default_rng(0)
+        ens = (rng.standard_normal((n_total, 3)) * [8, 9, 8] + [0, 0, 25])[row0:row0 + n_loc]
+        flt = entf.Filter(n_loc, seed=0, row0=row0, shard_samples=True)
+        cycles = 50
+        r = flt.benchmark(ens, np.array([1.0, 1.0, 25.0]), cycles)
+        tmf = flt.tm
+        handle = comm.get(tmf._lib, force=False)
+        nr = None
+        if handle is not None:
+            a, b = ctypes.c_int32(-1), ctypes.c_int32(-1)
+            tmf._lib.ttm_comm_size(handle, ctypes.byref(a), ctypes.byref(b))
+            nr = int(b.value)
+        out['rccl_ranks'] = nr
+        # the all-reduce of an optimiser evaluation by itself: 1 + m = 10 doubles, stream order, synchronised once at the end
+        buf = torch.ones(10, dtype=torch.float64, device='cuda')
+        for _ in range(50):
+            tmf._allreduce_world(buf)
+            buf.fill_(1.0)
+        sync()
+        n_ar = 500
+        t0 = time.perf_counter()
+        for _ in range(n_ar):
+            tmf._allreduce_world(buf)
+        sync()
+        r['allreduce_us'] = 1e6 * tmax(time.perf_counter() - t0) / n_ar
+        r['allreduce'] = ('ttm_allreduce_f64 over RCCL (%d ranks)' % nr) if nr else 'torch.distributed (%s): no RCCL communicator' % backend
+        r['evaluations_last_update'] = getattr(tmf, 'last_optimize_evaluations', None)
+        out['entf_sample_sharded'] = r
+    except Exception as exc:                           # noqa: BLE001
+        out['entf_sample_sharded_error'] = repr(exc)
+    return out
+
+
 def flops_per_eval(tm):
     """fp64 operations per component evaluation of the two U-form map kernels, counted from the arithmetic they
     execute (FMA = 2): forward = spline of the summed special terms (degree TTM_U_DEG = 11 Horner + 4 of index
@@ -531,6 +622,8 @@ def main():
             extra['other_configs']['C4'] = entf_config(torch)
         except Exception as exc:                       # noqa: BLE001
             extra['other_configs_C4_error'] = repr(exc)
+    if world > 1:
+        extra.update(multi_gpu_extras(torch, dist, args, rank, world, args.backend))
     if world > 1 and not args.no_optimize:
         # optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
         # holds the same ensemble (seed of rank 0), optimises a strided subset of the components, coefficients are

@@ -102,8 +102,13 @@ class Filter:
     pushforward of the resident samples (ttm_forward) -> conditional inverse with the observed value in the first
     column (ttm_inverse_table) -> back to physical units and ensemble order (ttm_map_columns)."""
 
-    def __init__(self, N, maxorder=3, lmbda=0.05, seed=0, obs_sd=2.0, **kwargs):
+    def __init__(self, N, maxorder=3, lmbda=0.05, seed=0, obs_sd=2.0, row0=0, **kwargs):
+        # A sample-sharded filter (one rank per GPU, `shard_samples=True` in kwargs) holds N rows of the ensemble starting
+        # at global row `row0`: the observation noise is a function of (seed, draw, GLOBAL row), so the sharded filter
+        # draws what the single-rank filter draws; everything else that couples the shards is the class's reductions
+        # (column moments, order statistics, objective / gradient sums - example_06.py:252-328 has no counterpart).
         self.N = int(N)
+        self.row0 = int(row0)
         self.tm = make_filter_map(self.N, maxorder, lmbda, **kwargs)
         self.seed = int(seed)
         self.obs_sd = float(obs_sd)
@@ -141,7 +146,7 @@ class Filter:
                 _check(tm._lib.ttm_perturb(col, tm._ptr(noises, idx * noises.shape[1]), 1.0, 0, 0, 0, N, tm._ptr(inp), tm._stream()))
             else:
                 self._draws += 1
-                _check(tm._lib.ttm_perturb(col, None, self.obs_sd, self.seed, self._draws, 0, N, tm._ptr(inp), tm._stream()))
+                _check(tm._lib.ttm_perturb(col, None, self.obs_sd, self.seed, self._draws, self.row0, N, tm._ptr(inp), tm._stream()))
             tm.reset_device(inp, N)
             tm.optimize()
             Z = tm.forward_device(tm._Xs, N)
@@ -170,14 +175,30 @@ class Filter:
             self.forecast(0.05, 2)
             self.assimilate(obs)
             return truth
+        dist = self.tm._dist()
+
+        def sync():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
         for _ in range(warmup):
             truth = cycle(truth)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(cycles):
             truth = cycle(truth)
-        torch.cuda.synchronize()
+        sync()
         el = time.perf_counter() - t0
+        if dist is not None:                                      # (sharded: the ensemble mean over all ranks, the slowest rank's clock)
+            acc = torch.cat((self.ens[:, :self.N].sum(dim=1), torch.tensor([float(self.N), el], dtype=torch.float64, device=self.ens.device)))
+            tmax = torch.tensor([el], dtype=torch.float64, device=self.ens.device)
+            dist.all_reduce(acc)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            mean = (acc[:3] / acc[3]).cpu().numpy()
+            el = float(tmax.item())
+            return dict(workload='C4: Lorenz-63 EnTF, Example-06 map, ensemble SAMPLE-SHARDED over the ranks (device resident)',
+                        N_total=int(acc[3].item()), N_per_rank=self.N, cycles=cycles, ms_per_cycle=1e3 * el / cycles, updates_per_cycle=3,
+                        rmse_last=float(np.sqrt(np.mean((mean - truth) ** 2))))
         mean = self.ens[:, :self.N].mean(dim=1).cpu().numpy()
         return dict(workload='C4: Lorenz-63 EnTF, Example-06 map (4 columns, D = 3, order 3, L2 0.05), ensemble resident on the device',
                     N=self.N, cycles=cycles, ms_per_cycle=1e3 * el / cycles, updates_per_cycle=3,

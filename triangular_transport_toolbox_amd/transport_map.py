@@ -1570,8 +1570,10 @@ class transport_map():
             raise ValueError('shard_components needs the full ensemble on every rank (shard_samples=False)')
         # components are independent problems (TM:2746-2786): with shard_components every rank optimises a
         # strided subset (most expensive, i.e. last, components first as TM:2814-2822) on its replica of X
-        K_local = list(reversed(K))[tdist.get_rank()::tdist.get_world_size()] if part else K
+        owner = self._partition_components(K, tdist.get_world_size()) if part else None
+        K_local = [k for k in reversed(K) if owner[k] == tdist.get_rank()] if part else K
         J_local = 0.0
+        n_eval = 0
         if self.monotonicity == "separable monotonicity":
             batched = self._optimize_separable_batch(K_local)
         elif self.monotonicity == "integrated rectifier":
@@ -1615,6 +1617,7 @@ class transport_map():
                 self.coeffs_mon[k] = copy.deepcopy(opt.x)
                 self.coeffs_nonmon[k] = solve_nonmon(opt.x)
             J_local += float(opt.fun)
+            n_eval += int(getattr(opt, 'nfev', 0) or 0)
             if self.verbose:
                 string = '\r' + 'Progress: |' + (k + 1) * '█' + (len(K) - k - 1) * ' ' + '|'
                 print(string, end='\r')
@@ -1622,8 +1625,6 @@ class transport_map():
             # exchange: coefficients of every component from its owner (a few KB) and ONE scalar all-reduce
             # of the summed objective - the only collective of the partitioned optimisation
             torch = _torch()
-            world, rank = tdist.get_world_size(), tdist.get_rank()
-            owner = {k: i % world for i, k in enumerate(reversed(K))}
             n_tot = int(self._cm.coef_off[-1])
             buf = torch.zeros(n_tot, dtype=torch.float64, device=self._dev)
             for k in K_local:
@@ -1641,4 +1642,28 @@ class transport_map():
             self.objective_total = float(jt.item())
         else:
             self.objective_total = J_local
+        self.last_optimize_evaluations = n_eval          # objective evaluations of this rank's components (benchmarks)
         return
+
+    def _partition_components(self, K, world):
+        """Owner rank of every component of K when the components are partitioned (TM:2789-2845: the reference's pool takes
+        them in reverse order, most expensive first).  Cost of a component = coefficients x columns it reads (the work of
+        one evaluation of its reduced problem); longest-processing-time assignment: most expensive first, each to the
+        rank with the least work so far - the same on every rank."""
+        cm = self._cm
+
+        def cost(k):
+            cols = {k + self.skip_dimensions}
+            for entry in list(self.monotone[k]) + list(self.nonmonotone[k]):
+                if isinstance(entry, str):
+                    cols.add(int(entry.split(' ')[1]))
+                else:
+                    cols.update(int(e) for e in entry if not isinstance(e, str))
+            return (int(cm.n_nm[k]) + int(cm.n_mon[k])) * len(cols)
+        load = [0] * world
+        owner = {}
+        for k in sorted(K, key=lambda kk: (-cost(kk), -kk)):
+            r = min(range(world), key=lambda i: (load[i], i))
+            owner[k] = r
+            load[r] += cost(k)
+        return owner
