@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+COPY_PEAK_GBS = 6290.0       # measured float4 copy of the same guide (79 % of the spec)
 FP64_PEAK_TFLOPS = 78.6      # vector fp64: half the 157.3 TFLOP/s fp32 vector peak of the same guide (16 lanes/clk/SIMD)
 
 WORKLOADS = {
@@ -420,19 +421,45 @@ def multi_gpu_extras(torch, dist, args, rank, world, backend):
     return out
 
 
+def component_sharded_optimize(torch, dist, args):
+    """optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
+    holds the same ensemble (seed of rank 0), optimises its share of the components, coefficients are exchanged once and
+    the summed objective is the one RCCL all-reduce."""
+    out = {}
+    try:
+        tm2, _, _ = build_map(args.workload, 0, args.n or None, shard_components=True)
+        for k in range(tm2.D):
+            tm2.coeffs_mon[k] = tm2.coeffs_mon[k] * 0 + tm2.coeffs_init
+            tm2.coeffs_nonmon[k] = tm2.coeffs_nonmon[k] * 0 + tm2.coeffs_init
+        dist.barrier(); torch.cuda.synchronize()
+        t0o = time.perf_counter()
+        tm2.optimize()
+        dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0o], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out['optimize_component_sharded_s'] = float(t.item())
+        out['optimize_objective_total'] = float(tm2.objective_total)
+    except Exception as exc:                           # noqa: BLE001
+        out['optimize_component_sharded_error'] = repr(exc)
+    return out
+
+
 def flops_per_eval(tm):
-    """fp64 operations per component evaluation of the two U-form map kernels, counted from the arithmetic they
-    execute (FMA = 2): forward = spline of the summed special terms (degree TTM_U_DEG = 11 Horner + 4 of index
-    arithmetic) + exp(-x_k^2/4) of the column cache (degree-12 series + reduction, 2 x 15) + per nonmonotone group the
-    two Horner passes of its degree class and the combination; inverse (k_inverse_rt) = the groups + clip and bucket
-    (6) + two compares + interpolation (Newton reciprocal 5, slope / delta / abscissa 6) + the interval exponential
-    (degree-7 Taylor + argument + table factor: 2 x 7 + 4).  Returns (forward, inverse) averaged over the components, or
-    None for maps without a U-form."""
+    """fp64 operations per component evaluation of the two large-ensemble map kernels, counted from the arithmetic they
+    execute (FMA = 2).  Banded maps (csrc/ttm_band.hip): forward = spline (degree-11 Horner 22 + column / local
+    coordinate 4) + exp(-x^2/4) from the pair table (argument 7, degree-7 Taylor 14, factor 1) + per group the two Horner
+    passes of its degree class and the accumulation (2 DB + 2 DA + 2) + 1; inverse = the same pushes + target and clip 3 +
+    bucket 2 + two compares 2 + interpolation (difference, floor, reciprocal with one Newton step, slope, abscissa) 11 +
+    the interval exponential (argument 3, Taylor 14, factor 1).  Other U-form maps with hot records: k_forward_hl /
+    k_inverse_rt as counted in round 2.  Returns (forward, inverse) averaged over the components, or None."""
     cm = tm._cm
     if not getattr(cm, 'u_enabled', False) or not getattr(cm, 'u_h_cls', 0):
         return None
     db, da = {1: (3, 1), 2: (5, 5), 3: (7, 7)}[int(cm.u_h_cls)]
     ngrp = float(np.mean(np.asarray(cm.ucomp).reshape(-1)[:cm.D * 8].reshape(cm.D, 8)[:, 2]))
+    if getattr(cm, 'u_p_lag', 0):
+        grp = ngrp * (2 * db + 2 * da + 2)
+        return grp + 26 + 22 + 1, grp + 3 + 2 + 2 + 11 + 18
     grp = ngrp * (2 * db + 2 * da + 3)
     fwd = grp + (2 * 11 + 4) + 30
     inv = grp + 6 + 2 + (5 + 6) + (14 + 4)
@@ -457,6 +484,8 @@ def main():
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the secondary numbers of the other single-GPU BASELINE configurations (C2b, C2a, C3, C4)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target duration of each CPU baseline leg')
+    ap.add_argument('--extras-timeout', type=float, default=240.0,
+                    help='N > 1: seconds the node-level extras may take before the headline line is printed without them')
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -577,6 +606,23 @@ def main():
         t = torch.tensor([elapsed, cold, uncached], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, cold, uncached = [float(v) for v in t.tolist()]
+    # what a plain elementwise pass achieves on the same buffers in the same alternating pattern (X -> Z, Z -> Xinv: the
+    # bytes of a step with no arithmetic), directly behind the timed steps: the card's own streaming floor for this step
+    floor_ms = None
+    if separable:
+        def floor_step():
+            torch.abs(Xs[:D], out=Z)
+            torch.abs(Z, out=Xinv[:D])
+        for _ in range(20):
+            floor_step()
+        evf = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 50))]
+        for a, b in evf:
+            a.record(); floor_step(); b.record()
+        torch.cuda.synchronize()
+        floor_ms = float(np.mean([a.elapsed_time(b) for a, b in evf]))
+        for _ in range(20):                              # (the buffers hold the map's own results again for the checks below)
+            step()
+        torch.cuda.synchronize()
     # round trip sanity inside the bench: S^{-1}(S(x)) == x up to the inverse's own accuracy
     err = float((Xinv[:, :N] - Xs[:, :N]).abs().max().item())
     extra = {}
@@ -622,30 +668,8 @@ def main():
             extra['other_configs']['C4'] = entf_config(torch)
         except Exception as exc:                       # noqa: BLE001
             extra['other_configs_C4_error'] = repr(exc)
-    if world > 1:
-        extra.update(multi_gpu_extras(torch, dist, args, rank, world, args.backend))
-    if world > 1 and not args.no_optimize:
-        # optimize() with the COMPONENTS partitioned over the ranks (SURVEY section 8e / BASELINE config 5): every rank
-        # holds the same ensemble (seed of rank 0), optimises a strided subset of the components, coefficients are
-        # exchanged once and the summed objective is the one RCCL all-reduce.  Never fatal for the scaling run.
-        try:
-            del tm, Xs, Z, Xinv
-            tm2, _, _ = build_map(args.workload, 0, args.n or None, shard_components=True)
-            for k in range(tm2.D):
-                tm2.coeffs_mon[k] = tm2.coeffs_mon[k] * 0 + tm2.coeffs_init
-                tm2.coeffs_nonmon[k] = tm2.coeffs_nonmon[k] * 0 + tm2.coeffs_init
-            sync()
-            t0o = time.perf_counter()
-            tm2.optimize()
-            sync()
-            t = torch.tensor([time.perf_counter() - t0o], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            extra['optimize_component_sharded_s'] = float(t.item())
-            extra['optimize_objective_total'] = float(tm2.objective_total)
-            tm = tm2
-        except Exception as exc:                       # noqa: BLE001
-            extra['optimize_component_sharded_error'] = repr(exc)
-
+    fl_pre = flops_per_eval(tm) if separable else None
+    out = None
     if rank == 0:
         fwd_bytes = 8.0 * N * (du + D)
         inv_bytes = 8.0 * N * (2 * D)
@@ -680,6 +704,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic.get("%s_hbm_bytes_per_launch" % dom_kernel.split("<")[0]),
+                         'traffic_other_kernel': traffic.get("%s_hbm_bytes_per_launch" % (fwd_kernel if dominant == 'inverse' else inv_kernel).split("<")[0]),
                          'kernel': dom_kernel, 'which': dominant,
                          'algorithmic_bytes_per_launch': dom_bytes, 'avg_launch_ms': dom_ms,
                          'forward_frac': gbps(fwd_bytes, fwd_ms) / HBM_PEAK_GBS, 'forward_kernel': fwd_kernel,
@@ -687,7 +712,14 @@ def main():
                          # forward + inverse as one unit of work against the same roof: by kernel time and by the
                          # wall-clock step (launch gaps included)
                          'pair_frac': gbps(fwd_bytes + inv_bytes, fwd_ms + inv_ms) / HBM_PEAK_GBS,
-                         'pair_frac_wallclock': gbps(fwd_bytes + inv_bytes, ms_step) / HBM_PEAK_GBS},
+                         'pair_frac_wallclock': gbps(fwd_bytes + inv_bytes, ms_step) / HBM_PEAK_GBS,
+                         # the same against what a copy achieves: the guide's measured float4 copy (6.29 TB/s) and an
+                         # elementwise pass over this step's own buffers, measured in this run (bench.py: floor_step)
+                         'copy_peak': {'guide_GBps': COPY_PEAK_GBS, 'frac': achieved / COPY_PEAK_GBS,
+                                       'pair_frac_wallclock': gbps(fwd_bytes + inv_bytes, ms_step) / COPY_PEAK_GBS,
+                                       'measured_elementwise_pair_ms': floor_ms,
+                                       'measured_GBps': (gbps(fwd_bytes + inv_bytes, floor_ms) if floor_ms else None),
+                                       'pair_frac_of_measured': (floor_ms / ms_step if floor_ms else None)}},
             'forward_ms': fwd_ms, 'inverse_ms': inv_ms,
             'forward_GBps_algorithmic': gbps(fwd_bytes, fwd_ms),
             'inverse_GBps_algorithmic': gbps(inv_bytes, inv_ms),
@@ -707,7 +739,7 @@ def main():
                                'sustained load (after an idle gap >= 1 ms the next ~50 launches run 10-30 % slower); '
                                'cold_ms_per_step is the same measurement without it'},
         }
-        fl = flops_per_eval(tm) if separable else None
+        fl = fl_pre
         if fl is not None:
             tf = lambda f, ms: f * N * D / (ms * 1e-3) / 1e12          # noqa: E731
             out['fp64'] = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -719,6 +751,35 @@ def main():
         out.update(extra)
         if cpu is not None:
             out['cpu_baseline'] = cpu
+    if world > 1:
+        # The node-level extras (strong scaling, the sample-sharded filter, the component-partitioned optimize()) are the
+        # first code of this repository that runs RCCL collectives of its own over more than one rank: they run behind the
+        # headline, under a watchdog - if they have not returned within --extras-timeout seconds rank 0 prints the line
+        # it has (with `multi_gpu_extras_error`) and every rank leaves, instead of a hung collective taking the headline
+        # with it.  (A thread can do that: the blocked calls have released the GIL.)
+        import threading
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out['multi_gpu_extras_error'] = 'not finished within %g s' % args.extras_timeout
+                print(json.dumps(out))
+                sys.stdout.flush()
+            else:
+                time.sleep(2.0)
+            os._exit(0)
+        dog = threading.Timer(args.extras_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            extra2 = multi_gpu_extras(torch, dist, args, rank, world, args.backend)
+            if not args.no_optimize:
+                extra2.update(component_sharded_optimize(torch, dist, args))
+        except Exception as exc:                       # noqa: BLE001
+            extra2 = {'multi_gpu_extras_error': repr(exc)}
+        dog.cancel()
+        if out is not None:
+            out.update(extra2)
+    if out is not None:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
