@@ -46,6 +46,9 @@ WORKLOADS = {
     'C3': ('C3', 500000, 'c3_sep', 'd=4 dense separable map, order 4, N=5e5 (banana target)'),
     'C2b': ('C2b', 1000000, 'c2b_sep', 'spiral d=2 separable map, order 5, N=1e6'),
     'C2a': ('C2a', 1000000, 'c2a_int', 'spiral d=2 integrated-rectifier map, order 5, Q=25, N=1e6'),
+    # the integrated-rectifier variants SURVEY.md section 8 names as canonical (FP64-bound: secondary numbers)
+    'C3int': ('C3int', 500000, 'c3_int', 'd=4 band-1 integrated-rectifier map, order 4, Q=25, N=5e5 (banana target)'),
+    'C5int': ('C5int', 200000, 'c5_int', 'd=40 band-2 integrated-rectifier map, order 3, Q=25, N=2e5 (Gaussian-mixture target)'),
 }
 
 
@@ -61,7 +64,7 @@ def build_map(workload, rank, n_override=None, **extra_kwargs):
     if n_override:
         N = n_override
     cfg = specs.config(cfgname)
-    seed = {'C5': 12345, 'C3': 0, 'C2b': 0, 'C2a': 0}[workload] + 1000 * rank
+    seed = {'C5': 12345, 'C5int': 12345}.get(workload, 0) + 1000 * rank
     X = cfg['sampler'](N, seed=seed)
     tm = transport_map(X=X, monotone=cfg['monotone'], nonmonotone=cfg['nonmonotone'], verbose=False, **cfg['kwargs'],
                        **extra_kwargs)
@@ -120,13 +123,13 @@ def cpu_baseline(workload, seconds):
     out = {'unit': 'map-evals/s', 'kind': 'port', 'host': core_info}
     # leg 2: NumPy, one core; sample sized from a short calibration run
     with mp.get_context('fork').Pool(1) as pool:
-        n0 = {'C5': 20000, 'C3': 50000, 'C2b': 100000, 'C2a': 500}[workload]
+        n0 = {'C5': 20000, 'C3': 50000, 'C2b': 100000, 'C2a': 500, 'C3int': 500, 'C5int': 100}[workload]
         ev, tf, ti = pool.map(_numpy_leg, [(workload, n0, 7000)])[0]
         n1 = int(max(n0, min(20 * n0, n0 * seconds / max(tf + ti, 1e-3))))
         ev, tf, ti = pool.map(_numpy_leg, [(workload, n1, 7013)])[0]
     out['numpy_1core'] = {'value': ev / (tf + ti), 'cores': 1, 'samples': n1, 'forward_s': tf, 'inverse_s': ti,
                           'what': 'oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), one process, one thread'}
-    if workload == 'C2a':
+    if workload in ('C2a', 'C3int', 'C5int'):
         out.update(value=out['numpy_1core']['value'], cores=1,
                    sample='NumPy oracle, %d samples of the workload, forward + bisection inverse, one core '
                           '(the OpenMP leg restates the separable path only)' % n1)
@@ -156,6 +159,29 @@ def cpu_baseline(workload, seconds):
                       '%d passes over a %d-sample ensemble of the workload: forward %.2f s, inverse %.2f s'
                       % (cores, reps, n0, t_f, t_i),
                forward_s=t_f, inverse_s=t_i, samples=reps * n0)
+    return out
+
+
+def counted_fp64(workload, N, forward_ms, inverse_ms, newton_ms=None):
+    """fp64 rate of the integrated-rectifier kernels from COUNTED operations (profiles/fp64_counts.json, written by
+    tools/fp64_counts.py from rocprofv3 PMC passes of this bench on the same workload); None without that file."""
+    path = os.path.join(ROOT, 'profiles', 'fp64_counts.json')
+    if not os.path.exists(path):
+        return None
+    c = json.load(open(path)).get(workload)
+    if not c:
+        return None
+    out = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'estimate': False, 'source': 'profiles/fp64_counts.json (rocprofv3 --pmc, counted)'}
+    scale = N / float(c['N'])
+    for key, kern, ms in (('forward', c.get('forward_kernel'), forward_ms), ('inverse', c.get('inverse_kernel'), inverse_ms),
+                          ('inverse_newton', c.get('newton_kernel'), newton_ms)):
+        k = c['kernels'].get(kern) if kern else None
+        if k is None or not ms:
+            continue
+        flop = k['flop_per_launch'] * scale
+        out[key] = {'kernel': kern, 'flop_per_launch': flop, 'TFLOPs': flop / (ms * 1e-3) / 1e12,
+                    'frac': flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    'valu_instructions_per_launch': k.get('valu_per_launch', 0) * scale}
     return out
 
 
@@ -218,19 +244,10 @@ def other_configs(torch, names, steps=40):
                 a.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); b.record()
             torch.cuda.synchronize()
             r['inverse_newton_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evn]))
-            # FP64-bound path: arithmetic rate next to the byte rate.  Operations per evaluation of
-            # S_k, estimated from the restructured integrand g(t) = sum_n w_n B_n(t): Q nodes x (P recurrence steps of 2
-            # flop + the rectifier's exp ~ 30 + 4 of accumulation) + the nonmonotone part (~ 40); the reference
-            # bisection needs ~ 31 midpoints + 2 bracket points per root (mean 30.5 on the spiral)
-            Q = int(tm._qx_d.numel())
-            P = 5
-            per_eval = Q * (2 * P + 30 + 4) + 40
-            r['fp64'] = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'estimate': True, 'flop_per_forward_eval': per_eval,
-                         'forward_TFLOPs': per_eval * N * D / (r['forward_ms'] * 1e-3) / 1e12,
-                         'bisection_evals_per_root': 33,
-                         'inverse_TFLOPs': 33 * per_eval * N * D / (r['inverse_ms'] * 1e-3) / 1e12}
-            r['fp64']['forward_frac'] = r['fp64']['forward_TFLOPs'] / FP64_PEAK_TFLOPS
-            r['fp64']['inverse_frac'] = r['fp64']['inverse_TFLOPs'] / FP64_PEAK_TFLOPS
+            # FP64-bound path: arithmetic rate next to the byte rate.  Executed fp64 operations per
+            # launch are COUNTED (SQ_INSTS_VALU_FMA/ADD/MUL/TRANS_F64 of tools/fp64_counts.sh, profiles/fp64_counts.json:
+            # 64 lanes x (2 FMA + ADD + MUL + TRANS) wave-instructions per launch at the profiled N, scaled to this N)
+            r['fp64'] = counted_fp64(name, N, r['forward_ms'], r['inverse_ms'], r.get('inverse_newton_ms'))
             r['roundtrip_median_abs_err_newton'] = float((Xinv[:, :N] - Xs[:, :N]).abs().median().item())
             tm.root_finder = 'reference'
         Nopt = N if separable else 100000            # (integrated-rectifier optimize(): BASELINE.md quotes N = 1e5)
@@ -661,7 +678,7 @@ def main():
         tm.coeffs_mon, tm.coeffs_nonmon = saved
     if world == 1 and not args.no_other_configs and args.workload == 'C5':
         try:
-            extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3'])
+            extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3', 'C3int', 'C5int'])
         except Exception as exc:                       # noqa: BLE001  (never fatal for the headline line)
             extra['other_configs_error'] = repr(exc)
         try:
