@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -181,10 +182,16 @@ namespace {
 
 // the reduced separable problem of one component (TM:2978-3018) minimised by the L-BFGS-B loop; launch(cc, out, flag,
 // mark, stream) enqueues the reduction of the sums for coefficients cc into out (flag != NULL: with the completion mark)
+//
+// ONE monotone term (m = 1: the filtering and smoothing maps of Examples C, most components of Markov-type maps): the sample
+// sums are known in closed form once they have been taken at one point.  dS_n = dPsi_n c + delta dPsi_n = dPsi_n (c + delta)
+// (TM:2990-2993), so sum_n log dS_n = N log(c + delta) + sum_n log dPsi_n and sum_n dPsi_n / dS_n = N / (c + delta): the
+// first evaluation of the loop goes to the device, every later one is two host operations - the same function to
+// rounding (1e-16 relative, like the order of a reduction), no launch, no round trip.  `delta` < 0 switches it off.
 template <class Launch>
 int optimize_separable_with(Launch launch, int32_t m, const double* A, const double* b, double Ntotal, const double* lb,
                             const double* ub, double* x, double* sums_dev, double* sums_host, ttm_comm* comm, void* stream,
-                            int32_t maxiter, double* result) {
+                            int32_t maxiter, double* result, double delta = -1.0) {
     struct Ctx {
         Launch& launch;
         const double *A, *b;
@@ -194,13 +201,19 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         void* stream;
         int rc;
         long seq;
-    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0};
+        double delta, Nw, KN;                                // closed form of m = 1: weights N, sum_n log dPsi_n
+        bool closed, have0;
+    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,
+        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false};
     sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n log dS_n, sums[1 + i] = sum_n dPsi_{n,i} / dS_n  (TM:2990-3006), over the local samples
         double* out = c.comm ? c.sums_dev : c.sums_host;
-        if (!c.comm) {                                       // results and completion mark from the reduction itself
+        if (c.closed && c.have0 && cc[0] + c.delta > 0.0) {
+            c.sums_host[0] = c.Nw * log(cc[0] + c.delta) + c.KN;
+            c.sums_host[1] = c.Nw / (cc[0] + c.delta);
+        } else if (!c.comm) {                                // results and completion mark from the reduction itself
             c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream,
                                       [&](double* flag, double mark) { return c.launch(cc, out, flag, mark, c.stream); });
             if (c.rc) return c.rc;
@@ -217,6 +230,11 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
 #endif
             c.rc = wait_for_mark(c.sums_host + 1 + n, c.seq, c.stream);
             if (c.rc) return c.rc;
+        }
+        if (c.closed && !c.have0 && cc[0] + c.delta > 0.0) {  // the point the closed form is anchored at
+            const double nw = c.sums_host[1] * (cc[0] + c.delta), kn = c.sums_host[0] - nw * log(cc[0] + c.delta);
+            if (nw > 0.0 && nw < 1.0e300 && kn == kn && kn > -1.0e300 && kn < 1.0e300) { c.Nw = nw; c.KN = kn; c.have0 = true; }
+            else c.closed = false;                           // (a vanishing or negative derivative somewhere: the sums stay on the device)
         }
         // J = c'Ac/2 - sum log dS / N + c.b,  grad = Ac - sums/N + b   (TM:3008-3018)
         double quad = 0.0, lin = 0.0;
@@ -246,7 +264,8 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
     auto launch = [&](const double* cc, double* out, double* flag, double mark, void* st) {
         return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
     };
-    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result);
+    static const bool closed = [] { const char* e = getenv("TTM_SEP_CLOSED_FORM"); return !e || atoi(e) != 0; }();
+    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result, closed ? delta : -1.0);
 }
 
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta, int32_t nthreads,
