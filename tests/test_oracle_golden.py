@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import scipy.stats
 
-from tests.util import (ALL_CASES, INTEGRATED, SEPARABLE, case_X, coeff_lists, load_case, make_oracle, relerr)
+from tests.util import (ALL_CASES, INTEGRATED, SEPARABLE, case_X, coeff_lists, ctor_kwargs, load_case, make_oracle, relerr)
 
 
 @pytest.mark.parametrize('name', ALL_CASES)
@@ -201,3 +201,44 @@ def test_entf_first_update_and_cycles():
     assert relerr(Zp, npz['u0_Z']) < 1e-12
     Ystar = np.repeat(npz['obs'][0][0].reshape((1, 1)), Zp.shape[0], axis=0)
     assert relerr(om.inverse_map(npz['u0_Z'], X_star=Ystar), npz['u0_ret']) < 1e-11
+
+
+def test_entf_five_cycles():
+    """The reference's five assimilation cycles (every random draw replayed) through the oracle and the host-loop
+    harness of the product: the analysis ensemble of every cycle within 1e-6."""
+    from oracle.ttm_oracle import OracleMap
+    from triangular_transport_toolbox_amd import entf
+    npz, desc = load_case('entf')
+    ens = npz['ens0']
+    om = OracleMap(X=np.random.default_rng(0).uniform(size=(ens.shape[0], 4)), monotone=desc['monotone'],
+                   nonmonotone=desc['nonmonotone'], **{**desc['kwargs'], 'quadrature_input': {'order': 5}})
+    assert len(npz['obs']) == 5
+    for t in range(5):
+        noises = [npz['noise_%d_%d' % (t, i)] for i in range(3)]
+        Xa = entf.assimilate(om, ens, npz['obs'][t], noises)
+        assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
+        ens = entf.rk4(Xa, 0.05, 2)
+        assert relerr(ens, npz['forecast_%d' % t]) < 1e-6
+
+
+def test_example05_density_grids():
+    """example_05.py:146-162 and 330-400 through the oracle."""
+    from oracle.ttm_oracle import OracleMap
+    from triangular_transport_toolbox_amd import specs
+    npz, desc = load_case('ex05_density')
+    om = make_oracle('ex05_density', npz, desc['full'])
+    grid = npz['grid']
+    assert relerr(om.map(grid), npz['grid_Z']) < 1e-12
+    assert relerr(om.evaluate_pullback_density(grid), npz['pullback']) < 1e-12
+    got = om.evaluate_pushforward_density(grid, specs.logpdf_wavy)
+    ok = np.isfinite(npz['pushforward'])
+    assert np.array_equal(np.isfinite(got), ok) and relerr(got[ok], npz['pushforward'][ok]) < 1e-9
+    d = desc['conditional']
+    oc = OracleMap(X=npz['X'], monotone=d['monotone'], nonmonotone=d['nonmonotone'], **ctor_kwargs(d))
+    oc.coeffs_mon, oc.coeffs_nonmon = coeff_lists(npz, oc.D, prefix='cond_')
+    g = np.linspace(-3, 3, 101)[:, np.newaxis]
+    Xstar = np.ones((101, 1))
+    assert relerr(oc.evaluate_pullback_density(g, X_star=Xstar), npz['cond_pullback']) < 1e-12
+    got = oc.evaluate_pushforward_density(g, lambda x: specs.logpdf_wavy(np.column_stack((Xstar, x))), X_star=Xstar)
+    ok = np.isfinite(npz['cond_pushforward'])
+    assert np.array_equal(np.isfinite(got), ok) and relerr(got[ok], npz['cond_pushforward'][ok]) < 1e-9

@@ -182,6 +182,31 @@ def test_densities(backend, name):
         assert relerr(got[ok], npz['pushforward'][ok]) < 1e-8
 
 
+def test_example05_density_grids(backend):
+    """The pullback and pushforward densities of example_05.py on its 101 x 101 grid (example_05.py:146-162; the grid
+    reaches three standard deviations beyond the samples: the tails of the table inverse) and the conditional
+    densities at x_1 = 1 of its second half."""
+    from triangular_transport_toolbox_amd import specs
+    npz, desc = load_case('ex05_density')
+    tm = make_tm('ex05_density', npz, desc['full'])
+    grid = npz['grid']
+    assert relerr(tm.map(grid), npz['grid_Z']) < 1e-11
+    assert relerr(tm.evaluate_pullback_density(grid), npz['pullback']) < 1e-10
+    got = tm.evaluate_pushforward_density(grid, specs.logpdf_wavy)
+    ok = np.isfinite(npz['pushforward'])
+    assert np.array_equal(np.isfinite(got), ok)
+    assert relerr(got[ok], npz['pushforward'][ok]) < 1e-8
+    tc = make_tm('ex05_density', npz, desc['conditional'], with_coeffs=False)
+    tc.coeffs_mon, tc.coeffs_nonmon = coeff_lists(npz, tc.D, prefix='cond_')
+    g = np.linspace(-3, 3, 101)[:, np.newaxis]
+    Xstar = np.ones((101, 1))
+    assert relerr(tc.evaluate_pullback_density(g, X_star=Xstar), npz['cond_pullback']) < 1e-10
+    got = tc.evaluate_pushforward_density(g, lambda x: specs.logpdf_wavy(np.column_stack((Xstar, x))), X_star=Xstar)
+    ok = np.isfinite(npz['cond_pushforward'])
+    assert np.array_equal(np.isfinite(got), ok)
+    assert relerr(got[ok], npz['cond_pushforward'][ok]) < 1e-8
+
+
 @pytest.mark.parametrize('name', ['c1_int', 'c2b_sep', 'c3_sep'])
 def test_optimize(backend, name):
     npz, desc = load_case(name)
@@ -289,13 +314,14 @@ def test_argument_errors(backend):
 
 
 def test_entf_cycles_match_reference(backend):
-    """Three full assimilation cycles of the Example-06 filter (N = 500, all random draws replayed from the
+    """Five full assimilation cycles of the Example-06 filter (N = 500, all random draws replayed from the
     fixture): the ensemble after every cycle stays within 1e-6 of the reference's."""
     from triangular_transport_toolbox_amd import entf
     npz, desc = load_case('entf')
     ens = npz['ens0']
     tm = entf.make_filter_map(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
-    for t in range(3):
+    assert len(npz['obs']) == 5
+    for t in range(len(npz['obs'])):
         noises = [npz['noise_%d_%d' % (t, i)] for i in range(3)]
         Xa = entf.assimilate(tm, ens, npz['obs'][t], noises)
         assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
@@ -305,7 +331,7 @@ def test_entf_cycles_match_reference(backend):
 
 def test_device_resident_filter_matches_reference_and_host_loop(backend):
     """entf.Filter - forecast, observation noise, map input, reset, optimisation, pushforward, conditional inverse all on
-    the device, no host copy of the ensemble - replays the reference's three cycles (its own noise draws added on the
+    the device, no host copy of the ensemble - replays the reference's five cycles (its own noise draws added on the
     device) within 1e-6, and agrees with the host-loop harness `assimilate` to rounding."""
     from triangular_transport_toolbox_amd import entf
     npz, desc = load_case('entf')
@@ -314,7 +340,7 @@ def test_device_resident_filter_matches_reference_and_host_loop(backend):
     flt.set_ensemble(ens)
     tm_host = entf.make_filter_map(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
     host = ens
-    for t in range(3):
+    for t in range(len(npz['obs'])):
         noises = np.stack([npz['noise_%d_%d' % (t, i)] for i in range(3)])
         flt.assimilate(npz['obs'][t], noises=noises)
         Xa = flt.ensemble()

@@ -117,6 +117,20 @@ def banded_separable_spec(D, band=2):
     return monotone, nonmonotone
 
 
+def density_example_spec(maxorder=3, D=2):
+    """The separable map of example_05.py:78-110: monotone [k] + (maxorder-1) iRBF k; nonmonotone [], [k-1] and
+    Hermite-function powers of x_{k-1} up to `maxorder`."""
+    monotone, nonmonotone = [], []
+    for k in range(D):
+        monotone.append([[k]] + ['iRBF ' + str(k)] * (maxorder - 1))
+        nonmonotone.append([[]])
+        if k > 0:
+            nonmonotone[-1].append([k - 1])
+            for o in range(1, maxorder):
+                nonmonotone[-1].append([k - 1] * (o + 1) + ['HF'])
+    return monotone, nonmonotone
+
+
 def entf_filter_spec(maxorder):
     """The 4-column filtering map of example_06.py:186-214 (X is N x 4, D = 3,
     skip_dimensions = 1)."""
@@ -200,6 +214,25 @@ def sample_mixture(N, d=40, seed=12345):
     return X
 
 
+def sample_wavy(N, seed=0):
+    """The "wavy" target of example_05.py:22-38 (a sine ridge with beta(2,2) marginal along x_0), drawn after
+    np.random.seed(seed) with the same sequence of RNG calls (beta then normal)."""
+    import scipy.stats
+    np.random.seed(seed)
+    x0 = (scipy.stats.beta.rvs(a=2, b=2, size=N) * 2 - 1) * 3
+    x1 = scipy.stats.norm.rvs(scale=1 / 6, size=N) + np.sin(x0 * 1.2)
+    return np.column_stack((x0 / 1.5, x1 * 1.5))
+
+
+def logpdf_wavy(X):
+    """Log-density of `sample_wavy` as example_05.py:41-68 evaluates it (beta argument clipped to [1e-6, 1-1e-6])."""
+    import scipy.stats
+    x0 = X[:, 0] * 1.5
+    x1 = X[:, 1] / 1.5 - np.sin(x0 * 1.2)
+    loc = np.clip((x0 / 3 + 1) / 2, 0.000001, 0.999999)
+    return np.log(1 / 6) + scipy.stats.beta.logpdf(loc, a=2, b=2) + scipy.stats.norm.logpdf(x1, scale=1 / 6)
+
+
 def reference_samples(N, D, seed=1):
     """Z drawn from the standard Gaussian reference (inverse-map input)."""
     return np.random.default_rng(seed).standard_normal((N, D))
@@ -243,4 +276,8 @@ def config(name):
         return dict(monotone=mon, nonmonotone=non, sampler=sample_mixture,
                     kwargs=dict(monotonicity='integrated rectifier',
                                 quadrature_input={'order': 25}))
+    if name == 'EX05':
+        mon, non = density_example_spec(3)
+        return dict(monotone=mon, nonmonotone=non, sampler=sample_wavy,
+                    kwargs=dict(monotonicity='separable monotonicity', quadrature_input={'order': 25}))
     raise KeyError(name)
