@@ -220,6 +220,9 @@ extern "C" {
 /* "push" records of a BANDED U-form map (P section, behind the H section; written by ttm_fold when u_p_lag > 0).
  * Banded: the components' columns are consecutive (kc_k = kc_0 + k), every nonmonotone group of component k reads a
  * column kc_k - 1 .. kc_k - u_p_lag, every component has a special-term spline and hot records exist (u_h_cls > 0).
+ * u_p_lag is 2, or 3 (= TTM_P_LAG_MAX) for a map of at most TTM_P_FEW_D components with a group three columns back; in
+ * the latter case the hot records exist ONLY as the source of the push records (their groups need not hit the planned
+ * column cache: the kernels that sweep hot records do not take such a map).
  * The band kernels (csrc/ttm_band.hip) walk the columns and add what a column contributes to the components that
  * read it as soon as the column is known, so the records are indexed by COLUMN: record r (0 <= r < D + u_p_lag)
  * belongs to column kc_0 - u_p_lag + r, i.e. to component k = r - u_p_lag when that is >= 0 (the first u_p_lag records
@@ -236,7 +239,8 @@ extern "C" {
  * ttm_fold also writes, into padding slot 12 of every spline column c of such a map, the offset s0 of its local
  * coordinate: s = x [4] + s0.                                                                                     */
 #define TTM_P_HDR         8
-#define TTM_P_LAG_MAX     2
+#define TTM_P_LAG_MAX     3
+#define TTM_P_FEW_D       4   /* components of a map the lag-3 kernels take, at most */
 
 typedef struct ttm_program {
     /* device tables */
@@ -288,7 +292,7 @@ typedef struct ttm_program {
     int32_t u_h_cls;            /* 0: no hot records; 1..3: degree class             */
     int32_t u_h_ng;             /* group records per component                       */
     int64_t u_p_off;            /* offset (within the U section) of the push records */
-    int32_t u_p_lag;            /* 0: not a banded map; else the largest lag of a group (<= TTM_P_LAG_MAX) */
+    int32_t u_p_lag;            /* 0: not a banded map; else groups per push record: 2, or 3 (see above) */
     int32_t u_p_stride;         /* doubles per push record                           */
 } ttm_program;
 

@@ -362,7 +362,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     const Prog g = make_prog(p);
     if (p->monotonicity == TTM_MONO_SEPARABLE && u_on(p) && all_fast(p, k0, k1)) {     // same dispatch as the library
         std::vector<double> S(k1 - k0);
-        const bool hot = p->u_h_cls > 0 && !getenv("TTM_EMU_NO_HOT");     // hot records (what k_forward_hl evaluates)
+        const bool hot = p->u_h_cls > 0 && p->u_p_lag <= 2 && !getenv("TTM_EMU_NO_HOT");     // hot records (what k_forward_hl evaluates)
         for (int64_t n = 0; n < N; ++n) {
             XSoA xa{X, ldx, n};
             double ld, ss;
@@ -443,7 +443,7 @@ int emu_forward_vec2(const ttm_program* p, const double* coef, const double* fol
             const int64_t n1 = n + 1 < N ? n + 1 : n;
             XSoA2 xa{X, ldx, n, n1};
             VecD<2> ld, ss;
-            const bool hot = p->u_h_cls > 0 && !getenv("TTM_EMU_NO_HOT");
+            const bool hot = p->u_h_cls > 0 && p->u_p_lag <= 2 && !getenv("TTM_EMU_NO_HOT");
             if (!(hot && forward_h_dispatch<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr)))
                 forward_u<VecD<2>>(p, fold, xa, k0, k1, true, true, S.data(), ld, ss, nullptr);
             for (int k = k0; k < k1; ++k) {
@@ -686,7 +686,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
                       int32_t truncate, void*) {
     const Prog g = make_prog(p);
-    if (u_on(p) && p->u_h_cls >= 1 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
+    if (u_on(p) && p->u_h_cls >= 1 && p->u_p_lag <= 2 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
         (nb + 1) % 4 == 0 && !getenv("TTM_EMU_NO_HOT")) {
         // hot records + bucket scan + computed linspace abscissae: what k_inverse_hl evaluates
         const double* U = fold + fold_base_size(p);

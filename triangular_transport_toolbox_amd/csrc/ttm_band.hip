@@ -185,6 +185,28 @@ __device__ __forceinline__ void band_push(const G& g, double start, double x, do
     }
 }
 
+// the same for the kernels of maps with a few components: only the first LAGE groups of a record (no group of the sweep
+// reaches further back), and without the plain polynomials when no group has any (PLAIN false).  GP: doubles per group
+// of the record.
+template <int DB, int DA, int GP, int LAGE, bool PLAIN, class G>
+__device__ __forceinline__ void band_push_e(const G& g, double start, double x, double E, double (&pend)[LAGE]) {
+#pragma unroll
+    for (int l = 0; l < LAGE; ++l) {
+        const auto c = &g[l * GP];
+        double b = c[DB];
+#pragma unroll
+        for (int i = DB - 1; i >= 0; --i) b = fma(b, x, c[i]);
+        double a = l + 1 < LAGE ? pend[l + 1] : start;
+        if (PLAIN) {
+            double q = c[DB + DA];
+#pragma unroll
+            for (int i = DA - 1; i >= 1; --i) q = fma(q, x, c[DB + i]);
+            a = fma(q, x, a);
+        }
+        pend[l] = fma(E, b, a);
+    }
+}
+
 // the special-term spline of a component at x: tab = the component's resident table, spl = {1 - t_lo/h, 1/h, 2/h}
 __device__ __forceinline__ double band_spline(const double* tab, int nI, double sp_a, double sp_b, double sp_ds, double x) {
     const int col = band_med3((int)fma(x, sp_b, sp_a), 0, nI - 1);
@@ -606,6 +628,221 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// maps of a few components (at most TTM_P_FEW_D: the spiral / temperature / banana examples, the filter and smoother
+// blocks): a launch is a handful of microseconds, so what counts is the chain of memory round trips in front of the
+// first store.  Here it is ONE: the E table, every spline and ALL columns of the tile are requested together (tables
+// first - the counter of outstanding loads retires in order), the tables go to LDS while the columns travel, then the
+// columns are walked in registers.  Same arithmetic per row as k_band_forward / k_band_density.
+// DENS: also sum_k log(dS_k/dx_k / sigma_k) and sum_k S_k^2 per row (Z optional)
+// ---------------------------------------------------------------------------
+#ifndef BAND_FEW_STAGE
+#define BAND_FEW_STAGE 0
+#endif
+#ifndef BAND_FEW_NS
+#define BAND_FEW_NS 2                                 /* rows per thread and tile of the few-component kernels */
+#endif
+#ifndef BAND_FEW_NT
+#define BAND_FEW_NT 1                                 /* non-temporal stores of the few-component kernels */
+#endif
+#define BAND_FEW_TAB (4 * BAND_CT)                    /* doubles of splines a launch can stage (two 16-byte loads per thread) */
+// LAG: groups per push record (u_p_lag); LAGE <= LAG: how far back a group of the sweep reaches; PLAIN: some group has
+// plain polynomial terms
+template <int CLS, int LAG, int LAGE, bool PLAIN, bool DENS>
+__global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                      const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                      double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
+                                                      const double* __restrict__ sigma, double* __restrict__ sumsq, int ntiles) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), GP = cls_gp(CLS), PS = rec_stride(CLS, LAG);
+    // two rows (one 16-byte pair) per thread and tile: with tiles of 2048 rows even half a million rows reach every CU;
+    // the columns of a workgroup's next tile are requested before the current one is evaluated
+    constexpr int NS = BAND_FEW_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT, FD = TTM_P_FEW_D;
+    extern __shared__ __align__(16) double g_lds[];
+    double* etab = g_lds;
+    double* tabs = g_lds + BAND_ET_DOUBLES;
+    const int tid = threadIdx.x;
+    const int nc = k1 - k0;
+#if BAND_FEW_STAGE == 1                                      /* (timing experiments: results wrong by construction) */
+    if (N > 0) return;
+#endif
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    cdbl_p kt = (cdbl_p)g_band_taylor;
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const unsigned int N32 = (unsigned int)N;
+    const int64_t ldxb = ldx * 8, ldzb = ldz * 8;
+    // tables: requested now, written to LDS after the first tile's columns have been requested
+    int tab0, ntab;
+    {
+        cint_p rb = (cint_p)(P + (int64_t)(k0 + LAG) * PS), re = (cint_p)(P + (int64_t)(k1 - 1 + LAG) * PS);
+        tab0 = rb[11];
+        ntab = re[11] + TTM_U_TSTRIDE * re[10] - tab0;                        // doubles (even, <= BAND_FEW_TAB: the host checks)
+    }
+    const D2 ev = *(const D2*)(g_band_etab + 2 * min(tid, TTM_BAND_ET_N - 1));
+    D2 sv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) sv[r] = *(const D2*)(U_ + tab0 + min(2 * tid + r * 2 * CT, ntab - 2));
+    __builtin_amdgcn_sched_barrier(0);
+    double luni = 0.0;
+    bool staged = false;
+    // every column of a tile: the LAGE columns in front of the first component (conditioning columns; none: zeros) and the
+    // components' own (clamped duplicates beyond the last: unconditional loads stay in flight together)
+    auto request = [&](int tile, D2 (&xf)[LAGE][NP], D2 (&xin)[FD][NP]) {
+        unsigned int roff[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned int n = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
+            n = n < last_pair ? n : last_pair;
+            roff[q] = n * 8u;
+        }
+        if (kcol0 > 0) {
+#pragma unroll
+            for (int i = 0; i < LAGE; ++i) {
+                const int cc = kcol0 - LAGE + i;
+                const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) xf[i][q] = band_load2(col + roff[q]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FD; ++j) {
+            const char* col = (const char*)X + (int64_t)(kcol0 + min(j, nc - 1)) * ldxb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xin[j][q] = band_load2(col + roff[q]);
+        }
+    };
+    D2 xf[LAGE][NP], xin[FD][NP], xfn[LAGE][NP], xinn[FD][NP];
+    if ((int)blockIdx.x < ntiles) request(blockIdx.x, xf, xin);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned int tbase = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!staged) {
+            if (tid < TTM_BAND_ET_N) *(D2*)(etab + 2 * tid) = ev;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = 2 * tid + r * 2 * CT;
+                if (i < ntab) *(D2*)(tabs + i) = sv[r];
+            }
+            if (DENS) {
+                // uniform part of the log-determinant: sum_k log(2 / h_k) - sum_k log(sigma_k), in component order
+                for (int k = 0; k < nc; ++k) {
+                    luni += band_log(P[(int64_t)(k0 + k + LAG) * PS + 4]);
+                    if (sigma) luni -= band_log(sigma[k]);
+                }
+            }
+            __syncthreads();
+            staged = true;
+        }
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more) request(tile + gridDim.x, xfn, xinn);
+        __builtin_amdgcn_sched_barrier(0);
+#if BAND_FEW_STAGE == 2 || BAND_FEW_STAGE == 3
+        {
+            double acc = etab[tid & 511] + tabs[tid & 255];
+#pragma unroll
+            for (int j = 0; j < FD; ++j)
+#pragma unroll
+                for (int q = 0; q < NP; ++q) acc += xin[j][q].x + xin[j][q].y;
+            if (BAND_FEW_STAGE == 3) {
+#pragma unroll
+                for (int j = 0; j < FD; ++j)
+                    if (j < nc)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const unsigned int n = tbase + (unsigned int)(q * HALF);
+                            if (n + 1 < N32) band_store2<false>((char*)Z + (int64_t)j * ldzb + (size_t)(n * 8u), acc, xin[j][q].y);
+                        }
+            } else if (acc == 1.2345e300) Z[tid] = acc;
+            continue;
+        }
+#endif
+        double pend[NS][LAGE];
+#pragma unroll
+        for (int l = 0; l < LAGE; ++l) {
+            const double s0 = P[(int64_t)(k0 + l) * PS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) pend[e][l] = s0;
+        }
+        if (kcol0 > 0) {
+#pragma unroll
+            for (int i = 0; i < LAGE; ++i) {
+                // (record of the column LAGE - i in front of component k0; the chain it starts is component k0 + i's)
+                const bool there = kcol0 - LAGE + i >= 0;
+                cdbl_p rec = P + (int64_t)(k0 + LAG - LAGE + i) * PS;
+                const double start = P[(int64_t)(k0 + i) * PS];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const double xa = there ? xf[i][q].x : 0.0, xb = there ? xf[i][q].y : 0.0;
+                    band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xa, band_expq(etab, xa, kt), pend[2 * q]);
+                    band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xb, band_expq(etab, xb, kt), pend[2 * q + 1]);
+                }
+            }
+        }
+        double ss[NS], prod[NS];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; }
+#pragma unroll
+        for (int j = 0; j < FD; ++j) {
+            if (j < nc) {
+                cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
+                const double start = P[(int64_t)(k0 + j + LAGE) * PS];        // (of the component LAGE columns on)
+                const double sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4];
+                cint_p ri = (cint_p)rec;
+                const int nI = ri[10];
+                const double* tab = tabs + (ri[11] - tab0);
+                char* zcol = (char*)Z + (int64_t)j * ldzb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    double zv[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int e = 2 * q + h;
+                        const double x = h ? xin[j][q].y : xin[j][q].x;
+                        double m, dm = 1.0;
+                        if (DENS) band_spline_d(tab, nI, sp_a, sp_b, sp_ds, x, m, dm);
+                        else m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
+                        const double E = band_expq(etab, x, kt);
+                        zv[h] = pend[e][0] + m;
+                        if (DENS) { ss[e] = fma(zv[h], zv[h], ss[e]); prod[e] *= dm; }
+                        band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, x, E, pend[e]);
+                    }
+                    if (!DENS || Z) {
+                        const unsigned int n = tbase + (unsigned int)(q * HALF);
+                        char* zp = zcol + (size_t)(n * 8u);
+                        if (n + 1 < N32) band_store2<BAND_FEW_NT != 0>(zp, zv[0], zv[1]);
+                        else if (n < N32) *(double*)zp = zv[0];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (DENS) {
+            // (a product of at most four derivatives cannot leave the fp64 range unless one of them does)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const unsigned int n = tbase + (unsigned int)(q * HALF);
+                if (logdet) {
+                    const double la = band_log(prod[2 * q]) + luni, lb = band_log(prod[2 * q + 1]) + luni;
+                    if (n + 1 < N32) band_store2<false>((char*)(logdet + n), la, lb);
+                    else if (n < N32) logdet[n] = la;
+                }
+                if (sumsq) {
+                    if (n + 1 < N32) band_store2<false>((char*)(sumsq + n), ss[2 * q], ss[2 * q + 1]);
+                    else if (n < N32) sumsq[n] = ss[2 * q];
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < LAGE; ++i) xf[i][q] = xfn[i][q];
+#pragma unroll
+                for (int jj = 0; jj < FD; ++jj) xin[jj][q] = xinn[jj][q];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // table inverse (TM:3987-4084) in push form
 // ---------------------------------------------------------------------------
 // The resident-table machinery is that of k_inverse_rt (csrc/ttm_kernels.hip: blocks of components, windowed tables,
@@ -847,7 +1084,8 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
     if (j < ke) step(j, za, zb);
 }
 
-template <int CLS, int LAG>
+// KM: components per block, at most (what the table load is unrolled for: 4 for maps of a few components, BAND_RT_KMAX)
+template <int CLS, int LAG, int KM>
 __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
                                                           const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
                                                           const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
@@ -911,7 +1149,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
         // the tables of the block: every load of the block in flight at once (element i of every table by thread i; the
         // bucket indices sixteen bytes at a time), the search parameters next to them
         {
-            constexpr int KMAX = BAND_RT_KMAX;                // components per block, at most (the host plans for it)
+            constexpr int KMAX = KM;                          // components per block, at most (the host plans for it)
             double lo = 0.0, hi = 0.0;
             if (tid < nk) { lo = tmin[kb - k0 + tid]; hi = tmax[kb - k0 + tid]; }
             {
@@ -1019,6 +1257,262 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
 }
 
 // ---------------------------------------------------------------------------
+// table inverse of maps with a few components: as k_band_few, ONE memory round trip in front of the first store - every
+// table (whole, no window), every bucket index and all columns of the tile are requested together.  Tables of any shape:
+// the bucket of a target is searched four ways at a time (three resident reads per phase, as many phases as the
+// fullest bucket of the component needs: 1 up to 3 entries, 2 up to 15, 3 up to 63, 4 up to 255), where k_band_inverse
+// compares up to four entries and sends fuller tables row by row to memory.
+// LDS (doubles): [tables: nc x tab_slot | {E_i, y_i}: 2 x Weven];  table slot: [scale, bias, int32 {fullest bucket, 0},
+// 0, 0, 0 (the entry "in front of the first") | xs: T entries + sentinels (+inf) up to Weven | bucket index: nb + 1 uint16]
+// Needs nb + 1 = 1024 (one 16-byte load of bucket starts per thread) and T + 4 <= 1024 (entry i by thread i).
+// ---------------------------------------------------------------------------
+template <int CLS, int LAG, int LAGE, bool PLAIN>
+__global__ __launch_bounds__(BAND_CT) void k_band_few_inverse(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                              const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
+                                                              const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
+                                                              const double* __restrict__ tmin, const double* __restrict__ tmax,
+                                                              const int* __restrict__ bkt, int nb, int tab_slot, int ntiles) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), GP = cls_gp(CLS), PS = rec_stride(CLS, LAG);
+    constexpr int NS = BAND_FEW_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT, FD = TTM_P_FEW_D, HDR = BAND_RT_HDR;
+    extern __shared__ __align__(16) double g_lds[];
+    const int tid = threadIdx.x;
+    const int nc = k1 - k0;
+    const int Weven = (T + 4 + 1) & ~1;
+    double* tabs = g_lds;
+    double* etab = tabs + (size_t)nc * tab_slot;
+    const lds_p etab1 = band_lds(etab) - 16;                  // pair of entry i - 1 at etab1 + 16 i
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    cdbl_p kt = (cdbl_p)g_band_taylor;
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const unsigned int N32 = (unsigned int)N;
+    const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
+    const double y0m = y0 - ystep;
+    const int nb1 = nb - 1;
+    // tables and bucket starts: requested now (first: the counter of outstanding loads retires in order)
+    double tv[FD];
+    {
+        const double* src = tab_x + min(tid, T - 1);
+#pragma unroll
+        for (int u = 0; u < FD; ++u) tv[u] = src[(int64_t)min(u, nc - 1) * T];
+    }
+    const int bc = min(tid >> 8, nc - 1), bw = tid & 255;     // this thread's four bucket starts: component, first bucket / 4
+    const int4 bv = *(const int4*)(bkt + (int64_t)bc * (nb + 1) + 4 * bw);
+    __builtin_amdgcn_sched_barrier(0);
+    // interp1d slope form (TM:4062-4065) in the located interval and exp(-x^2/4) = E[i-1] exp(w), w = -delta (y_lo + x) / 4
+    auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
+        const double dx = fmax(x_hi - x_lo, 1e-300);                          // (tie at a flat start: k_inverse_rt)
+        double rc = __builtin_amdgcn_rcp(dx);
+        rc = fma(fma(-dx, rc, 1.0), rc, rc);
+        const double delta = (ystep * rc) * (tgt - x_lo);
+        rr = delta + y_lo;
+        const double w = (delta * -0.25) * (y_lo + rr);
+        double p = fma(kt[0], w, kt[1]);
+        p = fma(p, w, kt[2]);
+        p = fma(p, w, kt[3]);
+        p = fma(p, w, kt[4]);
+        p = fma(p, w, kt[5]);
+        p = fma(p, w, 1.0);
+        p = fma(p, w, 1.0);
+        ee = e_lo * p;
+    };
+    // every column of a tile: the conditioning columns in front of the first component (already in X) and z
+    auto request = [&](int tile, D2 (&xf)[LAGE][NP], D2 (&zin)[FD][NP]) {
+        unsigned int roff[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned int n = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
+            n = n < last_pair ? n : last_pair;
+            roff[q] = n * 8u;
+        }
+        if (kcol0 > 0) {
+#pragma unroll
+            for (int i = 0; i < LAGE; ++i) {
+                const int cc = kcol0 - LAGE + i;
+                const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) xf[i][q] = band_load2(col + roff[q]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FD; ++j) {
+            const char* col = (const char*)Z + (int64_t)min(j, nc - 1) * ldzb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) zin[j][q] = band_load2(col + roff[q]);
+        }
+    };
+    D2 xf[LAGE][NP], zin[FD][NP], xfn[LAGE][NP], zinn[FD][NP];
+    if ((int)blockIdx.x < ntiles) request(blockIdx.x, xf, zin);
+    bool staged = false;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned int tbase = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!staged) {
+            // E of grid point i and, next to it, that point's abscissa exactly as the interpolation forms it from the interval
+            // number (computed while the loads travel)
+            if (tid < T) {
+                etab[2 * tid] = band_expq_series(tid == T - 1 ? ylast : (double)tid * ystep + y0);
+                etab[2 * tid + 1] = fma((double)(tid + 1), ystep, y0m);
+            }
+            if (tid < nc) {
+                double* slot = tabs + (size_t)tid * tab_slot;
+                double scale, bias;
+                band_bucket_params(tmin[tid], tmax[tid], nb, scale, bias);
+                slot[0] = scale; slot[1] = bias;
+                ((int*)slot)[4] = 0; ((int*)slot)[5] = 0;
+                slot[3] = 0.0; slot[4] = 0.0; slot[5] = 0.0;
+            }
+            // (stores unconditional: a slot beyond the last table repeats that table's value - the clamped load - into
+            // that table's slot)
+            if (tid < Weven) {
+#pragma unroll
+                for (int u = 0; u < FD; ++u) tabs[(size_t)min(u, nc - 1) * tab_slot + HDR + tid] = tid < T ? tv[u] : INFINITY;
+            }
+            {
+                unsigned short* bs = (unsigned short*)(tabs + (size_t)bc * tab_slot + HDR + Weven) + 4 * bw;
+                const uint2 pk = {(unsigned int)(bv.x & 0xffff) | ((unsigned int)bv.y << 16), (unsigned int)(bv.z & 0xffff) | ((unsigned int)bv.w << 16)};
+                *(uint2*)bs = pk;
+            }
+            __syncthreads();
+            // the fullest bucket of every table
+            if ((tid >> 8) < nc) {
+                const unsigned short* bs = (const unsigned short*)(tabs + (size_t)bc * tab_slot + HDR + Weven);
+                const int b4 = bw < 255 ? (int)bs[4 * bw + 4] : bv.w;
+                int per = max(bv.y - bv.x, max(bv.z - bv.y, bv.w - bv.z));
+                per = max(per, b4 - bv.w);                    // (bucket nb does not exist: b4 = its start there, 0 entries)
+                for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+                if ((tid & 63) == 0) atomicMax((int*)(tabs + (size_t)bc * tab_slot) + 4, per);
+            }
+            __syncthreads();
+            staged = true;
+        }
+        const bool more = tile + (int)gridDim.x < ntiles;
+        if (more) request(tile + gridDim.x, xfn, zinn);
+        __builtin_amdgcn_sched_barrier(0);
+        double pend[NS][LAGE];
+#pragma unroll
+        for (int l = 0; l < LAGE; ++l) {
+            const double s0 = P[(int64_t)(k0 + l) * PS + 1];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) pend[e][l] = s0;
+        }
+        if (kcol0 > 0) {
+#pragma unroll
+            for (int i = 0; i < LAGE; ++i) {
+                const bool there = kcol0 - LAGE + i >= 0;
+                cdbl_p rec = P + (int64_t)(k0 + LAG - LAGE + i) * PS;
+                const double start = P[(int64_t)(k0 + i) * PS + 1];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const double xa = there ? xf[i][q].x : 0.0, xb = there ? xf[i][q].y : 0.0;
+                    band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xa, there ? band_expq_series(xa) : 1.0, pend[2 * q]);
+                    band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xb, there ? band_expq_series(xb) : 1.0, pend[2 * q + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FD; ++j) {
+            if (j < nc) {
+                cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
+                const double start = P[(int64_t)(k0 + j + LAGE) * PS + 1];
+                const double* slot = tabs + (size_t)j * tab_slot;
+                const double scale = slot[0], bias = slot[1];
+                const int per = __builtin_amdgcn_readfirstlane(((const int*)slot)[4]);
+                const int pm = max(per, 1);
+                const bool deg = pm + 3 >= T || per > 255;
+                const lds_p xsl = band_lds(slot + HDR);
+                const lds_p bkl = band_lds(slot + HDR + Weven);
+                const double wl = band_lds_f64(xsl + 8 * (deg ? 1 : pm)), wh = band_lds_f64(xsl + 8 * (deg ? 1 : T - 2));
+                const int nph = per <= 3 ? 1 : per <= 15 ? 2 : per <= 63 ? 3 : 4;
+                double traw[NS], tg[NS], r[NS], E[NS];
+                unsigned long long outl = deg ? ~0ull : 0ull;
+                int pos[NS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const double z = (e & 1) ? zin[j][e >> 1].y : zin[j][e >> 1].x;
+                    traw[e] = z - pend[e][0];
+                    tg[e] = fmin(fmax(traw[e], wl), wh);
+                    outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
+                    const int bi = min((int)fma(tg[e], scale, bias), nb1);
+                    pos[e] = (int)*(const __attribute__((address_space(3))) unsigned short*)(bkl + 2 * bi);
+                }
+                // np.searchsorted(xs, target) (left) = entries in lower buckets + entries of the target's own bucket below it
+                // (the bucket function is monotone: k_table_index).  A phase of stride s tests the entries s, 2s, 3s on from
+                // pos: every one below the target moves pos on by s; what is left are fewer than s candidates.
+                for (int ph = 0, s = 1 << (2 * (nph - 1)); ph < nph; ++ph, s >>= 2) {
+                    double qv[NS][3];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) qv[e][i] = band_lds_f64_single(xsl + 8 * min(pos[e] + (i + 1) * s - 1, T + 3));
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        int c = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) c += qv[e][i] < tg[e] ? 1 : 0;
+                        pos[e] += c * s;
+                    }
+                }
+                {
+                    D2 ey[NS];
+                    double xlo[NS], xhi[NS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const int ps1 = band_med3(pos[e], 1, T - 1);          // (a flat start: the first interval, as the search in memory)
+                        ey[e] = band_lds_pair(etab1 + 16 * ps1);
+                        const lds_p xp = xsl + 8 * ps1;
+                        xlo[e] = band_lds_f64(xp - 8);
+                        xhi[e] = band_lds_f64_single(xp);
+                    }
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) interp(ey[e].y, xlo[e], xhi[e], ey[e].x, tg[e], r[e], E[e]);
+                }
+                if (outl != 0) {
+                    // outliers (the tails of the table, NaN; every row of a degenerate table): clip as TM:4074-4076,
+                    // np.searchsorted (left) over the whole row in memory, the same interpolation
+                    const double* xg = tab_x + (int64_t)j * T;
+                    const double lo = tmin[j], hi = tmax[j];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        if (deg || traw[e] != tg[e]) {
+                            double t = traw[e];
+                            const double cl = fmin(fmax(t, lo), hi);
+                            t = t != t ? t : cl;                              // a NaN target stays NaN
+                            int a = 0, b = T;
+                            while (a < b) {
+                                const int mid = (a + b) >> 1;
+                                if (xg[mid] < t) a = mid + 1; else b = mid;
+                            }
+                            const int i = min(max(a, 1), T - 1);
+                            interp(fma((double)i, ystep, y0m), xg[i - 1], xg[i], band_expq_series((double)(i - 1) * ystep + y0), t, r[e], E[e]);
+                        }
+                    }
+                }
+                // x_k is pushed on to the components that read it, and stored
+#pragma unroll
+                for (int e = 0; e < NS; ++e) band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, r[e], E[e], pend[e]);
+                char* xcol = (char*)X + (int64_t)(kcol0 + j) * ldxb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const unsigned int n = tbase + (unsigned int)(q * HALF);
+                    char* xp = xcol + (size_t)(n * 8u);
+                    if (n + 1 < N32) band_store2<BAND_FEW_NT != 0>(xp, r[2 * q], r[2 * q + 1]);
+                    else if (n < N32) *(double*)xp = r[2 * q];
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                for (int i = 0; i < LAGE; ++i) xf[i][q] = xfn[i][q];
+#pragma unroll
+                for (int jj = 0; jj < FD; ++jj) zin[jj][q] = zinn[jj][q];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static void allow_lds(const void* kern, size_t bytes) {
@@ -1049,8 +1543,22 @@ static int64_t chunk_rows(int64_t N, int cus) {
 }
 
 bool usable(const ttm_program* p, int k0, int k1) {
-    return p && p->u_enabled && p->u_p_lag == 2 && p->u_h_cls >= 1 && p->u_h_cls <= 3 && p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 &&
-           p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);
+    return p && p->u_enabled && (p->u_p_lag == 2 || (p->u_p_lag == 3 && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 && p->u_h_cls <= 3 &&
+           p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 && p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);
+}
+
+// how far back the groups of the components [k0, k1) reach, and whether any of them has plain polynomial terms
+static void sweep_shape(const ttm_program* p, int k0, int k1, int* lage, bool* plain) {
+    *lage = 1; *plain = false;
+    for (int k = k0; k < k1; ++k) {
+        const int32_t* uc = p->h_ucomp + k * TTM_UC_LEN;
+        for (int g = 0; g < uc[TTM_UC_N_GRP]; ++g) {
+            const int32_t* G = p->h_ugrp + (uc[TTM_UC_GRP_OFF] + g) * TTM_UG_LEN;
+            const int lag = uc[TTM_UC_KC] - G[TTM_UG_VAR];
+            *lage = lag > *lage ? lag : *lage;
+            *plain = *plain || (G[TTM_UG_FLAGS] & TTM_UGF_POLY);
+        }
+    }
 }
 
 int build_records(const ttm_program* p, double* U, void* stream) {
@@ -1104,6 +1612,43 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
         lds = s > lds ? s : lds;
     }
     lds += fixed - stat;                                      // (dynamic part)
+    const int cls = p->u_h_cls;
+    // a few components: everything requested at once, tiles of 2048 rows (k_band_few)
+    static const int few_on = [] { const char* e = getenv("TTM_BAND_FEW"); return e ? atoi(e) : 1; }();
+    if (k1 - k0 <= TTM_P_FEW_D && few_on) {
+        size_t tabd = 0;
+        for (int k = k0; k < k1; ++k) tabd += (size_t)p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] * TTM_U_TSTRIDE;
+        const size_t flds = (size_t)BAND_ET_DOUBLES * 8 + (tabd + 2) * 8;
+        if (tabd + 2 <= BAND_FEW_TAB && flds <= lds_per_cu && (!sigma || logdet)) {
+            typedef void (*fkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
+                                    double*, int);
+            const bool dens = logdet || sumsq;
+            int lage; bool plain;
+            sweep_shape(p, k0, k1, &lage, &plain);
+            if (lage > p->u_p_lag) return 1;
+            fkern_t fk = nullptr;
+#define BAND_FEW_C(L, E, PL, DN) (cls == 1 ? k_band_few<1, L, E, PL, DN> : cls == 2 ? k_band_few<2, L, E, PL, DN> : k_band_few<3, L, E, PL, DN>)
+#define BAND_FEW_E(L, E) (plain ? BAND_FEW_C(L, E, true, false) : BAND_FEW_C(L, E, false, false))
+            if (dens) {                                       // (the density pass: one variant per record layout)
+                if (p->u_p_lag == 3) fk = BAND_FEW_C(3, 3, true, true); else fk = BAND_FEW_C(2, 2, true, true);
+            } else if (p->u_p_lag == 3) {
+                fk = lage == 1 ? BAND_FEW_E(3, 1) : lage == 2 ? BAND_FEW_E(3, 2) : BAND_FEW_E(3, 3);
+            } else {
+                fk = lage == 1 ? BAND_FEW_E(2, 1) : BAND_FEW_E(2, 2);
+            }
+#undef BAND_FEW_E
+#undef BAND_FEW_C
+            const int64_t trows = BAND_FEW_NS * BAND_CT;
+            const int64_t ntiles = (N + trows - 1) / trows;
+            const int64_t grid = ntiles < cus ? ntiles : cus;
+            allow_lds((const void*)fk, flds);
+            hipLaunchKernelGGL(fk, dim3((unsigned)grid), dim3(BAND_CT), flds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                               (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, (int)ntiles);
+            if (kernel_name) *kernel_name = dens ? "k_band_few<density>" : "k_band_few";
+            return 0;
+        }
+    }
+    if (p->u_p_lag != 2) return 1;
     if (logdet || sumsq) {
         typedef void (*dkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
                                 double*, int64_t, int);
@@ -1139,6 +1684,36 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
                          (ldx % 2 == 0) && ldx >= ((N + 1) & ~(int64_t)1);
     if (!aligned) return 1;
     const int ncomp = k1 - k0;
+    // a few components: whole tables, everything requested at once, tiles of 2048 rows
+    static const int few_on = [] { const char* e = getenv("TTM_BAND_FEW"); return e ? atoi(e) : 1; }();
+    if (ncomp <= TTM_P_FEW_D && few_on && T + 4 <= BAND_CT && window <= 0) {          // (no blocks, no windows: `block` does not apply)
+        const int Weven = (T + 4 + 1) & ~1;
+        const int tab_slot = BAND_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);
+        const size_t lds = ((size_t)ncomp * tab_slot + (size_t)2 * Weven) * 8;
+        int lage; bool plain;
+        sweep_shape(p, k0, k1, &lage, &plain);
+        if (lds <= lds_per_cu && lage <= p->u_p_lag) {
+            typedef void (*fkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int,
+                                    double, double, double, const double*, const double*, const int*, int, int, int);
+            const int cls = p->u_h_cls;
+            fkern_t fk = nullptr;
+#define BAND_FEWI_C(L, E, PL) (cls == 1 ? k_band_few_inverse<1, L, E, PL> : cls == 2 ? k_band_few_inverse<2, L, E, PL> : k_band_few_inverse<3, L, E, PL>)
+#define BAND_FEWI_E(L, E) (plain ? BAND_FEWI_C(L, E, true) : BAND_FEWI_C(L, E, false))
+            if (p->u_p_lag == 3) fk = lage == 1 ? BAND_FEWI_E(3, 1) : lage == 2 ? BAND_FEWI_E(3, 2) : BAND_FEWI_E(3, 3);
+            else fk = lage == 1 ? BAND_FEWI_E(2, 1) : BAND_FEWI_E(2, 2);
+#undef BAND_FEWI_E
+#undef BAND_FEWI_C
+            const int64_t ntiles = (N + BAND_FEW_NS * BAND_CT - 1) / (BAND_FEW_NS * BAND_CT);
+            const int64_t grid = ntiles < cus ? ntiles : cus;
+            allow_lds((const void*)fk, lds);
+            hipLaunchKernelGGL(fk, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                               (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Zsoa, ldz, Xsoa, ldx, N, tab_x, T, y_affine[0], y_affine[1], y_affine[2],
+                               tmin, tmax, bkt, nb, tab_slot, (int)ntiles);
+            if (kernel_name) *kernel_name = "k_band_few_inverse";
+            return 0;
+        }
+    }
+    if (p->u_p_lag != 2) return 1;
     static const int stagger = [] { const char* e = getenv("TTM_BAND_STAGGER"); return e ? atoi(e) : 1; }();
     static const double wfrac = [] { const char* e = getenv("TTM_BAND_WFRAC"); return e ? atof(e) : 0.52; }();
     int W = T, w0 = 0, Weven = 0, tab_slot = 0, Bc = 0, nblk = 0;
@@ -1170,7 +1745,9 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
     if (Bc <= 0) return 1;
     typedef void (*kern_t)(const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int, double,
                            double, double, const double*, const double*, const int*, int, int, int, int64_t, int, int);
-    kern_t kern = p->u_h_cls == 1 ? k_band_inverse<1, 2> : p->u_h_cls == 2 ? k_band_inverse<2, 2> : k_band_inverse<3, 2>;
+    const int cls = p->u_h_cls;
+    kern_t kern;
+    kern = cls == 1 ? k_band_inverse<1, 2, BAND_RT_KMAX> : cls == 2 ? k_band_inverse<2, 2, BAND_RT_KMAX> : k_band_inverse<3, 2, BAND_RT_KMAX>;
     const int64_t rows = chunk_rows(N, cus);
     const int64_t grid = (N + rows - 1) / rows;
     allow_lds((const void*)kern, lds);

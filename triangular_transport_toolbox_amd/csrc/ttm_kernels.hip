@@ -2706,7 +2706,8 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
             // samples interleave to that rate; with two the chains wait on themselves)
             int hNS = 4;
             if (tn.hl_ns > 0) hNS = tn.hl_ns == 4 ? 4 : 2;
-            const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !tn.u_no_hot;
+            const bool hot = p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && !tn.u_no_hot &&
+                             p->u_p_lag <= 2;                          // (lag-3 maps: hot records without cache hits, include/ttm.h)
             const int hcw = TTM_HL_FWD_CW(logdet != nullptr);            // evaluating waves per workgroup of the hot kernel
             const int rows = hot ? hcw * 64 * hNS : TTM_UL_ROWS;
             auto lds_for = [&](int xl, int tl) { return ((size_t)(xl + 1) * rows + (size_t)(tl + 1) * tab_slot + (size_t)2 * ways * rows + TTM_EXPQ_TABLE_LEN) * 8; };
@@ -2892,8 +2893,8 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
     // large ensembles of maps with hot records: resident-table kernel (components in blocks, tables resident in LDS)
     if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
         h_y_affine && ldy == 0 && T <= 4096 && nb <= 65535 && N < ((int64_t)1 << 28) && !tuning().rt_off && !tuning().u_no_hot &&
-        ((N >= 64 * 1024 && k1 - k0 >= 4) || tuning().u_loader == 1)) {     // (small ensembles, fewer than four components: the
-                                                                            // table load per workgroup does not pay; option u_loader = 1 forces it)
+        (N >= 64 * 1024 || tuning().u_loader == 1)) {                       // (small ensembles: the table load per workgroup does not pay;
+                                                                            // option u_loader = 1 forces it)
         const DeviceInfo& di = device_info();
         const Tuning& tn = tuning();
         // banded maps: push-form kernel (csrc/ttm_band.hip); clipped searches only (exp(-x^2/4) from the located interval)
@@ -2903,6 +2904,9 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                                   tn.band_cus > 0 ? tn.band_cus : di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
                 return check_launch(name);
         }
+      // k_inverse_rt sweeps the hot records themselves: not for lag-3 maps (include/ttm.h), and with fewer than four
+      // components its table load per workgroup does not pay
+      if (p->u_p_lag <= 2 && (k1 - k0 >= 4 || tn.u_loader == 1)) {
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
         int NS = tn.rt_ns == 4 ? 4 : 2;
@@ -2995,6 +2999,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                                h_y_affine[1], h_y_affine[2], tmin, tmax, bkt, (int)nb, (int)truncate, tab_slot, Bc, ways, rows, w0, W);
             return check_launch(band ? "k_inverse_rt<band>" : "k_inverse_rt");
         }
+      }
     }
     const int bd = 256;
     int NS = N >= 4 * 256 * 256 ? 2 : 1;       // two samples per thread for large ensembles (scalar work halves)

@@ -655,7 +655,7 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
 H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24)
 H_DB, H_DA = (0, 3, 5, 7), (0, 1, 5, 7)
-P_HDR, P_LAG_MAX = 8, 2
+P_HDR, P_LAG_MAX, P_FEW_D = 8, 3, 4
 UCF_OWN, UGF_POLY = 1, 1 << 20
 U_KAPPA = 0.75                # spline interval width / smallest special-term scale (degree 11: fit error < 1e-14;
                               # 0.5: 3e-15, 0.9: 5e-14 - wider intervals = smaller tables to stream per sweep step)
@@ -718,16 +718,22 @@ def _compile_uform(cm, u_info, polyclass, separable):
             if fl & UGF_POLY:
                 ma = max(ma, (fl >> 24) & 15)
     ng = int(max(ucomp[:, 2], default=0))
-    if all_hit and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
+    # banded map (include/ttm.h "push records"): consecutive columns, every group reads one of the P_LAG_MAX columns in
+    # front of its component, a spline in every component -> csrc/ttm_band.hip.  Records for lag 2 (what the kernels of
+    # large maps are instantiated for) unless a group reaches three columns back, which only the kernels of maps with a
+    # few components (P_FEW_D) take.
+    kc0 = int(ucomp[0, 0]) if cm.D else 0
+    lags = [int(ucomp[k, 0]) - int(ugrp[int(ucomp[k, 3]) + g, 0]) for k in range(cm.D) for g in range(int(ucomp[k, 2]))]
+    maxlag = max(lags, default=1)
+    banded = cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(lag >= 1 for lag in lags) and \
+        (maxlag <= 2 or (maxlag <= P_LAG_MAX and cm.D <= P_FEW_D)) and all(len(u['st_p0']) > 0 for u in u_info)
+    # (a banded map whose groups do not all hit the planned column cache still gets hot records: as the source of its push
+    # records only, u_p_lag = 3 says so)
+    if (all_hit or (banded and maxlag == 3)) and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
         cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
         cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
-        # banded map (include/ttm.h "push records"): consecutive columns, every group reads one of the P_LAG_MAX columns
-        # in front of its component, a spline in every component -> csrc/ttm_band.hip
-        kc0 = int(ucomp[0, 0]) if cm.D else 0
-        lags = [int(ucomp[k, 0]) - int(ugrp[int(ucomp[k, 3]) + g, 0]) for k in range(cm.D) for g in range(int(ucomp[k, 2]))]
-        if cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(1 <= lag <= P_LAG_MAX for lag in lags) and \
-                all(len(u['st_p0']) > 0 for u in u_info):
-            cm.u_p_lag = P_LAG_MAX
+        if banded:
+            cm.u_p_lag = 3 if maxlag == 3 else 2
             gp = H_DB[cm.u_h_cls] + 1 + H_DA[cm.u_h_cls]
             cm.u_p_stride = -(-(P_HDR + cm.u_p_lag * gp) // 8) * 8        # whole 64-byte lines
     uform_geometry(cm)
