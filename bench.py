@@ -185,6 +185,46 @@ def counted_fp64(workload, N, forward_ms, inverse_ms, newton_ms=None):
     return out
 
 
+def _last_kernel(tm):
+    """name of the kernel the library's most recent launching entry point dispatched (include/ttm.h: ttm_last_kernel)"""
+    import ctypes
+    tm._lib.ttm_last_kernel.restype = ctypes.c_char_p
+    return tm._lib.ttm_last_kernel().decode()
+
+
+def graph_ms(torch, fn, launches=20, reps=10):
+    """ms per call of `fn` (a function that only launches kernels on the current stream), its launches replayed from a
+    captured HIP graph: the launches of the small configurations are shorter than the Python call that makes them (a
+    12 us call around a 9 us kernel), so a Python loop between two events times the host.  None when capture fails."""
+    try:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(launches):
+                    fn()
+        torch.cuda.synchronize()
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / (launches * reps)
+    except Exception:                                   # noqa: BLE001
+        torch.cuda.synchronize()
+        return None
+
+
 def other_configs(torch, names, steps=40):
     """The other single-GPU configurations of BASELINE.json (secondary numbers of the same JSON line): per workload
     forward / inverse launch times with HIP events (back to back behind a short untimed run), map-evals/s of forward +
@@ -200,6 +240,10 @@ def other_configs(torch, names, steps=40):
         def step():
             tm.forward_device(Xs, N, coef=coef, Z=Z)
             tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        tm.forward_device(Xs, N, coef=coef, Z=Z)
+        fwd_kernel = _last_kernel(tm)
+        tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        inv_kernel = _last_kernel(tm)
         n_warm = 200 if separable else 5            # (a bisection inverse of 1e6 samples is ~17 ms)
         n = steps if separable else max(3, steps // 8)
         for _ in range(n_warm):
@@ -215,6 +259,7 @@ def other_configs(torch, names, steps=40):
             a.record(); tm.forward_device(Xs, N, coef=coef, Z=Z); b.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); c.record()
         torch.cuda.synchronize()
         r = dict(workload=WORKLOADS[name][3], N=N, D=D, steps=n, ms_per_step=1e3 * el / n, value=N * D * n / el,
+                 forward_kernel=fwd_kernel, inverse_kernel=inv_kernel,
                  forward_ms=float(np.mean([a.elapsed_time(b) for a, b, c in ev])),
                  inverse_ms=float(np.mean([b.elapsed_time(c) for a, b, c in ev])),
                  inverse='table' if separable else 'bisection (reference sequence)',
@@ -222,6 +267,15 @@ def other_configs(torch, names, steps=40):
                  # (the max sits in the tails, where the reference's 1001-point table inverse clips / interpolates
                  # coarsely or the bisection window runs away; the median is the inverse's working accuracy)
                  roundtrip_median_abs_err=float((Xinv[:, :N] - Xs[:, :N]).abs().median().item()))
+        if separable:
+            # launches replayed from a graph (see graph_ms): the launch times themselves, and the step back to back
+            gf = graph_ms(torch, lambda: tm.forward_device(Xs, N, coef=coef, Z=Z))
+            gi = graph_ms(torch, lambda: tm.inverse_device(Z, N, coef=coef, X=Xinv))
+            gs = graph_ms(torch, step)
+            if gf is not None and gi is not None and gs is not None:
+                r.update(timing='HIP graph replay (20 launches per graph)', python_loop_ms_per_step=r['ms_per_step'],
+                         python_loop_forward_ms=r['forward_ms'], python_loop_inverse_ms=r['inverse_ms'],
+                         forward_ms=gf, inverse_ms=gi, ms_per_step=gs, value=N * D / (gs * 1e-3))
         r['forward_GBps_algorithmic'] = 8.0 * N * (d_used(tm) + D) / (r['forward_ms'] * 1e-3) / 1e9
         if separable:
             ld, ss = tm._empty(N), tm._empty(N)
@@ -233,6 +287,25 @@ def other_configs(torch, names, steps=40):
                 a.record(); tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss); b.record()
             torch.cuda.synchronize()
             r['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+            gp = graph_ms(torch, lambda: tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss))
+            gl = graph_ms(torch, lambda: tm.density_device(Xs, N, coef=coef, logdet=ld, sigma=sigma))
+            if gp is not None:
+                r['pullback_fused_ms'] = gp
+            # roofline of the configuration's launches on their algorithmic bytes: forward and
+            # inverse 8 N (d + D) each, the log-determinant-only pullback pass 8 N (d + 1)
+            fb, ib = 8.0 * N * (d_used(tm) + D), 8.0 * N * (d_used(tm) + D)
+            roof = {'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'copy_peak': COPY_PEAK_GBS,
+                    'forward': {'kernel': fwd_kernel, 'bytes': fb, 'achieved': fb / (r['forward_ms'] * 1e-3) / 1e9},
+                    'inverse': {'kernel': inv_kernel, 'bytes': ib, 'achieved': ib / (r['inverse_ms'] * 1e-3) / 1e9},
+                    'step': {'bytes': fb + ib, 'achieved': (fb + ib) / (r['ms_per_step'] * 1e-3) / 1e9}}
+            if gl is not None:
+                lb = 8.0 * N * (d_used(tm) + 1)
+                r['pullback_logdet_only_ms'] = gl
+                roof['pullback_logdet_only'] = {'kernel': _last_kernel(tm), 'bytes': lb, 'achieved': lb / (gl * 1e-3) / 1e9}
+            for v in roof.values():
+                if isinstance(v, dict):
+                    v['frac'] = v['achieved'] / HBM_PEAK_GBS
+            r['roofline'] = roof
         if not separable:
             # the same inversion with the engine's safeguarded Newton root search (root_finder='newton', an extension:
             # same roots to |S - z| <= 1e-9, not the reference's midpoint sequence)

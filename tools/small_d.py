@@ -68,9 +68,14 @@ for name in names:
             tm.forward_device(Xs, N, Z=Z)
             tm.inverse_device(Z, N, X=Xi)
         tp = timed(pair)
+        ld = torch.empty(N + 2, dtype=torch.float64, device='cuda')
+        sg = torch.ones(D, dtype=torch.float64, device='cuda')
+        tm.density_device(Xs, N, logdet=ld, sigma=sg)
+        kd = lib.ttm_last_kernel().decode()
+        td = timed(lambda: tm.density_device(Xs, N, logdet=ld, sigma=sg))
         a = torch.empty(D * N, dtype=torch.float64, device='cuda'); b = torch.empty_like(a)
         tc = timed(lambda: torch.abs(a, out=b))
         mb = 16.0 * N * D / 1e6
-        print('%s N=%8d  %5.1f MB | fwd %-16s %6.2f us %5.2f TB/s | inv %-16s %6.2f us %5.2f TB/s | pair %6.2f us %5.2f TB/s | elementwise %6.2f us %5.2f TB/s | host call %5.1f us' %
-              (name, N, mb, kf, tf, mb / tf, ki, ti, mb / ti, tp, 2 * mb / tp, tc, mb / tc, host), flush=True)
+        print('%s N=%8d  %5.1f MB | fwd %-16s %6.2f us %5.2f TB/s | inv %-16s %6.2f us %5.2f TB/s | pair %6.2f us %5.2f TB/s | logdet %s %6.2f us %5.2f TB/s | elementwise %6.2f us %5.2f TB/s | host call %5.1f us' %
+              (name, N, mb, kf, tf, mb / tf, ki, ti, mb / ti, tp, 2 * mb / tp, kd, td, 8e-6 * N * (Xs.shape[0] + 1) / td, tc, mb / tc, host), flush=True)
         del tm, a, b

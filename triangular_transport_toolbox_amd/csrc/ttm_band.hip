@@ -731,8 +731,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
             __syncthreads();
             staged = true;
         }
+        // (the density pass has no registers to spare for a second set of columns: its next tile is requested after this one)
         const bool more = tile + (int)gridDim.x < ntiles;
-        if (more) request(tile + gridDim.x, xfn, xinn);
+        if (more && !DENS) request(tile + gridDim.x, xfn, xinn);
         __builtin_amdgcn_sched_barrier(0);
 #if BAND_FEW_STAGE == 2 || BAND_FEW_STAGE == 3
         {
@@ -830,7 +831,8 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
                 }
             }
         }
-        if (more) {
+        if (more && DENS) request(tile + gridDim.x, xf, xin);
+        if (more && !DENS) {
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
 #pragma unroll
@@ -1628,14 +1630,14 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
             if (lage > p->u_p_lag) return 1;
             fkern_t fk = nullptr;
 #define BAND_FEW_C(L, E, PL, DN) (cls == 1 ? k_band_few<1, L, E, PL, DN> : cls == 2 ? k_band_few<2, L, E, PL, DN> : k_band_few<3, L, E, PL, DN>)
-#define BAND_FEW_E(L, E) (plain ? BAND_FEW_C(L, E, true, false) : BAND_FEW_C(L, E, false, false))
-            if (dens) {                                       // (the density pass: one variant per record layout)
-                if (p->u_p_lag == 3) fk = BAND_FEW_C(3, 3, true, true); else fk = BAND_FEW_C(2, 2, true, true);
-            } else if (p->u_p_lag == 3) {
+#define BAND_FEW_P(L, E, DN) (plain ? BAND_FEW_C(L, E, true, DN) : BAND_FEW_C(L, E, false, DN))
+#define BAND_FEW_E(L, E) (dens ? BAND_FEW_P(L, E, true) : BAND_FEW_P(L, E, false))
+            if (p->u_p_lag == 3) {
                 fk = lage == 1 ? BAND_FEW_E(3, 1) : lage == 2 ? BAND_FEW_E(3, 2) : BAND_FEW_E(3, 3);
             } else {
                 fk = lage == 1 ? BAND_FEW_E(2, 1) : BAND_FEW_E(2, 2);
             }
+#undef BAND_FEW_P
 #undef BAND_FEW_E
 #undef BAND_FEW_C
             const int64_t trows = BAND_FEW_NS * BAND_CT;

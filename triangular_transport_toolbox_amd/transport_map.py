@@ -244,7 +244,14 @@ class transport_map():
     def _stream(self):
         if self._dev.type != 'cuda':
             return None
-        return ctypes.c_void_p(_torch().cuda.current_stream().cuda_stream)
+        # (the raw handle of torch's current stream: torch.cuda.current_stream().cuda_stream builds a Stream object
+        # and resolves the device on every call - 3 us of a 12 us launch call)
+        torch = _torch()
+        idx = getattr(self, '_dev_index', None)
+        if idx is None:
+            idx = self._dev_index = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
+        getter = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        return ctypes.c_void_p(getter(idx) if getter is not None else torch.cuda.current_stream(idx).cuda_stream)
 
     @staticmethod
     def _ptr(t, offset=0):
@@ -734,6 +741,14 @@ class transport_map():
                                           self._ptr(Z), Z.shape[1], self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq),
                                           self._stream()))
         return Z
+
+    def density_device(self, Xs, N, coef=None, logdet=None, sigma=None, sumsq=None):
+        """The density pass WITHOUT the map values: sum_k log(dS_k/dx_k / sigma_k) and / or sum_k S_k^2 per sample of a
+        standardised column-major device matrix (what evaluate_pullback_density needs, TM:2646-2712: 8 N (d + 1) bytes)."""
+        coef = self._current(coef)
+        _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N, 0, self.D,
+                                          None, N, self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq), self._stream()))
+        return logdet, sumsq
 
     def inverse_device(self, Zs, N, coef=None, X=None, table=None):
         """S^{-1}(z) for a column-major device matrix Zs (D x N) -> standardised X (d x N);
