@@ -346,7 +346,7 @@ def other_configs(torch, names, steps=40):
     return out
 
 
-def entf_config(torch, N=100000, cycles=200):
+def entf_config(torch, N=100000, cycles=2000):
     """BASELINE configs[3] (C4): Lorenz-63 Ensemble Transport Filter, Example-06 map (4 columns, D = 3), N = 1e5:
     `cycles` assimilation cycles timed end to end, each = three one-observation updates
     (reset -> optimize -> map -> inverse_map with the observation as X_star) + the RK4 forecast."""
