@@ -56,7 +56,7 @@ sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
 rank = int(os.environ['RANK'])
 dist.init_process_group('gloo', rank=rank, world_size=2)
-torch.cuda.set_device(0)
+torch.cuda.set_device(rank if os.environ.get('TTM_TEST_ONE_GPU_PER_RANK') else 0)
 from triangular_transport_toolbox_amd import _capi, comm
 lib = _capi.load()
 with warnings.catch_warnings(record=True) as w:
@@ -79,7 +79,7 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
+def _run_two_ranks(tmp_path, extra_env):
     import socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -90,7 +90,7 @@ def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     try:
@@ -108,6 +108,11 @@ def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
         line = [ln for ln in o.splitlines() if ln.startswith('RESULT ')]
         assert line, o[-2000:]
         res.append(json.loads(line[0][7:]))
+    return res
+
+
+def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
+    res = _run_two_ranks(tmp_path, {})
     print('communicator created:', res[0]['handle'], '|', res[0]['warned'])
     assert res[0]['handle'] == res[1]['handle']                # the ranks agree
     assert res[0]['after'] == res[1]['after'] == 3.0            # and are still in step afterwards
@@ -115,3 +120,15 @@ def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
         assert res[0]['sum'] == res[1]['sum'] == [0] + [3.0] * 5
     else:
         assert all('communicator not available' in ' '.join(r['warned']) for r in res)
+
+
+def test_two_ranks_on_two_gpus_reduce_over_rccl(tmp_path):
+    """The real thing, on a box with at least two devices (skipped on the one-GPU boxes): one rank per GPU, the RCCL
+    communicator of csrc/ttm_comm.cpp created through comm.get(), an in-place sum of a device vector over xGMI."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    res = _run_two_ranks(tmp_path, {'TTM_TEST_ONE_GPU_PER_RANK': '1'})
+    assert res[0]['handle'] and res[1]['handle'], res
+    assert res[0]['sum'] == res[1]['sum'] == [0] + [3.0] * 5
+    assert res[0]['after'] == res[1]['after'] == 3.0

@@ -100,10 +100,16 @@ def test_c3_full_size_map_inverse_pullback_optimize():
     tm, om, X = build('C3', 'c3_sep', N)
     idx = subset_with_tails(X)
     Z = tm.map(X)
-    record_parity('c3_full/map_vs_oracle', relerr(Z[idx], om.map(X[idx])), 1e-11)
+    tm.forward_device(tm._Xs, tm._N)
+    assert _last_kernel(tm) == 'k_band_few'                  # (a group three columns back: lag-3 push records)
+    record_parity('c3_full/map(k_band_few)_vs_oracle', relerr(Z[idx], om.map(X[idx])), 1e-11)
     assert relerr(Z[idx], om.map(X[idx])) < 1e-11
     Xi = tm.inverse_map(Z)
-    record_parity('c3_full/table_inverse_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
+    tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
+    assert _last_kernel(tm) == 'k_band_few_inverse'
+    tm.density_device(tm._Xs, tm._N, logdet=tm._empty(tm._N))
+    assert _last_kernel(tm) == 'k_band_few<density>'
+    record_parity('c3_full/table_inverse(k_band_few_inverse)_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
     assert relerr(Xi[idx], om.inverse_map(Z[idx])) < 1e-11
     pd, pdo = tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])
     record_parity('c3_full/pullback_density_vs_oracle', relerr(pd, pdo), 1e-10)
@@ -139,9 +145,14 @@ def test_c2b_full_size_forward_inverse_pullback():
     tm, om, X = build('C2b', 'c2b_sep', N)
     idx = subset_with_tails(X)
     Z = tm.map(X)
+    tm.forward_device(tm._Xs, tm._N)
+    assert _last_kernel(tm) == 'k_band_few'
+    record_parity('c2b_full/map(k_band_few)_vs_oracle', relerr(Z[idx], om.map(X[idx])), 1e-11)
     assert relerr(Z[idx], om.map(X[idx])) < 1e-11
     Xi = tm.inverse_map(Z)
-    record_parity('c2b_full/table_inverse_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
+    tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
+    assert _last_kernel(tm) == 'k_band_few_inverse'
+    record_parity('c2b_full/table_inverse(k_band_few_inverse)_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
     assert relerr(Xi[idx], om.inverse_map(Z[idx])) < 1e-11
     pd, pdo = tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])
     record_parity('c2b_full/pullback_density_vs_oracle', relerr(pd, pdo), 1e-10)
