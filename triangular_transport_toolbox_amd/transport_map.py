@@ -1110,7 +1110,9 @@ class transport_map():
         """(Gnn + ridge I)^-1 Gnm by Cholesky on the diagonally equilibrated matrix with one step of iterative
         refinement; None when the equilibrated matrix is too ill-conditioned for the normal equations (ridge == 0
         only: a ridge bounds the condition number by itself)."""
-        import scipy.linalg
+        # (LAPACK's dpotrf / dpotrs called directly - what scipy.linalg.cho_factor / cho_solve call, without their argument
+        # checks: 15 instead of 42 us per solve, six solves per update of the filter)
+        potrf, potrs = cls._lapack_chol()
         M = Gnn + ridge * np.identity(Gnn.shape[0])
         d = np.sqrt(np.diag(M))
         if not np.all(d > 0) or not np.all(np.isfinite(d)):
@@ -1120,14 +1122,25 @@ class transport_map():
             w = np.linalg.eigvalsh(Ms)
             if not (w[0] > 0) or w[-1] / w[0] > cls.GRAM_COND_MAX:
                 return None
-        try:
-            cf = scipy.linalg.cho_factor(Ms)
-        except np.linalg.LinAlgError:
+        if not np.all(np.isfinite(Ms)) or not np.all(np.isfinite(Gnm)):
+            raise ValueError('array must not contain infs or NaNs')
+        cf, info = potrf(Ms, lower=False, overwrite_a=False, clean=False)
+        if info != 0:
             return None if ridge == 0.0 else np.linalg.solve(M, Gnm)
         rhs = Gnm / d[:, None]
-        y = scipy.linalg.cho_solve(cf, rhs)
-        y += scipy.linalg.cho_solve(cf, rhs - Ms @ y)                 # one refinement step
+        y, _ = potrs(cf, rhs, lower=False, overwrite_b=False)
+        dy, _ = potrs(cf, rhs - Ms @ y, lower=False, overwrite_b=False)
+        y += dy                                                       # one refinement step
         return y / d[:, None]
+
+    _LAPACK_CHOL = None
+
+    @classmethod
+    def _lapack_chol(cls):
+        if cls._LAPACK_CHOL is None:
+            import scipy.linalg.lapack as lapack
+            transport_map._LAPACK_CHOL = (lapack.dpotrf, lapack.dpotrs)
+        return cls._LAPACK_CHOL
 
     def _separable_setup_qr(self, k):
         """The reduced problem exactly as the reference forms it (TM:2966-2975, 3152-3157): Householder QR of Psi_nonmon
