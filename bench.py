@@ -628,6 +628,20 @@ def main():
         tm.forward_device(Xs, N, coef=c, Z=Z)
         tm.inverse_device(Z, N, coef=c, X=Xinv)
 
+    unc_prev = [None]
+
+    def step_uncached_deferred():
+        # the same with `deferred_checks`: the two per-vector checks (spline fit errors, table sortedness) are read ONE STEP
+        # LATER from pinned copies made in stream order (transport_map.validate) instead of behind a synchronisation in
+        # front of the lookups; a failed check would mean computing that step again (it never fails for this map)
+        tm._pack_memo = None
+        c = tm._pack_coeffs()
+        tm.forward_device(Xs, N, coef=c, Z=Z)
+        tm.inverse_device(Z, N, coef=c, X=Xinv)
+        if unc_prev[0] is not None and not tm.validate(unc_prev[0]):
+            raise RuntimeError('deferred check failed')
+        unc_prev[0] = c
+
     def sync():
         if dist is not None:
             dist.barrier()
@@ -692,6 +706,12 @@ def main():
     for _ in range(3):
         step_uncached()
     uncached = timed(step_uncached, n_unc)
+    tm.deferred_checks = True
+    for _ in range(3):
+        step_uncached_deferred()
+    uncached_deferred = timed(step_uncached_deferred, n_unc)
+    tm.validate(unc_prev[0])
+    tm.deferred_checks = False
     if dist is not None:
         t = torch.tensor([elapsed, cold, uncached], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -821,6 +841,9 @@ def main():
             # coefficient vector and is NOT inside `value`; a step that redoes it every time:
             'uncached_ms_per_step': 1e3 * uncached / n_unc,
             'setup_us': 1e3 * (1e3 * uncached / n_unc - ms_step),
+            # ... with the per-vector checks read one step later (transport_map.deferred_checks / validate())
+            'uncached_deferred_checks_ms_per_step': 1e3 * uncached_deferred / n_unc,
+            'setup_deferred_checks_us': 1e3 * (1e3 * uncached_deferred / n_unc - ms_step),
             'cached': 'folded coefficients, U-form section and inverse tables are functions of the coefficient vector '
                       'and are built once before the timed region; uncached_ms_per_step rebuilds them every step '
                       '(the reference rebuilds its table in every inverse_map, TM:4047-4058)',

@@ -173,3 +173,52 @@ def test_band_kernels_on_rows_outside_their_resident_paths(ttm_opt):
     keep = np.ones(len(X), bool); keep[8] = False
     assert relerr(Xi[keep], Xo[keep]) < 1e-11
     assert np.all(np.isnan(Xi[8]))
+
+
+@pytest.mark.gpu
+def test_deferred_checks_give_the_same_results_and_catch_what_the_eager_checks_catch(ttm_opt, monkeypatch):
+    """`deferred_checks`: no host visit behind a new coefficient vector; validate() reads the flags later.  Same bits as
+    the eager path when the checks hold; when they do not (a table that is not sorted; a spline outside the
+    tolerance) validate() says so and repairs the state."""
+    import torch
+    from triangular_transport_toolbox_amd import termtable
+    tm, om, X, rng = _build('c5_shape', n=3001)
+    N = tm._N
+    Zin = rng.standard_normal((N, tm.D))
+    Z0 = tm.forward_device(tm._Xs, N).clone()
+    Zd = tm._cols(tm.D, N)
+    Zd[:, :N] = tm._to_dev(np.ascontiguousarray(Zin.T))
+    X0 = tm.inverse_device(Zd, N).clone()
+    tm.deferred_checks = True
+    tm._pack_memo = None                                      # a new coefficient vector
+    coef = tm._pack_coeffs()
+    assert getattr(coef, '_ttm_pending', None) is not None
+    Z1 = tm.forward_device(tm._Xs, N, coef=coef).clone()
+    X1 = tm.inverse_device(Zd, N, coef=coef).clone()
+    assert tm.validate(coef) and tm.validate(coef)            # (a second call has nothing left to read)
+    assert np.array_equal(Z1[:, :N].cpu().numpy(), Z0[:, :N].cpu().numpy())
+    assert np.array_equal(X1[:, :N].cpu().numpy(), X0[:, :N].cpu().numpy())
+    # a table reported as not sorted: validate() says so, later inversions take the sorted lookup of the eager path
+    tm._pack_memo = None
+    coef = tm._pack_coeffs()
+    torch.cuda.synchronize()
+    coef._ttm_pending[3][1] = 1                               # (the pinned copy of the flags: table 1 "not sorted")
+    assert tm.validate(coef) is False
+    assert [e[4] for e in coef._ttm_tables.values()] == [False]
+    X2 = tm.inverse_device(Zd, N, coef=coef)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    assert lib.ttm_last_kernel().decode() == 'k_inverse_table'
+    assert relerr(X2[:, :N].cpu().numpy(), X0[:, :N].cpu().numpy()) < 1e-13
+    # a spline outside the tolerance: found at validate(), U-form switched off, the vector folded again
+    tm, om, X, rng = _build('c5_shape', n=3001)
+    N = tm._N
+    Zref = om.map(X)
+    tm.deferred_checks = True
+    monkeypatch.setattr(termtable, 'U_TOL_VALUE', 0.0)
+    tm._pack_memo = None
+    coef = tm._pack_coeffs()
+    tm.forward_device(tm._Xs, N, coef=coef)
+    assert tm.validate(coef) is False and not tm._cm.u_enabled
+    Z = tm.forward_device(tm._Xs, N, coef=coef)
+    assert relerr(Z[:, :N].cpu().numpy().T, Zref) < 1e-11

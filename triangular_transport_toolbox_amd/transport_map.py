@@ -312,7 +312,7 @@ class transport_map():
         self._u_checked = None
         self._epoch = getattr(self, '_epoch', 0) + 1      # new spline geometry: folds / tables kept with a vector are stale
 
-    def _check_uform(self, fold):
+    def _check_uform(self, fold, err=None):
         """The special-term splines are verified when they are built (fit error against the direct evaluation,
         csrc/ttm_uform.h).  The errors are read back with every packed coefficient vector (2 D doubles); a spline
         outside the tolerance disables the U-form for this map until the next special-term placement (the direct
@@ -320,8 +320,10 @@ class transport_map():
         cm = self._cm
         if not cm.u_enabled:
             return True
-        off = int(self._lib.ttm_uform_offset(self._pp)) + int(cm.u_err_off)
-        err = fold[off:off + 2 * cm.D].cpu().numpy().reshape(cm.D, 2)
+        if err is None:
+            off = int(self._lib.ttm_uform_offset(self._pp)) + int(cm.u_err_off)
+            err = fold[off:off + 2 * cm.D].cpu().numpy()
+        err = np.array(err, dtype=float).reshape(cm.D, 2)
         self.uform_fit_error = err
         ok = bool(np.all(err[:, 0] <= termtable.U_TOL_VALUE) and np.all(err[:, 1] <= termtable.U_TOL_DERIV))
         self._u_checked = ok
@@ -644,6 +646,26 @@ class transport_map():
         # a new coefficient vector: the fit errors of the splines and the sortedness flags of the tables then come back
         # behind a single synchronisation (two before: here and in the first inverse_map)
         pending = self._launch_default_tables(coef) if self._eager_tables() else None
+        if getattr(self, 'deferred_checks', False) and self._dev.type == 'cuda':
+            # no host visit now (`deferred_checks`, validate()): the kernels behind this vector run on the assumption that
+            # the splines fit and the tables are sorted - what the checks find for every map seen so far - and the flags
+            # are read at the caller's next synchronisation point
+            torch = _torch()
+            errs = flags = None
+            if self._cm.u_enabled:                          # (copies into pinned memory, in stream order behind the kernels)
+                off = int(self._lib.ttm_uform_offset(self._pp)) + int(self._cm.u_err_off)
+                errs = torch.empty(2 * self._cm.D, dtype=torch.float64, pin_memory=True)
+                errs.copy_(fold[off:off + 2 * self._cm.D], non_blocking=True)
+            if pending is not None:
+                tkey, entry = pending
+                coef._ttm_tables[tkey] = entry[:4] + (True,)
+                flags = torch.empty(entry[4].numel(), dtype=torch.int32, pin_memory=True)
+                flags.copy_(entry[4], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            coef._ttm_pending = (fold, pending, errs, flags, done)
+            coef._ttm_epoch = self._epoch
+            return coef
         if not self._check_uform(fold):
             fold = self._zeros(int(self._lib.ttm_fold_size(self._pp)))
             _capi.check(self._lib.ttm_fold(self._pp, self._ptr(coef), self._ptr(fold), self._stream()))
@@ -655,6 +677,35 @@ class transport_map():
             coef._ttm_tables[tkey] = entry[:4] + (int(entry[4].cpu().max().item()) == 0,)
         coef._ttm_epoch = self._epoch
         return coef
+
+    def validate(self, coef=None):
+        """With `deferred_checks = True` the device entry points (forward_device, inverse_device, density_device) do not
+        wait for the two checks every new coefficient vector gets - fit errors of the special-term splines, sortedness of
+        the default inverse tables - before they launch.  validate() reads them (ONE synchronisation, at a point of the
+        caller's choosing: it must come before results computed with this vector are used) and returns True when
+        both held.  False: the state is repaired (U-form off and the vector folded again / the tables marked unsorted)
+        and everything computed with `coef` since it was packed has to be computed again."""
+        coef = self._pack_memo[2] if coef is None and getattr(self, '_pack_memo', None) is not None else coef
+        pend = getattr(coef, '_ttm_pending', None) if coef is not None else None
+        if pend is None:
+            return True
+        fold, pending, errs, flags, done = pend
+        coef._ttm_pending = None
+        done.synchronize()                                   # (the copies behind the fold / index kernels, not the stream)
+        ok = True
+        if pending is not None:
+            tkey, entry = pending
+            if int(flags.numpy().max()) != 0:
+                coef._ttm_tables[tkey] = entry[:4] + (False,)
+                ok = False
+        if coef._ttm_epoch == self._epoch and errs is not None and not self._check_uform(fold, errs.numpy()):
+            saved, self.deferred_checks = self.deferred_checks, False
+            try:
+                self._fold(coef)
+            finally:
+                self.deferred_checks = saved
+            ok = False
+        return ok
 
     def _eager_tables(self):
         return (self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity' and self._cm.u_enabled and
@@ -1449,6 +1500,10 @@ class transport_map():
     # separable components are minimised by the library's own L-BFGS-B loop (ttm_optimize_separable: no Python per
     # evaluation); False = scipy.optimize's loop driven from Python with the same device reductions
     native_optimizer = True
+
+    # device entry points: read the per-vector checks (spline fit errors, table sortedness) at validate() instead of
+    # behind every new coefficient vector (see validate())
+    deferred_checks = False
 
     def _optimize_separable_native(self, A, k, x0, bounds):
         """TM:3108-3114 for one component without leaving the library; None when the native loop does not apply
