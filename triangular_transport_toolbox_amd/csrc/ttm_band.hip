@@ -651,7 +651,8 @@ template <int CLS, int LAG, int LAGE, bool PLAIN, bool DENS>
 __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
                                                       const double* __restrict__ X, int64_t ldx, int64_t N,
                                                       double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
-                                                      const double* __restrict__ sigma, double* __restrict__ sumsq, int ntiles) {
+                                                      const double* __restrict__ sigma, double* __restrict__ sumsq, int ntiles,
+                                                      int tab0, int ntab) {
     constexpr int DB = cls_db(CLS), DA = cls_da(CLS), GP = cls_gp(CLS), PS = rec_stride(CLS, LAG);
     // two rows (one 16-byte pair) per thread and tile: with tiles of 2048 rows even half a million rows reach every CU;
     // the columns of a workgroup's next tile are requested before the current one is evaluated
@@ -669,13 +670,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
     const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
     const unsigned int N32 = (unsigned int)N;
     const int64_t ldxb = ldx * 8, ldzb = ldz * 8;
-    // tables: requested now, written to LDS after the first tile's columns have been requested
-    int tab0, ntab;
-    {
-        cint_p rb = (cint_p)(P + (int64_t)(k0 + LAG) * PS), re = (cint_p)(P + (int64_t)(k1 - 1 + LAG) * PS);
-        tab0 = rb[11];
-        ntab = re[11] + TTM_U_TSTRIDE * re[10] - tab0;                        // doubles (even, <= BAND_FEW_TAB: the host checks)
-    }
+    // tables (tab0: offset of the first spline in the U section, ntab doubles - even, <= BAND_FEW_TAB: from the host, which
+    // knows them, so the request does not wait for a record): requested now, written to LDS after the first tile's columns
+    // have been requested
     const D2 ev = *(const D2*)(g_band_etab + 2 * min(tid, TTM_BAND_ET_N - 1));
     D2 sv[2];
 #pragma unroll
@@ -1618,12 +1615,13 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     // a few components: everything requested at once, tiles of 2048 rows (k_band_few)
     static const int few_on = [] { const char* e = getenv("TTM_BAND_FEW"); return e ? atoi(e) : 1; }();
     if (k1 - k0 <= TTM_P_FEW_D && few_on) {
-        size_t tabd = 0;
-        for (int k = k0; k < k1; ++k) tabd += (size_t)p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] * TTM_U_TSTRIDE;
-        const size_t flds = (size_t)BAND_ET_DOUBLES * 8 + (tabd + 2) * 8;
-        if (tabd + 2 <= BAND_FEW_TAB && flds <= lds_per_cu && (!sigma || logdet)) {
+        // the splines of the sweep as they stand in the U section (padding between them included)
+        const int tab0 = p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_TAB_OFF];
+        const int ntab = p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_TAB_OFF] + TTM_U_TSTRIDE * p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_NI] - tab0;
+        const size_t flds = (size_t)BAND_ET_DOUBLES * 8 + ((size_t)(ntab > 0 ? ntab : 0) + 2) * 8;
+        if (ntab >= 2 && ntab % 2 == 0 && tab0 % 2 == 0 && ntab <= BAND_FEW_TAB && flds <= lds_per_cu && (!sigma || logdet)) {
             typedef void (*fkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
-                                    double*, int);
+                                    double*, int, int, int);
             const bool dens = logdet || sumsq;
             int lage; bool plain;
             sweep_shape(p, k0, k1, &lage, &plain);
@@ -1645,7 +1643,7 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
             const int64_t grid = ntiles < cus ? ntiles : cus;
             allow_lds((const void*)fk, flds);
             hipLaunchKernelGGL(fk, dim3((unsigned)grid), dim3(BAND_CT), flds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
-                               (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, (int)ntiles);
+                               (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, (int)ntiles, tab0, ntab);
             if (kernel_name) *kernel_name = dens ? "k_band_few<density>" : "k_band_few";
             return 0;
         }
