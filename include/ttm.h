@@ -560,6 +560,11 @@ typedef struct ttm_sep_task {
     const int32_t* kinds;        /* device, m */
     const double* pars;          /* device, 5 m */
 } ttm_sep_task;
+/* ttm_separable_reduce_l2 (host arithmetic only): the reduced separable problem with L2 regularisation (TM:3021-3050,
+ * 3148-3169) from the (n + m) x (n + m) Gram matrix G of [Psi_nonmon | Psi_mon] (row-major, host): A (m x m) and sol (n x m,
+ * c_nonmon = -sol c_mon), by Cholesky on the diagonally equilibrated normal equations with one refinement step.
+ * TTM_E_UNSUPPORTED when a matrix is not positive definite (the caller then solves it its own way).                  */
+int ttm_separable_reduce_l2(const double* G, int32_t n, int32_t m, double lam, double* A, double* sol);
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta,
                                  int32_t nthreads, void* stream, int32_t maxiter);
 int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, int32_t maxiter, double* result);

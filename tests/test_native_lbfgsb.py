@@ -105,3 +105,33 @@ def test_unconstrained_rosenbrock_and_limits():
     assert np.max(np.abs(x - ref.x)) < 1e-4 and abs(info['nit'] - ref.nit) <= 3
     x, info, _ = native_minimize(emu.lib(), lambda v: (rosen(v), rosen_der(v)), x0, np.full(4, -np.inf), np.full(4, np.inf), maxiter=3)
     assert info['status'] == 2 and info['nit'] == 3
+
+
+def test_native_l2_reduction_equals_the_numpy_path():
+    """ttm_separable_reduce_l2 (csrc/ttm_optim.cpp) against transport_map.separable_setup's NumPy / LAPACK arithmetic on
+    random Gram matrices: A and the nonmonotone solve agree to rounding; a Gram matrix that is not positive definite is
+    handed back."""
+    import ctypes
+    from tests.hostemu import emu
+    from triangular_transport_toolbox_amd.transport_map import transport_map as T
+    rng = np.random.default_rng(3)
+    lib = emu.lib()
+    if True:
+        for n, m, lam in ((5, 4, 0.05), (9, 1, 0.05), (13, 5, 1e-3), (1, 1, 0.5), (40, 8, 0.05)):
+            B = rng.standard_normal((300, n + m)) * (1 + 10 * rng.random(n + m))
+            G = B.T @ B
+            Gnn, Gnm, Gmm = G[:n, :n], G[:n, n:], G[n:, n:]
+            Gm = T._normal_solve(Gnn, Gnm, lam)
+            dd = Gmm - Gnm.T @ Gm - Gm.T @ Gnm + Gm.T @ Gnn @ Gm
+            A0 = dd / 2 + lam * (Gm.T @ Gm + np.identity(m))
+            A0 = (A0 + A0.T) / 2
+            S0 = T._normal_solve(Gnn, Gnm, 2 * lam)
+            A, S = np.empty((m, m)), np.empty((n, m))
+            Gc = np.ascontiguousarray(G)
+            assert lib.ttm_separable_reduce_l2(ctypes.c_void_p(Gc.ctypes.data), n, m, lam, ctypes.c_void_p(A.ctypes.data),
+                                               ctypes.c_void_p(S.ctypes.data)) == 0
+            assert np.max(np.abs(A - A0)) <= 1e-12 * np.max(np.abs(A0)) and np.array_equal(A, A.T)
+            assert np.max(np.abs(S - S0)) <= 1e-12 * max(1.0, np.max(np.abs(S0)))
+        G = -np.identity(3)
+        A, S = np.empty((1, 1)), np.empty((2, 1))
+        assert lib.ttm_separable_reduce_l2(ctypes.c_void_p(G.ctypes.data), 2, 1, 0.05, ctypes.c_void_p(A.ctypes.data), ctypes.c_void_p(S.ctypes.data)) != 0

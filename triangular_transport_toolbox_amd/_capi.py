@@ -91,6 +91,7 @@ _SIGNATURES = {
     'ttm_optimize_separable': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp,
                                               c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_optimize_separable_batch': (ctypes.c_int, [ctypes.POINTER(ttm_sep_task), c_i32, c_i64, c_dbl, c_dbl, c_i32, c_vp, c_i32]),
+    'ttm_separable_reduce_l2': (ctypes.c_int, [c_vp, c_i32, c_i32, c_dbl, c_vp, c_vp]),
     'ttm_optimize_integrated_batch': (ctypes.c_int, [ctypes.POINTER(ttm_program), ctypes.POINTER(ttm_int_task), c_i32, c_vp, c_i64, c_i64,
                                                      c_dbl, c_i32, c_vp, c_i32]),
     'ttm_bfgs_minimize': (ctypes.c_int, [c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),

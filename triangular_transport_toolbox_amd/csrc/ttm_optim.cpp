@@ -287,6 +287,101 @@ int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N,
     });
 }
 
+// (Gnn + ridge I)^-1 Gnm by Cholesky on the diagonally equilibrated matrix with one step of iterative refinement - the host
+// class's _normal_solve, ridge > 0.  G: the (n + m) x (n + m) Gram matrix, row-major; y: n x m.  false: not positive
+// definite / not finite (the caller decides what then).
+static bool sep_normal_solve(const double* G, int n, int m, double ridge, std::vector<double>& y) {
+    const int ld = n + m;
+    std::vector<double> d(n), Ms((size_t)n * n), U((size_t)n * n, 0.0), rhs((size_t)n * m), r((size_t)n * m);
+    for (int i = 0; i < n; ++i) {
+        d[i] = sqrt(G[i * ld + i] + ridge);
+        if (!(d[i] > 0.0) || !(d[i] < INFINITY)) return false;
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            Ms[i * n + j] = ((G[i * ld + j] + (i == j ? ridge : 0.0)) / d[i]) / d[j];
+            if (!(fabs(Ms[i * n + j]) < INFINITY)) return false;
+        }
+    for (int j = 0; j < n; ++j) {                       // Ms = U'U, U upper triangular
+        double s = Ms[j * n + j];
+        for (int k = 0; k < j; ++k) s -= U[k * n + j] * U[k * n + j];
+        if (!(s > 0.0)) return false;
+        const double ujj = sqrt(s);
+        U[j * n + j] = ujj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = Ms[j * n + i];
+            for (int k = 0; k < j; ++k) t -= U[k * n + j] * U[k * n + i];
+            U[j * n + i] = t / ujj;
+        }
+    }
+    auto solve = [&](std::vector<double>& b) {          // U'U x = b, column by column, in place
+        for (int c = 0; c < m; ++c) {
+            for (int i = 0; i < n; ++i) {
+                double t = b[i * m + c];
+                for (int k = 0; k < i; ++k) t -= U[k * n + i] * b[k * m + c];
+                b[i * m + c] = t / U[i * n + i];
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                double t = b[i * m + c];
+                for (int k = i + 1; k < n; ++k) t -= U[i * n + k] * b[k * m + c];
+                b[i * m + c] = t / U[i * n + i];
+            }
+        }
+    };
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < m; ++c) {
+            rhs[i * m + c] = G[i * ld + n + c] / d[i];
+            if (!(fabs(rhs[i * m + c]) < INFINITY)) return false;
+        }
+    y = rhs;
+    solve(y);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < m; ++c) {
+            double t = rhs[i * m + c];
+            for (int k = 0; k < n; ++k) t -= Ms[i * n + k] * y[k * m + c];
+            r[i * m + c] = t;
+        }
+    solve(r);
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < m; ++c) y[i * m + c] = (y[i * m + c] + r[i * m + c]) / d[i];
+    return true;
+}
+
+// The reduced separable problem with L2 regularisation (TM:3021-3050, 3148-3169) from the Gram matrix of
+// [Psi_nonmon | Psi_mon]: A (m x m) of the monotone coefficients' objective and the map c_mon -> c_nonmon = -sol c_mon
+// (sol: n x m).  What transport_map.separable_setup computes with NumPy, for the optimiser batches of the filter and smoother
+// updates (six small solves per update: 0.2 ms of Python).  TTM_E_UNSUPPORTED: a matrix is not positive definite - the
+// caller's own dense solve takes over.
+int ttm_separable_reduce_l2(const double* G, int32_t n, int32_t m, double lam, double* A, double* sol) {
+    if (!G || !A || !sol || n < 1 || m < 1 || n > 256 || m > 64 || !(lam > 0.0)) return TTM_E_ARG;
+    const int ld = n + m;
+    std::vector<double> Gm, S2;
+    if (!sep_normal_solve(G, n, m, lam, Gm) || !sep_normal_solve(G, n, m, 2.0 * lam, S2)) return TTM_E_UNSUPPORTED;
+    // dd = Gmm - Gnm'Gm - Gm'Gnm + (Gm'Gnn) Gm;  A = dd / 2 + lam (Gm'Gm + I), symmetrised
+    std::vector<double> W((size_t)m * n), dd((size_t)m * m);
+    for (int a = 0; a < m; ++a)
+        for (int j = 0; j < n; ++j) {
+            double t = 0.0;
+            for (int i = 0; i < n; ++i) t += Gm[i * m + a] * G[i * ld + j];
+            W[a * n + j] = t;                           // (Gm'Gnn)[a][j]
+        }
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b) {
+            double t1 = 0.0, t2 = 0.0, t3 = 0.0, gg = 0.0;
+            for (int i = 0; i < n; ++i) {
+                t1 += G[i * ld + n + a] * Gm[i * m + b];
+                t2 += Gm[i * m + a] * G[i * ld + n + b];
+                t3 += W[a * n + i] * Gm[i * m + b];
+                gg += Gm[i * m + a] * Gm[i * m + b];
+            }
+            dd[a * m + b] = (((G[(n + a) * ld + n + b] - t1) - t2) + t3) / 2.0 + lam * (gg + (a == b ? 1.0 : 0.0));
+        }
+    for (int a = 0; a < m; ++a)
+        for (int b = 0; b < m; ++b) A[a * m + b] = (dd[a * m + b] + dd[b * m + a]) / 2.0;
+    memcpy(sol, S2.data(), (size_t)n * m * 8);
+    return TTM_OK;
+}
+
 int ttm_optimize_integrated_batch(const ttm_program* p, ttm_int_task* tasks, int32_t ntasks, const double* Xsoa, int64_t ldx, int64_t N,
                                   double Ntotal, int32_t nthreads, void* stream, int32_t maxiter) {
     if (!p || !tasks || ntasks < 1 || N < 1) return TTM_E_ARG;

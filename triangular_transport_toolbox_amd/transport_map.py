@@ -1144,6 +1144,14 @@ class transport_map():
             return A, (lambda c: -(sol @ c))
         if self.regularization.lower() == 'l2':
             lam = self.regularization_lambda
+            if self.native_optimizer and lam > 0:           # the same arithmetic in the library (no NumPy: 15 against 75 us)
+                Gc = np.ascontiguousarray(G, dtype=float)
+                m = Gc.shape[0] - n_nm
+                A, sol2 = np.empty((m, m)), np.empty((n_nm, m))
+                rc = self._lib.ttm_separable_reduce_l2(ctypes.c_void_p(Gc.ctypes.data), n_nm, m, float(lam), ctypes.c_void_p(A.ctypes.data),
+                                                       ctypes.c_void_p(sol2.ctypes.data))
+                if rc == 0:
+                    return A, (lambda c: -(sol2 @ c))
             Gm = self._normal_solve(Gnn, Gnm, lam)
             dd = Gmm - Gnm.T @ Gm - Gm.T @ Gnm + Gm.T @ Gnn @ Gm
             A = dd / 2 + lam * (Gm.T @ Gm + np.identity(Gm.shape[-1]))      # no 1/N: as TM:3040-3050
