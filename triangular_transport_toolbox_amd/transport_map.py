@@ -408,8 +408,11 @@ class transport_map():
                 gmean = s1 / self._Nglobal
                 s2 = self._allreduce((sd * sd + (mean - gmean) ** 2) * n_r)
                 mean, sd = gmean, torch.sqrt(s2 / self._Nglobal)
-            self.X_mean = mean.cpu().numpy()
-            self.X_std = sd.cpu().numpy()
+            # (one copy for both vectors; the device copies the layout kernels read are the reduction's own output)
+            both = torch.stack((mean, sd)).cpu().numpy()
+            self.X_mean, self.X_std = both[0].copy(), both[1].copy()
+            self._mean_d, self._std_d = mean, sd
+            return
         elif self.standardization.lower() in ('quantile', 'quantiles'):
             # median / quantile spread per column (TM:775-778) from device order statistics; the
             # quantiles of X - median are the quantiles of X minus the median (monotone shift)
@@ -456,9 +459,19 @@ class transport_map():
         col = col.contiguous()
         ranks = np.asarray(ranks, dtype=np.int64)
         out = np.empty(len(ranks))
-        work = torch.empty(int(self._lib.ttm_select_work_size(16)), dtype=torch.uint8, device=self._dev)
+        # (scratch and the rank vectors - functions of N and the requested quantiles only - stay on the device between calls:
+        # the filter asks for the same order statistics in every update)
+        work = getattr(self, '_select_work', None)
+        if work is None:
+            work = self._select_work = torch.empty(int(self._lib.ttm_select_work_size(16)), dtype=torch.uint8, device=self._dev)
+        rcache = getattr(self, '_select_ranks', None)
+        if rcache is None or len(rcache) > 64:
+            rcache = self._select_ranks = {}
         for i in range(0, len(ranks), 16):
-            r = self._to_dev(ranks[i:i + 16])
+            rkey = ranks[i:i + 16].tobytes()
+            r = rcache.get(rkey)
+            if r is None:
+                r = rcache[rkey] = self._to_dev(ranks[i:i + 16])
             o = self._empty(len(ranks[i:i + 16]))
             if handle is not None:
                 _capi.check(self._lib.ttm_order_statistics_dist(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()), r.numel(),
