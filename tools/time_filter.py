@@ -61,3 +61,4 @@ for _ in range(20):
     flt.forecast(); flt.assimilate(obs)
 sync(); pr.disable()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(30)
+pstats.Stats(pr).sort_stats('tottime').print_stats(28)
