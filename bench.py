@@ -750,6 +750,16 @@ def main():
             b.record()
         torch.cuda.synchronize()
         extra['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        # the log-determinant-only pass (no map values written: what evaluate_pullback_density needs, 8 N (d + 1) bytes)
+        for _ in range(20):
+            tm.density_device(Xs, N, coef=coef, logdet=ld, sigma=sigma)
+        for a, b in evp:
+            a.record()
+            tm.density_device(Xs, N, coef=coef, logdet=ld, sigma=sigma)
+            b.record()
+        torch.cuda.synchronize()
+        extra['pullback_logdet_only_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        extra['pullback_logdet_only_frac'] = 8.0 * N * (du + 1) / (extra['pullback_logdet_only_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS
     if world == 1 and not args.no_optimize:
         # secondary metric of BASELINE.json: optimize() wall-clock on the resident ensemble (from coeffs_init)
         saved = ([c.copy() for c in tm.coeffs_mon], [c.copy() for c in tm.coeffs_nonmon])

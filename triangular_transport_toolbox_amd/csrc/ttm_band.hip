@@ -357,9 +357,10 @@ __device__ __forceinline__ void band_spline_d(const double* tab, int nI, double 
     m = a; dm = da;
 }
 
-// The log-determinant is taken as the log of PRODUCTS of BAND_LD_CHUNK derivatives (one log per chunk instead of one per
-// evaluation: a third of the pass's arithmetic); the uniform factors of the derivatives (2/h of every spline, 1/sigma_k)
-// enter as one number per launch.  A product of four derivatives cannot leave the fp64 range unless one of them does.
+// The log-determinant is taken as the log of the PRODUCT of a row's derivatives, renormalised every BAND_LD_CHUNK columns
+// (mantissa kept, binary exponent counted; a product of four derivatives cannot leave the fp64 range unless one of them
+// does): ONE logarithm per row instead of one per evaluation; the uniform factors of the derivatives (2/h of every
+// spline, 1/sigma_k) enter as one number per launch.
 #define BAND_LD_CHUNK 4
 #define BAND_UNI 256                                  /* components of a density pass, at most */
 #ifndef BAND_DENS_RT
@@ -422,9 +423,14 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
             n = n < last_pair ? n : last_pair;
             roff[q] = n * 8u;
         }
-        double ld[NS], ss[NS], prod[NS];
+        // log det = log of the PRODUCT of the row's derivatives: every BAND_LD_CHUNK columns the product is renormalised
+        // (mantissa kept, exponent counted: two instructions where a logarithm takes 35), ONE logarithm per row at the end.
+        // dmin: the smallest derivative of the row - a negative one makes the row NaN as the reference's log does (two of
+        // them would cancel in the product)
+        double ss[NS], prod[NS], dmin[NS];
+        int pexp[NS];
 #pragma unroll
-        for (int e = 0; e < NS; ++e) { ld[e] = 0.0; ss[e] = 0.0; prod[e] = 1.0; }
+        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; dmin[e] = 0.0; pexp[e] = 0; }
         double pend[NS][LAG];
         for (int kb = k0; kb < k1; kb += Bc) {
             const int ke = kb + Bc < k1 ? kb + Bc : k1;
@@ -490,6 +496,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
                         zv[h] = pend[e][0] + m;
                         ss[e] = fma(zv[h], zv[h], ss[e]);
                         prod[e] *= dm;
+                        dmin[e] = fmin(dmin[e], dm);
                         band_push<DB, DA, LAG>(rec + TTM_P_HDR, start, x, E, pend[e]);
                         if (BAND_DENS_RT == 1) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
                 }
                 if (WRITE_Z && (((j - k0) & (BAND_LD_CHUNK - 1)) == BAND_LD_CHUNK - 1)) {
 #pragma unroll
-                    for (int e = 0; e < NS; ++e) { ld[e] += band_log(prod[e]); prod[e] = 1.0; }
+                    for (int e = 0; e < NS; ++e) { int ex; prod[e] = frexp(prod[e], &ex); pexp[e] += ex; }
                 }
                 rec += PS; xcol += ldxb;
                 if (WRITE_Z) zcol += ldzb;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
             // four inlined logarithms of every step copy cost the registers of two rows)
             auto flush_ld = [&]() {
 #pragma unroll
-                for (int e = 0; e < NS; ++e) { ld[e] += band_log(prod[e]); prod[e] = 1.0; }
+                for (int e = 0; e < NS; ++e) { int ex; prod[e] = frexp(prod[e], &ex); pexp[e] += ex; }
             };
             int j = kb;
             if (WRITE_Z) {                                    // (fewer step copies: two columns at a time)
@@ -540,8 +547,15 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
         for (int q = 0; q < NP; ++q) {
             const unsigned int n = tbase + (unsigned int)(q * HALF);
             if (logdet) {
-                if (n + 1 < c1_32) band_store2<false>((char*)(logdet + n), ld[2 * q] + luni, ld[2 * q + 1] + luni);
-                else if (n < c1_32) logdet[n] = ld[2 * q] + luni;
+                double lv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * q + h;
+                    lv[h] = fma((double)pexp[e], 6.93147180559945286e-01, band_log(prod[e])) + luni;
+                    lv[h] = dmin[e] < 0.0 ? NAN : lv[h];
+                }
+                if (n + 1 < c1_32) band_store2<false>((char*)(logdet + n), lv[0], lv[1]);
+                else if (n < c1_32) logdet[n] = lv[0];
             }
             if (sumsq) {
                 if (n + 1 < c1_32) band_store2<false>((char*)(sumsq + n), ss[2 * q], ss[2 * q + 1]);
@@ -774,9 +788,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
                 }
             }
         }
-        double ss[NS], prod[NS];
+        double ss[NS], prod[NS], dmin[NS];
 #pragma unroll
-        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; }
+        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; dmin[e] = 0.0; }
 #pragma unroll
         for (int j = 0; j < FD; ++j) {
             if (j < nc) {
@@ -799,7 +813,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
                         else m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
                         const double E = band_expq(etab, x, kt);
                         zv[h] = pend[e][0] + m;
-                        if (DENS) { ss[e] = fma(zv[h], zv[h], ss[e]); prod[e] *= dm; }
+                        if (DENS) { ss[e] = fma(zv[h], zv[h], ss[e]); prod[e] *= dm; dmin[e] = fmin(dmin[e], dm); }
                         band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, x, E, pend[e]);
                     }
                     if (!DENS || Z) {
@@ -818,7 +832,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
             for (int q = 0; q < NP; ++q) {
                 const unsigned int n = tbase + (unsigned int)(q * HALF);
                 if (logdet) {
-                    const double la = band_log(prod[2 * q]) + luni, lb = band_log(prod[2 * q + 1]) + luni;
+                    // (a negative derivative makes the row NaN, as the reference's log does: two would cancel in the product)
+                    const double la = dmin[2 * q] < 0.0 ? NAN : band_log(prod[2 * q]) + luni;
+                    const double lb = dmin[2 * q + 1] < 0.0 ? NAN : band_log(prod[2 * q + 1]) + luni;
                     if (n + 1 < N32) band_store2<false>((char*)(logdet + n), la, lb);
                     else if (n < N32) logdet[n] = la;
                 }
