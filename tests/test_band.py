@@ -222,3 +222,21 @@ def test_deferred_checks_give_the_same_results_and_catch_what_the_eager_checks_c
     assert tm.validate(coef) is False and not tm._cm.u_enabled
     Z = tm.forward_device(tm._Xs, N, coef=coef)
     assert relerr(Z[:, :N].cpu().numpy().T, Zref) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['c5_shape', 'few_c2b'])
+def test_density_pass_with_negative_derivatives_is_nan_where_the_reference_is(case, ttm_opt):
+    """The density kernels take ONE logarithm of the product of a row's derivatives: a negative derivative must still make
+    the row NaN (np.log of a negative number, TM:2690-2700), also when two of them would cancel in the product."""
+    tm, om, X, rng = _build(case, n=3001)
+    for k in range(min(3, tm.D)):                             # LET terms with negative coefficients: dS_k/dx_k < 0 in the left tail
+        tm.coeffs_mon[k][0] = om.coeffs_mon[k][0] = -0.6
+    ttm_opt('u_loader', 1); ttm_opt('band_fwd', 1)
+    with np.errstate(all='ignore'):
+        ref = om.evaluate_pullback_density(X)
+    got = tm.evaluate_pullback_density(X)
+    bad = ~np.isfinite(ref)
+    assert bad.sum() > 20 and (~bad).sum() > 20               # (the case has rows of both kinds)
+    assert np.array_equal(~np.isfinite(got), bad)
+    assert relerr(got[~bad], ref[~bad]) < 1e-10
