@@ -220,9 +220,9 @@ extern "C" {
 /* "push" records of a BANDED U-form map (P section, behind the H section; written by ttm_fold when u_p_lag > 0).
  * Banded: the components' columns are consecutive (kc_k = kc_0 + k), every nonmonotone group of component k reads a
  * column kc_k - 1 .. kc_k - u_p_lag, every component has a special-term spline and hot records exist (u_h_cls > 0).
- * u_p_lag is 2, or 3 (= TTM_P_LAG_MAX) for a map of at most TTM_P_FEW_D components with a group three columns back; in
- * the latter case the hot records exist ONLY as the source of the push records (their groups need not hit the planned
- * column cache: the kernels that sweep hot records do not take such a map).
+ * u_p_lag is 2, or 3 (= TTM_P_LAG_MAX) for a map of at most TTM_P_FEW_D components whose groups do not all hit the planned
+ * column cache (a group three columns back; conditioning columns in front of the first component); in the latter case the
+ * hot records exist ONLY as the source of the push records (the kernels that sweep hot records do not take such a map).
  * The band kernels (csrc/ttm_band.hip) walk the columns and add what a column contributes to the components that
  * read it as soon as the column is known, so the records are indexed by COLUMN: record r (0 <= r < D + u_p_lag)
  * belongs to column kc_0 - u_p_lag + r, i.e. to component k = r - u_p_lag when that is >= 0 (the first u_p_lag records

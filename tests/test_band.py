@@ -37,6 +37,7 @@ CASES = {
     'few_c2b': dict(D=2, d=2, spec=lambda: _specs().temperature_spec(5), cls=2, few=True),
     'few_c3': dict(D=4, d=4, spec=lambda: _specs().dense_separable_spec(4, 4), cls=2, lag=3, few=True),
     'few_cond': dict(D=3, d=4, spec=lambda: _banded_with_conditioning(3, 1, band=3), cls=1, lag=3, few=True),
+    'few_cond2': dict(D=4, d=6, spec=lambda: _banded_with_conditioning(4, 2), cls=1, lag=3, few=True),   # (lag 2, but conditioning columns: records of three groups)
 }
 
 
@@ -89,7 +90,7 @@ def test_maps_that_are_not_banded_have_no_push_records():
         rng = np.random.default_rng(2)
         for mon, non, d in (_synthetic_separable(6, 3, 3, 1, 2) + (6,),          # a group three columns back
                             specs.dense_separable_spec(5, 3) + (5,),
-                            _banded_with_conditioning(4, 2) + (6,),              # conditioning columns: no hot records (cache misses)
+                            _banded_with_conditioning(5, 2) + (7,),              # conditioning columns: no hot records (cache misses), more than a few components
                             _banded_with_conditioning(5, 1, band=3) + (6,)):     # three columns back, more than a few components
             X = rng.standard_normal((300, d))
             tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, monotonicity='separable monotonicity')

@@ -299,7 +299,9 @@ def test_generic_uform_kernels_against_the_oracle(backend, monkeypatch, case, tt
         cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
         tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
-    assert tm._cm.u_enabled and tm._cm.u_h_cls == 0
+    # (no hot records, or hot records that only feed the push records of a map with a few components: the kernels here
+    # are the generic ones either way)
+    assert tm._cm.u_enabled and (tm._cm.u_h_cls == 0 or tm._cm.u_p_lag == 3)
     for loader in ('0', '1'):
         ttm_opt('u_loader', int(loader))
         assert relerr(tm.map(X), om.map(X)) < 1e-11

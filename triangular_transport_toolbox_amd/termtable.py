@@ -727,13 +727,15 @@ def _compile_uform(cm, u_info, polyclass, separable):
     maxlag = max(lags, default=1)
     banded = cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(lag >= 1 for lag in lags) and \
         (maxlag <= 2 or (maxlag <= P_LAG_MAX and cm.D <= P_FEW_D)) and all(len(u['st_p0']) > 0 for u in u_info)
-    # (a banded map whose groups do not all hit the planned column cache still gets hot records: as the source of its push
-    # records only, u_p_lag = 3 says so)
-    if (all_hit or (banded and maxlag == 3)) and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
+    # (a banded map of a few components whose groups do not all hit the planned column cache - a group three columns back,
+    # conditioning columns in front of the first component - still gets hot records: as the source of its push records
+    # only, u_p_lag = 3 says so)
+    few_only = banded and cm.D <= P_FEW_D and (maxlag == 3 or not all_hit)
+    if (all_hit or few_only) and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
         cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
         cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
         if banded:
-            cm.u_p_lag = 3 if maxlag == 3 else 2
+            cm.u_p_lag = 3 if few_only else 2
             gp = H_DB[cm.u_h_cls] + 1 + H_DA[cm.u_h_cls]
             cm.u_p_stride = -(-(P_HDR + cm.u_p_lag * gp) // 8) * 8        # whole 64-byte lines
     uform_geometry(cm)
