@@ -652,6 +652,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
 #ifndef BAND_FEW_STAGE
 #define BAND_FEW_STAGE 0
 #endif
+#ifndef BAND_FEWI_STAGE
+#define BAND_FEWI_STAGE 0
+#endif
 #ifndef BAND_FEW_NS
 #define BAND_FEW_NS 2                                 /* rows per thread and tile of the few-component kernels */
 #endif
@@ -1403,6 +1406,19 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few_inverse(const double* __re
         const bool more = tile + (int)gridDim.x < ntiles;
         if (more) request(tile + gridDim.x, xfn, zinn);
         __builtin_amdgcn_sched_barrier(0);
+#if BAND_FEWI_STAGE == 2                                     /* (timing experiments: results wrong by construction) */
+        {
+#pragma unroll
+            for (int j = 0; j < FD; ++j)
+                if (j < nc)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const unsigned int n = tbase + (unsigned int)(q * HALF);
+                        if (n + 1 < N32) band_store2<BAND_FEW_NT != 0>((char*)X + (int64_t)(kcol0 + j) * ldxb + (size_t)(n * 8u), zin[j][q].x + tabs[tid & 255], zin[j][q].y + etab[tid & 255]);
+                    }
+            continue;
+        }
+#endif
         double pend[NS][LAGE];
 #pragma unroll
         for (int l = 0; l < LAGE; ++l) {
@@ -1478,8 +1494,13 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few_inverse(const double* __re
                         xlo[e] = band_lds_f64(xp - 8);
                         xhi[e] = band_lds_f64_single(xp);
                     }
+#if BAND_FEWI_STAGE == 3
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) { r[e] = xlo[e] + ey[e].y; E[e] = xhi[e] * ey[e].x; }
+#else
 #pragma unroll
                     for (int e = 0; e < NS; ++e) interp(ey[e].y, xlo[e], xhi[e], ey[e].x, tg[e], r[e], E[e]);
+#endif
                 }
                 if (outl != 0) {
                     // outliers (the tails of the table, NaN; every row of a degenerate table): clip as TM:4074-4076,
