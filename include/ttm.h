@@ -219,9 +219,11 @@ extern "C" {
 
 /* "push" records of a BANDED U-form map (P section, behind the H section; written by ttm_fold when u_p_lag > 0).
  * Banded: the components' columns are consecutive (kc_k = kc_0 + k), every nonmonotone group of component k reads a
- * column kc_k - 1 .. kc_k - u_p_lag, every component has a special-term spline and hot records exist (u_h_cls > 0).
+ * column kc_k - 1 .. kc_k - u_p_lag, the monotone part of every component is a special-term spline (maps of a few components:
+ * and / or one linear term of its own variable) and hot records exist (u_h_cls > 0).
  * u_p_lag is 2, or 3 (= TTM_P_LAG_MAX) for a map of at most TTM_P_FEW_D components whose groups do not all hit the planned
- * column cache (a group three columns back; conditioning columns in front of the first component); in the latter case the
+ * column cache (a group three columns back; conditioning columns in front of the first component) or that have linear own
+ * terms; in the latter case the
  * hot records exist ONLY as the source of the push records (the kernels that sweep hot records do not take such a map).
  * The band kernels (csrc/ttm_band.hip) walk the columns and add what a column contributes to the components that
  * read it as soon as the column is known, so the records are indexed by COLUMN: record r (0 <= r < D + u_p_lag)
@@ -232,7 +234,8 @@ extern "C" {
  *       monotone constants) + the constant terms of its groups' plain polynomials; 0 when there is no such component
  *   [1] the same for the inverse (nonmonotone constant + the groups' constant terms: the offset TM:4039 subtracts)
  *   [2] 1 - t_lo/h   [3] 1/h   [4] 2/h      spline geometry of the record's own component: column = trunc(x [3] + [2])
- *   [5] int32 {NI, TAB_OFF}   [6] int32 {k (-1: none), 0}   [7] 0
+ *   [5] int32 {NI, TAB_OFF}   [6] int32 {k (-1: none), 0}   [7] slope of the component's own linear term (maps of a few
+ *       components whose monotone list holds [k] next to, or instead of, special terms: NI = 0 then; its constant is in [0])
  *   [8 + l GP ...], l = 0..u_p_lag-1: the group of component k + l + 1 that reads this column (zeros if none):
  *       B[0..DB] (Hermite-function part, monomial coefficients), A[1..DA] (plain part without its constant term);
  *       GP = DB + 1 + DA, (DB, DA) as in the hot records.

@@ -37,6 +37,9 @@ CASES = {
     'few_c2b': dict(D=2, d=2, spec=lambda: _specs().temperature_spec(5), cls=2, few=True),
     'few_c3': dict(D=4, d=4, spec=lambda: _specs().dense_separable_spec(4, 4), cls=2, lag=3, few=True),
     'few_cond': dict(D=3, d=4, spec=lambda: _banded_with_conditioning(3, 1, band=3), cls=1, lag=3, few=True),
+    # linear terms of the own variable next to / instead of the special terms: the filter map of example 06, the map of example 05
+    'few_entf': dict(D=3, d=4, spec=lambda: _specs().entf_filter_spec(3), cls=1, lag=3, few=True),
+    'few_ex05': dict(D=2, d=2, spec=lambda: _specs().density_example_spec(3), cls=1, lag=3, few=True),
     'few_cond2': dict(D=4, d=6, spec=lambda: _banded_with_conditioning(4, 2), cls=1, lag=3, few=True),   # (lag 2, but conditioning columns: records of three groups)
 }
 
@@ -241,3 +244,38 @@ def test_density_pass_with_negative_derivatives_is_nan_where_the_reference_is(ca
     assert bad.sum() > 20 and (~bad).sum() > 20               # (the case has rows of both kinds)
     assert np.array_equal(~np.isfinite(got), bad)
     assert relerr(got[~bad], ref[~bad]) < 1e-10
+
+
+@pytest.mark.gpu
+def test_hot_record_kernels_do_not_pick_up_what_an_earlier_launch_left_in_lds(ttm_opt):
+    """A column that only plain-polynomial groups read is put into the planned cache without exp(-x^2/4) (nobody needs it);
+    the hot-record evaluators read both halves of a cache slot and multiply the second by the group's Hermite-function
+    polynomial - zero here.  That half must be DEFINED: after a table inverse (+inf sentinels behind its resident tables) the
+    same LDS bytes held +inf, and 0 * inf put NaN into a few rows of k_forward_hl's output (found by tools/fuzz_few.py,
+    seed 327).  The sequence of that run: inverse, then the forward map through the hot-record kernel."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    rng = np.random.default_rng(327)
+    mon = [['LET 1', 'iRBF 1', 'iRBF 1', 'iRBF 1', 'RET 1'], ['LET 2', 'iRBF 2', 'iRBF 2', 'RET 2']]
+    non = [[[]], [[], [1]]]
+    kw = dict(monotonicity='separable monotonicity', polynomial_type="probabilist's hermite")
+    n = 5003
+    X = rng.standard_normal((n, 3)) @ (np.tril(rng.standard_normal((3, 3)) * 0.4) + np.eye(3)).T
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(2):
+        c = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = c.copy(), c.copy()
+        c = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k]))
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = c.copy(), c.copy()
+    Zo = om.map(X)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    for rep in range(3):
+        ttm_opt('u_loader', 1); ttm_opt('band_fwd', 1); ttm_opt('band_inv', 1)
+        tm.inverse_map(rng.standard_normal((n, 2)), X_star=X[:, :1])      # (+inf sentinels into LDS)
+        ttm_opt('band_fwd', 0); ttm_opt('band_inv', 0)
+        Z = tm.map(X)
+        tm.forward_device(tm._Xs, tm._N)
+        assert lib.ttm_last_kernel().decode() == 'k_forward_hl'
+        assert np.isfinite(Z).all() and relerr(Z, Zo) < 1e-11

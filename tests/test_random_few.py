@@ -48,7 +48,13 @@ def random_spec(rng):
                     nm.append([j] * o + ['HF'])
         non.append(nm)
         n_irbf = int(rng.integers(0, 4))
-        mon.append(['LET %d' % kc] + ['iRBF %d' % kc] * n_irbf + ['RET %d' % kc])
+        m = ['LET %d' % kc] + ['iRBF %d' % kc] * n_irbf + ['RET %d' % kc]
+        u = rng.random() if family != 'laguerre' else 1.0         # (L_1 = 1 - x decreases: with it the monotone part is not monotone)
+        if u < 0.3:
+            m = [[kc]] + m                                      # a linear term next to the special terms (example 05)
+        elif u < 0.45 and k > 0:
+            m = [[kc]]                                          # ... or instead of them (examples 06 / 07)
+        mon.append(m)
     return D, skip, mon, non, family
 
 
@@ -77,7 +83,7 @@ def one(seed):
     Z, Zo = tm.map(Xq), om.map(Xq)
     tm.forward_device(tm._Xs, tm._N)
     kf = lib.ttm_last_kernel().decode()
-    assert relerr(Z, Zo) < 1e-11, ('map', relerr(Z, Zo))
+    assert relerr(Z, Zo) < 5e-11, ('map', relerr(Z, Zo))      # (rows 12 sigma out under degree-5/6 polynomials: cancellation)
     Xs = (X - om.X_mean) / om.X_std
     for k in range(D):
         assert relerr(tm.s(Xs, k), om.s(Xs, k)) < 1e-11, ('s', k)
@@ -87,7 +93,13 @@ def one(seed):
     Xi, Xo = tm.inverse_map(Zin, X_star=star), om.inverse_map(Zin, X_star=star)
     tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N, X=tm._Xs.clone())
     ki = lib.ttm_last_kernel().decode()
-    assert relerr(Xi, Xo) < 1e-10, ('inverse', relerr(Xi, Xo))
+    assert relerr(Xi, Xo) < 1e-9, ('inverse', relerr(Xi, Xo))
+    # the kernels these replace (generic U-form map, table lookup in memory): the same numbers to rounding, whatever the
+    # conditioning of the map
+    lib.ttm_set_option(b'band_fwd', 0); lib.ttm_set_option(b'band_inv', 0)
+    Zg, Xg = tm.map(Xq), tm.inverse_map(Zin, X_star=star)
+    lib.ttm_set_option(b'band_fwd', 1); lib.ttm_set_option(b'band_inv', 1)
+    assert relerr(Z, Zg) < 1e-12 and relerr(Xi, Xg) < 1e-11, ('vs generic', relerr(Z, Zg), relerr(Xi, Xg))
     if skip == 0:
         with np.errstate(all='ignore'):
             po = om.evaluate_pullback_density(Xq[:300])
@@ -105,4 +117,5 @@ def test_random_maps_of_a_few_components(seed):
         banded, kf, ki, info = one(seed)
     finally:
         lib.ttm_reset_options()
-    assert banded and kf == 'k_band_few' and ki == 'k_band_few_inverse', (kf, ki, info)
+    # (a table that is not increasing - e.g. a Laguerre L_1 = 1 - x term with a positive coefficient - takes the sorted lookup)
+    assert banded and kf == 'k_band_few' and ki in ('k_band_few_inverse', 'k_inverse_table'), (kf, ki, info)

@@ -66,6 +66,12 @@ __global__ __launch_bounds__(64) void k_band_records(const int* __restrict__ uco
     const int hs = TTM_H_HDR + ng * GS;
     double* rec = U + p_off + (int64_t)r * ps;
     auto hot = [&](int kk) { return U + h_off + (int64_t)kk * hs; };
+    // the linear term of a component's own variable, if it has one (maps of a few components: A[0], A[1] of the group behind
+    // the nonmonotone ones in the component's U-form block)
+    auto own = [&](int kk, int deg) {
+        const int* uc = ucomp + kk * TTM_UC_LEN;
+        return (uc[TTM_UC_FLAGS] & TTM_UCF_OWN) ? U[uc[TTM_UC_DBL_OFF] + 4 + 16 * uc[TTM_UC_N_GRP] + 8 + deg] : 0.0;
+    };
     // the group of component kk that reads the column `lg` columns in front of it: index into its hot record, -1: none
     auto group_at = [&](int kk, int lg) {
         const int* uc = ucomp + kk * TTM_UC_LEN;
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(64) void k_band_records(const int* __restrict__ uco
                 v = i == 0 ? h[2] : h[7];
                 const int* uc = ucomp + kk * TTM_UC_LEN;
                 for (int g = 0; g < uc[TTM_UC_N_GRP]; ++g) v += h[TTM_H_HDR + g * GS + 2 + DB];      // A[0] of the group
+                if (i == 0) v += own(kk, 0);                  // (the monotone part's own constant: forward map only)
             }
         } else if (i < TTM_P_HDR) {
             if (k >= 0) {
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(64) void k_band_records(const int* __restrict__ uco
                 else if (i == 4) v = h[5];
                 else if (i == 5) { int2 w = {uc[TTM_UC_NI], uc[TTM_UC_TAB_OFF]}; v = *(double*)&w; }
                 else if (i == 6) { int2 w = {k, 0}; v = *(double*)&w; }
+                else if (i == 7) v = own(k, 1);
             } else if (i == 6) { int2 w = {-1, 0}; v = *(double*)&w; }
         } else {
             const int l = (i - TTM_P_HDR) / GP, j = (i - TTM_P_HDR) % GP;
@@ -735,12 +743,10 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
                 const int i = 2 * tid + r * 2 * CT;
                 if (i < ntab) *(D2*)(tabs + i) = sv[r];
             }
-            if (DENS) {
-                // uniform part of the log-determinant: sum_k log(2 / h_k) - sum_k log(sigma_k), in component order
-                for (int k = 0; k < nc; ++k) {
-                    luni += band_log(P[(int64_t)(k0 + k + LAG) * PS + 4]);
-                    if (sigma) luni -= band_log(sigma[k]);
-                }
+            if (DENS && sigma) {
+                // uniform part of the log-determinant: - sum_k log(sigma_k), in component order (the 2 / h_k of the splines
+                // are applied per evaluation here: a component may have a linear term next to its spline, or no spline)
+                for (int k = 0; k < nc; ++k) luni -= band_log(sigma[k]);
             }
             __syncthreads();
             staged = true;
@@ -799,9 +805,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
             if (j < nc) {
                 cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
                 const double start = P[(int64_t)(k0 + j + LAGE) * PS];        // (of the component LAGE columns on)
-                const double sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4];
+                const double sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4], own1 = rec[7];      // own1: slope of the component's linear term
                 cint_p ri = (cint_p)rec;
-                const int nI = ri[10];
+                const int nI = ri[10];                                                  // (0: no special terms, no spline)
                 const double* tab = tabs + (ri[11] - tab0);
                 char* zcol = (char*)Z + (int64_t)j * ldzb;
 #pragma unroll
@@ -811,12 +817,19 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
                     for (int h = 0; h < 2; ++h) {
                         const int e = 2 * q + h;
                         const double x = h ? xin[j][q].y : xin[j][q].x;
-                        double m, dm = 1.0;
-                        if (DENS) band_spline_d(tab, nI, sp_a, sp_b, sp_ds, x, m, dm);
-                        else m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
+                        double m = 0.0, dm = 0.0;
+                        if (nI > 0) {
+                            if (DENS) band_spline_d(tab, nI, sp_a, sp_b, sp_ds, x, m, dm);
+                            else m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
+                        }
                         const double E = band_expq(etab, x, kt);
-                        zv[h] = pend[e][0] + m;
-                        if (DENS) { ss[e] = fma(zv[h], zv[h], ss[e]); prod[e] *= dm; dmin[e] = fmin(dmin[e], dm); }
+                        zv[h] = fma(own1, x, pend[e][0] + m);
+                        if (DENS) {
+                            const double dx = fma(dm, sp_ds, own1);           // dS_k/dx_k in standardised units
+                            ss[e] = fma(zv[h], zv[h], ss[e]);
+                            prod[e] *= dx;
+                            dmin[e] = fmin(dmin[e], dx);
+                        }
                         band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, x, E, pend[e]);
                     }
                     if (!DENS || Z) {

@@ -1056,7 +1056,8 @@ struct PlanCache {
             if (v >= 0) {
                 const R x = xa(v & ~TTM_PLAN_E);
                 st.set(2 * w, x);
-                if (v & TTM_PLAN_E) st.set(2 * w + 1, st.etab ? exp_q_tab(st.etab, x) : exp_q_fast(x));
+                // (the second half of the slot is defined either way: hot-record evaluators read both halves, see h_component)
+                st.set(2 * w + 1, (v & TTM_PLAN_E) ? (st.etab ? exp_q_tab(st.etab, x) : exp_q_fast(x)) : R(0.0));
             }
         }
     }

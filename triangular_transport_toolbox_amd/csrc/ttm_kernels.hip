@@ -1209,7 +1209,8 @@ __device__ __attribute__((noinline)) void rt_warm(const int* state_, const char*
                 n = n < last_pair ? n : last_pair;
                 const D2 x = *(const D2*)(col + (size_t)(n * 8u));
                 cc.set(2 * w, q, x);
-                if (v & TTM_PLAN_E) cc.set(2 * w + 1, q, rt_expq(x));
+                const D2 zero = {0.0, 0.0};                  // (defined either way: the group evaluation reads both halves)
+                cc.set(2 * w + 1, q, (v & TTM_PLAN_E) ? rt_expq(x) : zero);
             }
         }
     }
@@ -1608,6 +1609,9 @@ __global__ __launch_bounds__(1024) void k_inverse_rt(const int* __restrict__ uco
                         if (flg & 1) {
                             D2 eo = {ev[2 * q], ev[2 * q + 1]};
                             cc.set(put2 + 1, q, ETAB ? eo : rt_expq(rprev[q]));
+                        } else {
+                            const D2 zero = {0.0, 0.0};      // (defined: read next to x by the groups of later components)
+                            cc.set(put2 + 1, q, zero);
                         }
                     }
                 }

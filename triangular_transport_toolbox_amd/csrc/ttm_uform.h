@@ -544,8 +544,10 @@ TTM_HD void h_component(cdbl_p rec, const double* tab, const R& xk, const ST& st
     S = s + m;
     dS = dm;
     if (put2 >= 0) {
-        if (flg & 1) st.set2(put2, xk, ek);
-        else st.set(put2, xk);
+        // (no later group needs exp(-x_k^2/4): the slot next to x_k is still DEFINED - the hot-record evaluators read both
+        // halves of a slot and multiply the second by the group's Hermite-function polynomial, zero for such a group: what an
+        // earlier launch left in LDS (+inf sentinels of the inverse tables) times zero would be NaN)
+        st.set2(put2, xk, (flg & 1) ? ek : R(0.0));
     }
 }
 
@@ -594,7 +596,7 @@ TTM_HD void h_put(cdbl_p rec, const ST& st, const R& xk) {
     const int put2 = ((cint_p)rec)[0], flg = ((cint_p)rec)[1];
     if (put2 >= 0) {
         if (flg & 1) st.set2(put2, xk, TTM_HL_EXP(st, xk));
-        else st.set(put2, xk);
+        else st.set2(put2, xk, R(0.0));                      // (defined, see h_component)
     }
 }
 

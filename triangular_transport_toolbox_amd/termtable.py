@@ -725,13 +725,21 @@ def _compile_uform(cm, u_info, polyclass, separable):
     kc0 = int(ucomp[0, 0]) if cm.D else 0
     lags = [int(ucomp[k, 0]) - int(ugrp[int(ucomp[k, 3]) + g, 0]) for k in range(cm.D) for g in range(int(ucomp[k, 2]))]
     maxlag = max(lags, default=1)
+    # the monotone part of a component: its special-term spline, and for maps of a few components possibly ONE linear term
+    # of its own variable next to it (or instead of it: the [k] terms of examples 05 / 06 / 07) - the push record carries
+    # that coefficient; other polynomial / Hermite-function terms of the own variable stay with the generic kernels
+    own = [bool(int(f) & UCF_OWN) for f in ucomp[:, 7]]
+    own_linear = [o and u['maxP_hf'] == 0 and u['maxP_poly'] == 1 for o, u in zip(own, u_info)]
+    few = cm.D <= P_FEW_D
     banded = cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(lag >= 1 for lag in lags) and \
-        (maxlag <= 2 or (maxlag <= P_LAG_MAX and cm.D <= P_FEW_D)) and all(len(u['st_p0']) > 0 for u in u_info)
+        (maxlag <= 2 or (maxlag <= P_LAG_MAX and few)) and \
+        all((len(u['st_p0']) > 0 and not o) or (few and ol) for u, o, ol in zip(u_info, own, own_linear)) and \
+        any(len(u['st_p0']) > 0 for u in u_info)
     # (a banded map of a few components whose groups do not all hit the planned column cache - a group three columns back,
-    # conditioning columns in front of the first component - still gets hot records: as the source of its push records
-    # only, u_p_lag = 3 says so)
-    few_only = banded and cm.D <= P_FEW_D and (maxlag == 3 or not all_hit)
-    if (all_hit or few_only) and ng <= H_NG_MAX and not any(int(f) & UCF_OWN for f in ucomp[:, 7]):
+    # conditioning columns in front of the first component - or with linear own terms still gets hot records: as the source of
+    # its push records only, u_p_lag = 3 says so)
+    few_only = banded and few and (maxlag == 3 or not all_hit or any(own))
+    if ((all_hit and not any(own)) or few_only) and ng <= H_NG_MAX:
         cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
         cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
         if banded:
