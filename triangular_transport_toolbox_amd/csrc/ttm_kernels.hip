@@ -516,10 +516,12 @@ struct UTabs {               // by-value kernel argument
 };
 
 // one workgroup per component: monomial coefficients of the groups, spline of the summed special terms, fit check
-__global__ __launch_bounds__(256) void k_uform(DevProg P, UTabs T, const double* __restrict__ fold, double* __restrict__ U,
-                                               int64_t err_off, int64_t h_off, int h_cls, int h_ng) {
+// (1024 threads per component: the node, fit and verification phases each hand out nI x 12..13 independent evaluations -
+// ~450 at C5 - and a workgroup of four waves walked them in two dependent rounds: 15.8 us per launch, 9 with sixteen)
+__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ fold, double* __restrict__ U,
+                                                int64_t err_off, int64_t h_off, int h_cls, int h_ng) {
     __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
-    __shared__ double red[2][4];
+    __shared__ double red[2][16];
     const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
     const int D1 = P.D + 1;
     const int* uc = T.ucomp + k * TTM_UC_LEN;
@@ -2643,7 +2645,7 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* strea
             if (p->h_ucomp && p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > TTM_U_NI_MAX)
                 return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
         const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
-        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(256), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
+        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
                            fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng);
         if (p->u_p_lag > 0 && p->u_h_cls > 0) ttm_band::build_records(p, fold + fold_base_size(p), stream);       // push records of banded maps
     }
