@@ -432,6 +432,8 @@ def multi_gpu_extras(torch, dist, args, rank, world, backend):
     Never fatal for the headline line."""
     import ctypes
     from triangular_transport_toolbox_amd import comm, entf
+    if os.environ.get('TTM_BENCH_ABORT_IN_EXTRAS') == str(rank):          # (rehearsal of the guardian in main())
+        os.abort()
     out = {}
 
     def sync():
@@ -881,10 +883,36 @@ def main():
         # it has (with `multi_gpu_extras_error`) and every rank leaves, instead of a hung collective taking the headline
         # with it.  (A thread can do that: the blocked calls have released the GIL.)
         import threading
+        # ... and should a rank DIE inside them (an abort inside a collective cannot be caught), a guardian forked off rank 0
+        # beforehand - it holds the headline line, touches nothing but a pipe and stdout - prints that line in its place
+        guard_w = guard_pid = None
+        if rank == 0 and out is not None:
+            sys.stdout.flush()
+            guard_r, guard_w = os.pipe()
+            guard_pid = os.fork()
+            if guard_pid == 0:
+                os.close(guard_w)
+                try:
+                    done = os.read(guard_r, 1)             # b'1': the parent prints the line itself; EOF: it is gone
+                    if done != b'1':
+                        out['multi_gpu_extras_error'] = 'the process ended inside the multi-GPU extras'
+                        os.write(1, (json.dumps(out) + '\n').encode())
+                finally:
+                    os._exit(0)
+            os.close(guard_r)
+
+        def release_guard():
+            if guard_w is not None:
+                try:
+                    os.write(guard_w, b'1')
+                    os.close(guard_w)
+                except OSError:
+                    pass
 
         def give_up():
             if rank == 0 and out is not None:
                 out['multi_gpu_extras_error'] = 'not finished within %g s' % args.extras_timeout
+                release_guard()
                 print(json.dumps(out))
                 sys.stdout.flush()
             else:
@@ -900,6 +928,12 @@ def main():
         except Exception as exc:                       # noqa: BLE001
             extra2 = {'multi_gpu_extras_error': repr(exc)}
         dog.cancel()
+        release_guard()
+        if guard_pid:
+            try:
+                os.waitpid(guard_pid, 0)
+            except OSError:
+                pass
         if out is not None:
             out.update(extra2)
     if out is not None:
