@@ -259,6 +259,60 @@ __global__ __launch_bounds__(256) void k_export(const double* __restrict__ Xsoa,
     }
 }
 
+// The same for matrices of at most 64 columns - every map of the reference's examples and benchmarks: a slab of 64 rows is
+// 64 d CONSECUTIVE doubles of the row-major matrix, so it is read (written) as a flat stream with every lane busy; the
+// tiled kernels above give a column to a lane (d = 40: 24 of 64 lanes idle; d = 4 - the filter's map input - 60 of 64).
+// tile[c][r] with a row stride of 65 doubles: the flat side walks c fastest, the column side r fastest, both conflict-free.
+__global__ __launch_bounds__(256) void k_import_flat(const double* __restrict__ Xrow, int64_t N, int d,
+                                                     const double* __restrict__ mean, const double* __restrict__ sd,
+                                                     double* __restrict__ Xsoa, int64_t ldx) {
+    __shared__ double tile[64 * 65];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)(N - n0 < 64 ? N - n0 : 64), total = rows * d, tid = threadIdx.x;
+    const double* src = Xrow + n0 * d;
+    const int dq = 256 / d, dr = 256 - dq * d;                  // 256 = dq d + dr: how (row, column) moves from one pass to the next
+    int r = tid / d, c = tid - r * d;
+    for (int e = tid; e < total; e += 256) {
+        tile[c * 65 + r] = src[e];
+        r += dq; c += dr;
+        if (c >= d) { c -= d; ++r; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < d * 64; idx += 256) {
+        const int cc = idx >> 6, rr = idx & 63;
+        if (rr < rows) {
+            double v = tile[cc * 65 + rr];
+            if (mean) v = (v - mean[cc]) / sd[cc];
+            Xsoa[(int64_t)cc * ldx + n0 + rr] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_export_flat(const double* __restrict__ Xsoa, int64_t ldx, int64_t N, int j0, int dout,
+                                                     const double* __restrict__ mean, const double* __restrict__ sd,
+                                                     double* __restrict__ Xrow) {
+    __shared__ double tile[64 * 65];
+    const int64_t n0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)(N - n0 < 64 ? N - n0 : 64), total = rows * dout, tid = threadIdx.x;
+    for (int idx = tid; idx < dout * 64; idx += 256) {
+        const int cc = idx >> 6, rr = idx & 63;
+        if (rr < rows) {
+            double v = Xsoa[(int64_t)(j0 + cc) * ldx + n0 + rr];
+            if (mean) v = v * sd[j0 + cc] + mean[j0 + cc];
+            tile[cc * 65 + rr] = v;
+        }
+    }
+    __syncthreads();
+    double* dst = Xrow + n0 * dout;
+    const int dq = 256 / dout, dr = 256 - dq * dout;
+    int r = tid / dout, c = tid - r * dout;
+    for (int e = tid; e < total; e += 256) {
+        dst[e] = tile[c * 65 + r];
+        r += dq; c += dr;
+        if (c >= dout) { c -= dout; ++r; }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1: column statistics of a row-major matrix (two passes, fixed tree)
 // pass A: partial sums per block -> mean ; pass B: partial sums of (x-mean)^2 -> std
@@ -2561,6 +2615,10 @@ int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, con
                int64_t ldx, void* stream) {
     if (!Xrow || !Xsoa || N < 1 || d < 1 || ldx < N) return set_err(TTM_E_ARG, "ttm_import: bad arguments%s");
     if ((mean == nullptr) != (sd == nullptr)) return set_err(TTM_E_ARG, "ttm_import: mean and std must both be given%s");
+    if (d <= 64) {
+        hipLaunchKernelGGL(k_import_flat, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Xrow, N, (int)d, mean, sd, Xsoa, ldx);
+        return check_launch("k_import_flat");
+    }
     dim3 grid((unsigned)((N + 63) / 64), (d + 63) / 64);
     hipLaunchKernelGGL(k_import, grid, dim3(256), 0, (hipStream_t)stream, Xrow, N, (int)d, mean, sd, Xsoa, ldx);
     return check_launch("k_import");
@@ -2570,6 +2628,10 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
                const double* sd, double* Xrow, void* stream) {
     if (!Xrow || !Xsoa || N < 1 || dout < 1 || j0 < 0 || ldx < N) return set_err(TTM_E_ARG, "ttm_export: bad arguments%s");
     if ((mean == nullptr) != (sd == nullptr)) return set_err(TTM_E_ARG, "ttm_export: mean and std must both be given%s");
+    if (dout <= 64) {
+        hipLaunchKernelGGL(k_export_flat, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream, Xsoa, ldx, N, (int)j0, (int)dout, mean, sd, Xrow);
+        return check_launch("k_export_flat");
+    }
     dim3 grid((unsigned)((N + 63) / 64), (dout + 63) / 64);
     hipLaunchKernelGGL(k_export, grid, dim3(256), 0, (hipStream_t)stream, Xsoa, ldx, N, (int)j0, (int)dout, mean, sd, Xrow);
     return check_launch("k_export");
