@@ -558,7 +558,27 @@ def flops_per_eval(tm):
     return fwd, inv
 
 
+def guardian_main():
+    """`bench.py --guardian` (started by rank 0 of a multi-rank run at the very top of main(), BEFORE that process imports
+    torch or touches the GPU; it never touches the GPU itself): reads lines from its standard input until it closes and
+    prints the LAST complete one on the standard output it inherited.  Rank 0 sends the headline line (marked
+    `multi_gpu_extras_error`) before the node-level extras and the full line after them, so exactly one JSON line comes
+    out whether the rank finishes, is stopped by its watchdog or dies inside a collective."""
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, signal.SIG_IGN)           # (it ends when rank 0's end of the pipe closes, not before)
+    last = None
+    for line in sys.stdin.buffer:
+        if line.endswith(b'\n'):
+            last = line
+    if last is not None:
+        os.write(1, last)
+    return 0
+
+
 def main():
+    if '--guardian' in sys.argv[1:]:
+        return guardian_main()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -589,6 +609,27 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
+    guard = None
+    if world > 1 and rank == 0:
+        # the guardian of the JSON line exists before this process imports torch (see guardian_main)
+        import subprocess
+        guard = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--guardian'], stdin=subprocess.PIPE,
+                                 start_new_session=True)
+
+    def emit(obj, last=False):
+        line = json.dumps(obj) + '\n'
+        if guard is None:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            return
+        try:
+            guard.stdin.write(line.encode())
+            guard.stdin.flush()
+            if last:
+                guard.stdin.close()
+                guard.wait(timeout=30)
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            pass
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         # first, before anything touches the GPU (the NumPy leg forks a worker)
@@ -883,41 +924,18 @@ def main():
         # it has (with `multi_gpu_extras_error`) and every rank leaves, instead of a hung collective taking the headline
         # with it.  (A thread can do that: the blocked calls have released the GIL.)
         import threading
-        # ... and should a rank DIE inside them (an abort inside a collective cannot be caught), a guardian forked off rank 0
-        # beforehand - it holds the headline line, touches nothing but a pipe and stdout - prints that line in its place
-        guard_w = guard_pid = None
+        # ... and should a rank DIE inside them (an abort inside a collective cannot be caught), the guardian started at the
+        # top of main() already holds the headline line: it prints the last line it was sent when rank 0's pipe closes
         if rank == 0 and out is not None:
-            sys.stdout.flush()
-            guard_r, guard_w = os.pipe()
-            guard_pid = os.fork()
-            if guard_pid == 0:
-                os.close(guard_w)
-                try:
-                    done = os.read(guard_r, 1)             # b'1': the parent prints the line itself; EOF: it is gone
-                    if done != b'1':
-                        out['multi_gpu_extras_error'] = 'the process ended inside the multi-GPU extras'
-                        os.write(1, (json.dumps(out) + '\n').encode())
-                finally:
-                    os._exit(0)
-            os.close(guard_r)
-
-        def release_guard():
-            if guard_w is not None:
-                try:
-                    os.write(guard_w, b'1')
-                    os.close(guard_w)
-                except OSError:
-                    pass
+            emit(dict(out, multi_gpu_extras_error='the process ended inside the multi-GPU extras'))
 
         def give_up():
             if rank == 0 and out is not None:
                 out['multi_gpu_extras_error'] = 'not finished within %g s' % args.extras_timeout
-                release_guard()
-                print(json.dumps(out))
-                sys.stdout.flush()
+                emit(out, last=True)
             else:
                 time.sleep(2.0)
-            os._exit(0)
+            os._exit(3)                                  # (a hung collective is a failed run: the line says why)
         dog = threading.Timer(args.extras_timeout, give_up)
         dog.daemon = True
         dog.start()
@@ -928,16 +946,10 @@ def main():
         except Exception as exc:                       # noqa: BLE001
             extra2 = {'multi_gpu_extras_error': repr(exc)}
         dog.cancel()
-        release_guard()
-        if guard_pid:
-            try:
-                os.waitpid(guard_pid, 0)
-            except OSError:
-                pass
         if out is not None:
             out.update(extra2)
     if out is not None:
-        print(json.dumps(out))
+        emit(out, last=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -12,7 +12,7 @@ import pytest
 import scipy.stats
 
 from tests.hostemu import emu
-from tests.util import (ALL_CASES, INTEGRATED, SEPARABLE, case_X, coeff_lists, ctor_kwargs, load_case, make_oracle, relerr)
+from tests.util import (ALL_CASES, INTEGRATED, SEPARABLE, case_X, check, coeff_lists, ctor_kwargs, load_case, make_oracle, relerr)
 
 
 @pytest.fixture(params=[pytest.param('hostemu'), pytest.param('hip', marks=pytest.mark.gpu)])
@@ -66,7 +66,7 @@ def test_map(backend, name):
     X = case_X(name, npz)[:npz['Z'].shape[0]]
     Z = tm.map(X)
     assert Z.shape == npz['Z'].shape
-    assert relerr(Z, npz['Z']) < 1e-11
+    check('golden/map[%s]' % name, relerr(Z, npz['Z']), 1e-11, backend)
     if npz['Z'].shape[0] == tm._N:
         assert relerr(tm.map(), npz['Z']) < 1e-11          # stored samples
 
@@ -97,8 +97,8 @@ def test_objective_integrated(backend, name):
     for k in range(tm.D):
         div = len(tm.coeffs_nonmon[k])
         for c, J, G in zip(npz['obj_c_%d' % k], npz['obj_J_%d' % k], npz['obj_G_%d' % k]):
-            assert abs(tm.objective_function(c.copy(), k, div) - J) <= 1e-10 * (1 + abs(J))   # north_star bar
-            assert relerr(tm.objective_function_jacobian(c.copy(), k, div), G) < 1e-10
+            check('golden/objective_J[%s]' % name, abs(tm.objective_function(c.copy(), k, div) - J) / (1 + abs(J)), 1e-10, backend)   # north_star bar
+            check('golden/objective_gradJ[%s]' % name, relerr(tm.objective_function_jacobian(c.copy(), k, div), G), 1e-10, backend)
 
 
 def test_example01_known_answer(backend):
@@ -107,8 +107,8 @@ def test_example01_known_answer(backend):
     tm = make_tm('ex01_order10', npz, desc)
     J0 = tm.objective_function(None, 0, len(tm.coeffs_nonmon[0]))
     J1 = tm.objective_function(None, 1, len(tm.coeffs_nonmon[1]))
-    assert abs(J0 - 0.22517858233600704) < 1e-10 * 1.3
-    assert abs(J1 - (-0.7978830242276339)) < 1e-10 * 1.8
+    check('golden/ex01_known_answer_J0', abs(J0 - 0.22517858233600704) / 1.3, 1e-10, backend)
+    check('golden/ex01_known_answer_J1', abs(J1 - (-0.7978830242276339)) / 1.8, 1e-10, backend)
     for k in range(2):
         G = tm.objective_function_jacobian(None, k, len(tm.coeffs_nonmon[k]))
         assert np.max(np.abs(G)) < 1e-5
@@ -123,13 +123,13 @@ def test_separable_reduction(backend, name):
     npz, desc = load_case(name)
     tm = make_tm(name, npz, desc)
     for k in range(0, tm.D, 13 if tm.D > 8 else 1):
-        A, solve_nonmon = tm.separable_setup(k)
-        assert relerr(A, npz['sep_A_%d' % k]) < 1e-9
+        A, solve_nonmon = tm.separable_setup(k)                # the engine's own Gram + Cholesky reduction ...
+        check('golden/sep_A[%s]' % name, relerr(A, npz['sep_A_%d' % k]), 1e-10, backend)
         for c, J, G in zip(npz['sep_c_%d' % k], npz['sep_J_%d' % k], npz['sep_G_%d' % k]):
-            Jg, Gg = tm.separable_objective(c.copy(), npz['sep_A_%d' % k], k)
-            assert abs(Jg - J) <= 1e-10 * (1 + abs(J))
-            assert relerr(Gg, G) < 1e-10
-        assert relerr(solve_nonmon(npz['coeffs_mon_%d' % k]), npz['coeffs_nonmon_%d' % k]) < 1e-8
+            Jg, Gg = tm.separable_objective(c.copy(), A, k)    # ... is what the objective is evaluated with
+            check('golden/sep_J[%s]' % name, abs(Jg - J) / (1 + abs(J)), 1e-10, backend)
+            check('golden/sep_gradJ[%s]' % name, relerr(Gg, G), 1e-10, backend)
+        check('golden/sep_c_nonmon[%s]' % name, relerr(solve_nonmon(npz['coeffs_mon_%d' % k]), npz['coeffs_nonmon_%d' % k]), 1e-10, backend)
 
 
 @pytest.mark.parametrize('name', SEPARABLE)
@@ -138,10 +138,10 @@ def test_inverse_table(backend, name):
     tm = make_tm(name, npz, desc)
     X = tm.inverse_map(npz['inv_Z'])
     assert X.shape == npz['inv_X_table'].shape
-    assert relerr(X, npz['inv_X_table']) < 1e-10
+    check('golden/inverse_table[%s]' % name, relerr(X, npz['inv_X_table']), 1e-11, backend)
     if 'inv_cond_X' in npz:
         Xc = tm.inverse_map(npz['inv_Z'][:, 1:], X_star=npz['inv_cond_Xstar'])
-        assert relerr(Xc, npz['inv_cond_X']) < 1e-10
+        check('golden/inverse_table_conditional[%s]' % name, relerr(Xc, npz['inv_cond_X']), 1e-11, backend)
 
 
 @pytest.mark.parametrize('name', ['c1_int', 'c2a_int', 'c3_int', 'c2b_sep', 'c3_sep', 'misc_sep', 'misc_grid'])
@@ -152,7 +152,7 @@ def test_inverse_bisection(backend, name):
     Zin = npz['inv_Z']
     key = 'inv_X_nostar' if name == 'misc_grid' else ('inv_X' if 'inv_X' in npz else 'inv_X_bisect')
     X = tm.inverse_map(Zin)
-    assert relerr(X, npz[key]) < 1e-6
+    check('golden/inverse_bisection[%s]' % name, relerr(X, npz[key]), 1e-6, backend)
     # residual under the oracle's forward map (bisection stops at |S - z| <= 1e-9)
     skipcols = np.zeros((len(X), om.skip_dimensions)) + om.X_mean[:om.skip_dimensions]
     assert np.max(np.abs(om.map(np.column_stack((skipcols, X)))[1:] - Zin[1:])) < 5e-9
@@ -172,14 +172,14 @@ def test_densities(backend, name):
     npz, desc = load_case(name)
     tm = make_tm(name, npz, desc)
     X = case_X(name, npz)[:npz['pullback'].shape[0]]
-    assert relerr(tm.evaluate_pullback_density(X), npz['pullback']) < 1e-10
+    check('golden/pullback[%s]' % name, relerr(tm.evaluate_pullback_density(X), npz['pullback']), 1e-10, backend)
     if 'pushforward' in npz:
         def log_target_pdf(x):
             return scipy.stats.multivariate_normal.logpdf(x, mean=np.zeros(x.shape[-1]), cov=np.identity(x.shape[-1]))
         got = tm.evaluate_pushforward_density(npz['inv_Z'], log_target_pdf)
         ok = np.isfinite(npz['pushforward'])
         assert np.array_equal(np.isfinite(got), ok)
-        assert relerr(got[ok], npz['pushforward'][ok]) < 1e-8
+        check('golden/pushforward[%s]' % name, relerr(got[ok], npz['pushforward'][ok]), 1e-8, backend)
 
 
 def test_example05_density_grids(backend):
@@ -190,8 +190,8 @@ def test_example05_density_grids(backend):
     npz, desc = load_case('ex05_density')
     tm = make_tm('ex05_density', npz, desc['full'])
     grid = npz['grid']
-    assert relerr(tm.map(grid), npz['grid_Z']) < 1e-11
-    assert relerr(tm.evaluate_pullback_density(grid), npz['pullback']) < 1e-10
+    check('golden/ex05_map', relerr(tm.map(grid), npz['grid_Z']), 1e-11, backend)
+    check('golden/ex05_pullback', relerr(tm.evaluate_pullback_density(grid), npz['pullback']), 1e-10, backend)
     got = tm.evaluate_pushforward_density(grid, specs.logpdf_wavy)
     ok = np.isfinite(npz['pushforward'])
     assert np.array_equal(np.isfinite(got), ok)
@@ -207,14 +207,23 @@ def test_example05_density_grids(backend):
     assert relerr(got[ok], npz['cond_pushforward'][ok]) < 1e-8
 
 
-@pytest.mark.parametrize('name', ['c1_int', 'c2b_sep', 'c3_sep'])
+@pytest.mark.parametrize('name', ['c1_int', 'c2b_sep', 'c3_sep', 'c5_sep'])
 def test_optimize(backend, name):
+    """optimize() against the reference's final coefficients.  c5_sep: the 40 components of BASELINE
+    config 5 on the fixture's 10^4 samples - what bench.py times at N = 10^6 (TM:2903-3172); there the objective the
+    reference's own L-BFGS-B run ended on is in the fixture (sep_Jopt_k) and is compared as well."""
     npz, desc = load_case(name)
     tm = make_tm(name, npz, desc, with_coeffs=False)
     ref_mon, ref_non = coeff_lists(npz, tm.D)
     tm.optimize()
     om = make_oracle(name, npz, desc)
     for k in range(tm.D):
+        if 'sep_Jopt_%d' % k in npz:
+            A, _ = om.separable_setup(k)
+            J_got = om.separable_objective(tm.coeffs_mon[k], A, k)[0]
+            J_opt = float(npz['sep_Jopt_%d' % k])
+            assert J_got <= J_opt + 1e-8 * abs(J_opt) + 1e-10
+            check('golden/optimize_J_vs_reference_Jopt[%s]' % name, max(J_got - J_opt, 0.0) / (1 + abs(J_opt)), 1e-8, backend)
         if name.endswith('_int'):
             div = len(ref_non[k])
             J_ref = om.objective_function(np.concatenate((ref_non[k], ref_mon[k])), k, div)
@@ -272,16 +281,16 @@ def test_entf_update_with_reset(backend):
     assert relerr(tm.X_mean, npz['u0_X_mean']) < 1e-13
     for k in range(tm.D):
         A, _ = tm.separable_setup(k)
-        assert relerr(A, npz['u0_sep_A_%d' % k]) < 1e-9
+        check('golden/entf_sep_A', relerr(A, npz['u0_sep_A_%d' % k]), 1e-10, backend)
     tm.optimize()
     for k in range(tm.D):
         assert relerr(tm.coeffs_mon[k], npz['u0_coeffs_mon_%d' % k]) < 1e-4
         assert relerr(tm.coeffs_nonmon[k], npz['u0_coeffs_nonmon_%d' % k]) < 1e-4
     tm.coeffs_mon, tm.coeffs_nonmon = coeff_lists(npz, tm.D, prefix='u0_')
     Zp = tm.map(npz['u0_map_input'])
-    assert relerr(Zp, npz['u0_Z']) < 1e-11
+    check('golden/entf_map', relerr(Zp, npz['u0_Z']), 1e-11, backend)
     Ystar = np.repeat(npz['obs'][0][0].reshape((1, 1)), Zp.shape[0], axis=0)
-    assert relerr(tm.inverse_map(npz['u0_Z'], X_star=Ystar), npz['u0_ret']) < 1e-10
+    check('golden/entf_conditional_inverse', relerr(tm.inverse_map(npz['u0_Z'], X_star=Ystar), npz['u0_ret']), 1e-11, backend)
 
 
 def test_argument_errors(backend):
@@ -324,7 +333,7 @@ def test_entf_cycles_match_reference(backend):
     for t in range(len(npz['obs'])):
         noises = [npz['noise_%d_%d' % (t, i)] for i in range(3)]
         Xa = entf.assimilate(tm, ens, npz['obs'][t], noises)
-        assert relerr(Xa, npz['ens_%d_2' % t]) < 1e-6
+        check('golden/entf_cycles', relerr(Xa, npz['ens_%d_2' % t]), 1e-6, backend)
         ens = entf.rk4(Xa, 0.05, 2)
         assert relerr(ens, npz['forecast_%d' % t]) < 1e-6
 
@@ -374,7 +383,7 @@ def test_ents_backward_smoother_matches_reference(backend):
     Xs = entf.smooth(tm, npz['forecasts'], npz['analyses'])
     assert Xs.shape == npz['smoothed'].shape
     for t in range(len(Xs)):
-        assert relerr(Xs[t], npz['smoothed'][t]) < 1e-6
+        check('golden/ents_smoothed', relerr(Xs[t], npz['smoothed'][t]), 1e-6, backend)
     for k in range(tm.D):                     # (coefficients of the last update, t = 0)
         assert relerr(tm.coeffs_mon[k], npz['last_coeffs_mon_%d' % k]) < 1e-4
         assert relerr(tm.coeffs_nonmon[k], npz['last_coeffs_nonmon_%d' % k]) < 1e-4
@@ -428,4 +437,4 @@ def test_nearly_collinear_nonmonotone_basis_takes_the_qr_path(backend):
     assert relerr(tm.separable_objective(c, A, k)[0], om.separable_objective(c, Ao, k)[0]) < 1e-9
     # a well-conditioned component of the same map keeps the Gram path and agrees as before
     A1, _ = tm.separable_setup(1)
-    assert relerr(A1, om.separable_setup(1)[0]) < 1e-9
+    assert relerr(A1, om.separable_setup(1)[0]) < 1e-10

@@ -78,3 +78,16 @@ def record_parity(key, value, tol=None):
             json.dump(data, f, indent=1, sort_keys=True)
     except Exception:                                   # noqa: BLE001
         pass
+
+
+def check(key, err, tol, backend=None):
+    """Assert `err < tol` and keep the achieved error (record_parity) - the golden-level tests call this so that
+    profiles/parity_rNN.json lists every check with its tolerance, not only the full-size ones."""
+    if backend is None or backend == 'hip':
+        prev = _PARITY_MAX.get(key, 0.0)
+        _PARITY_MAX[key] = max(prev, float(err))
+        record_parity(key, _PARITY_MAX[key], tol)
+    assert err < tol, '%s: %.3e >= %.1e' % (key, err, tol)
+
+
+_PARITY_MAX = {}
