@@ -171,17 +171,21 @@ def counted_fp64(workload, N, forward_ms, inverse_ms, newton_ms=None):
     c = json.load(open(path)).get(workload)
     if not c:
         return None
-    out = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'estimate': False, 'source': 'profiles/fp64_counts.json (rocprofv3 --pmc, counted)'}
+    out = {'peak_TFLOPs': FP64_PEAK_TFLOPS, 'estimate': False, 'source': 'profiles/fp64_counts.json (rocprofv3 --pmc, counted)',
+           'definition': c.get('definition')}
     scale = N / float(c['N'])
     for key, kern, ms in (('forward', c.get('forward_kernel'), forward_ms), ('inverse', c.get('inverse_kernel'), inverse_ms),
                           ('inverse_newton', c.get('newton_kernel'), newton_ms)):
         k = c['kernels'].get(kern) if kern else None
         if k is None or not ms:
             continue
-        flop = k['flop_per_launch'] * scale
-        out[key] = {'kernel': kern, 'flop_per_launch': flop, 'TFLOPs': flop / (ms * 1e-3) / 1e12,
-                    'frac': flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                    'valu_instructions_per_launch': k.get('valu_per_launch', 0) * scale}
+        # per CALL: the reference-sequence inversion is two launches (samples 1..N-1, then the replay of sample 0) and `ms`
+        # times both - tools/fp64_counts.py sums the counted operations over the launches of one call
+        flop = k.get('flop_per_call', k['flop_per_launch']) * scale
+        out[key] = {'kernel': kern, 'flop_per_call': flop, 'launches_per_call': k.get('launches_per_call', 1),
+                    'TFLOPs': flop / (ms * 1e-3) / 1e12, 'frac': flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    'valu_instructions_per_call': k.get('valu_per_call', k.get('valu_per_launch', 0)) * scale,
+                    'salu_per_valu': (k['salu_per_call'] / k['valu_per_call'] if k.get('valu_per_call') else None)}
     return out
 
 
@@ -779,6 +783,19 @@ def main():
     # round trip sanity inside the bench: S^{-1}(S(x)) == x up to the inverse's own accuracy
     err = float((Xinv[:, :N] - Xs[:, :N]).abs().max().item())
     extra = {}
+    if not separable:
+        # the same inversion with the safeguarded Newton root search (an extension, SURVEY section 8a' K5) and the counted
+        # fp64 rates of the three launches (profiles/fp64_counts.json)
+        tm.root_finder = 'newton'
+        for _ in range(2):
+            tm.inverse_device(Z, N, coef=coef, X=Xinv)
+        evn = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in evn:
+            a.record(); tm.inverse_device(Z, N, coef=coef, X=Xinv); b.record()
+        torch.cuda.synchronize()
+        tm.root_finder = 'reference'
+        extra['inverse_newton_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evn]))
+        extra['fp64_counted'] = counted_fp64(args.workload, N, fwd_ms, inv_ms, extra['inverse_newton_ms'])
     if separable:
         ld = tm._empty(N)
         ss = tm._empty(N)

@@ -267,7 +267,11 @@ typedef struct ttm_program {
     const int32_t* h_ftab_off;  /* length D+1: prefix offsets into ftab              */
     const int32_t* h_nb1;       /* length D: nB+1 (distinct x_k functions + 1)      */
     const int32_t* h_complex;   /* length D: bit 0 = component needs the generic interpreter (cross / generic terms),
-                                   bit 1 = integrated component with a dense B set (orders 1..P, no special terms)   */
+                                   bit 1 = integrated component with a dense B set (orders 1..P, no special terms),
+                                   bit 2 = integrated component whose functions of x_k are polynomials / Hermite functions
+                                   only (any orders): the monomial-form kernels of csrc/ttm_int.hip apply,
+                                   bits 8-11 / 12-15 = largest Hermite-function / plain polynomial order among the
+                                   functions of x_k (saturating at 15)                                          */
     /* device copy of the five prefix tables, 5 x (D+1) int32:
        [comp_off | dpar_off | coef_off | fold_off | ftab_off]                        */
     const int32_t* d_offsets;

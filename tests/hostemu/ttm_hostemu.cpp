@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_eval.h"
+#include "../../triangular_transport_toolbox_amd/csrc/ttm_dense.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_uform.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_rng.h"
 
@@ -74,6 +75,14 @@ void comp_of(const ttm_program* p, int k, const double* coef_k, HostComp& h, con
     const int* fb = p->ftab + p->h_ftab_off[k];
     h.c.fslot = fb + cb[TTM_HDR_OFF_FSLOT];
     h.c.fsrc = fb + cb[TTM_HDR_OFF_FSRC];
+}
+
+// same dispatch rule as the library (csrc/ttm_int.hip: ttm_int::usable): integrated maps whose components all have a dense
+// B set go through the monomial-form bodies of csrc/ttm_dense.h
+bool int_dense(const ttm_program* p, int ka, int kb, DenseClass& cls) {
+    if (getenv("TTM_INT_DENSE") && atoi(getenv("TTM_INT_DENSE")) == 0) return false;
+    if (p->monotonicity != TTM_MONO_INTEGRATED || p->family < 0 || p->family > 5) return false;
+    return dense_range_class(p->h_complex, ka, kb, cls);
 }
 
 // same dispatch rule as the library: planned-cache fast path when every component of the range is simple
@@ -374,6 +383,36 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         }
         return 0;
     }
+    DenseClass dcls;
+    if (int_dense(p, k0, k1, dcls)) {
+        std::vector<double> scr(4096);
+        std::vector<HostComp> hc(k1 - k0);
+        for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
+        const double qws = dense_qw_sum(g);
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+            double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
+            double ld = 0.0, ss = 0.0;
+            for (int k = k0; k < k1; ++k) {
+                const Comp& c = hc[k - k0].c;
+                VecSlots w{scr.data()};
+                double S = 0.0, dS = 0.0;
+#define TTM_CALL(PH, PP, RECT)                                                                                  \
+    do {                                                                                                        \
+        if (logdet) dense_sample_forward<PH, PP, RECT, true>(c, g, qws, x, w, Z || sumsq, S, dS);               \
+        else dense_sample_forward<PH, PP, RECT, false>(c, g, qws, x, w, true, S, dS);                           \
+    } while (0)
+                TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+                if (logdet) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
+                if (Z) Z[(int64_t)(k - k0) * ldz + n] = S;
+                ss = fma(S, S, ss);
+            }
+            if (logdet) logdet[n] = ld;
+            if (sumsq) sumsq[n] = ss;
+        }
+        return 0;
+    }
     if (all_fast(p, k0, k1)) {
         std::vector<double> S(k1 - k0);
         for (int64_t n = 0; n < N; ++n) {
@@ -548,11 +587,19 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     const int nacc = g.mono == TTM_MONO_SEPARABLE ? 1 + c.n_mon : 1 + c.n_nm + c.n_mon;
     for (int i = 0; i < nacc; ++i) out[i] = 0.0;
     VecAcc acc{out};
+    DenseClass dcls;
+    const bool dense = int_dense(p, k, k + 1, dcls);
+    const double qws = dense ? dense_qw_sum(g) : 0.0;
     for (int64_t n = 0; n < N; ++n) {
         XSoA xa{X, ldx, n};
         double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
         VecSlots w{scr.data()}, Bv{scr.data() + nb1}, I{scr.data() + 2 * nb1};
         if (g.mono == TTM_MONO_SEPARABLE) sample_objective_sep(c, g, x, w, acc);
+        else if (dense) {
+#define TTM_CALL(PH, PP, RECT) dense_sample_objective<PH, PP, RECT>(c, g, qws, x, w, w, I, acc)
+            TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+        }
         else sample_objective_int(c, g, x, w, Bv, I, acc);
     }
     return 0;
@@ -781,6 +828,9 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
     std::vector<double> scr(4096);
     std::vector<HostComp> hc(k1 - k0);
     for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
+    DenseClass dcls;
+    const bool dense = int_dense(p, k0, k1, dcls);
+    const double qws = dense ? dense_qw_sum(g) : 0.0;
     for (int64_t n = 0; n < N; ++n) {
         XSoA xa{X, ldx, n};
         double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
@@ -789,7 +839,14 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
             VecSlots w{scr.data()};
             const double off = nonmon_sum<double>(c, g, x);
             int it = 0;
-            const double r = sample_root<-1, false>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it);
+            double r = 0.0;
+            if (dense) {
+#define TTM_CALL(PH, PP, RECT) r = dense_sample_root<PH, PP, RECT, false>(c, g, qws, x, w, off, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it)
+                TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+            } else {
+                r = sample_root<-1, false>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it);
+            }
             X[(int64_t)c.kc * ldx + n] = r;
             x.put(c.kc, r);
             if (it > iters[k - k0]) iters[k - k0] = it;
@@ -804,6 +861,9 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
     std::vector<double> scr(4096);
     std::vector<HostComp> hc(k1 - k0);
     for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
+    DenseClass dcls;
+    const bool dense = int_dense(p, k0, k1, dcls);
+    const double qws = dense ? dense_qw_sum(g) : 0.0;
     for (int64_t n = 0; n < N; ++n) {
         XSoA xa{X, ldx, n};
         double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
@@ -812,7 +872,14 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
             VecSlots w{scr.data()};
             const double off = nonmon_sum<double>(c, g, x);
             int it = 0;
-            const double r = sample_root<-1, true>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], -1, it);
+            double r = 0.0;
+            if (dense) {
+#define TTM_CALL(PH, PP, RECT) r = dense_sample_root<PH, PP, RECT, true>(c, g, qws, x, w, off, Z[(int64_t)(k - k0) * ldz + n], -1, it)
+                TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+            } else {
+                r = sample_root<-1, true>(c, g, x, w, off, Z[(int64_t)(k - k0) * ldz + n], -1, it);
+            }
             X[(int64_t)c.kc * ldx + n] = r;
             x.put(c.kc, r);
             if (it > iters[k - k0]) iters[k - k0] = it;

@@ -11,4 +11,4 @@ for W in C2a C3int C5int C5; do
   rm -rf $R/gpurun_out/fp64a_$W $R/gpurun_out/fp64b_$W          # (raw counter CSVs: tens of MB; gpurun_out returns <= 64 MiB)
   echo "$W done"
 done
-cd $R && python3 tools/fp64_counts.py gpurun_out C2a C3int C5int C5 && cp profiles/fp64_counts.json profiles/r03_fp64_pmc_summary.json gpurun_out/
+cd $R && python3 tools/fp64_counts.py gpurun_out C2a C3int C5int C5 && cp profiles/fp64_counts.json profiles/r04_fp64_pmc_summary.json gpurun_out/

@@ -17,7 +17,7 @@ rows = {}
 for line in out.splitlines():
     m = re.search(r'Function Name: (\S+)', line)
     if m:
-        cur = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip().split('(')[0]
+        cur = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip().replace('(anonymous namespace)::', '').split('(')[0]
         rows[cur] = {}
         continue
     m = re.search(r'remark:\s+(VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)', line)

@@ -19,7 +19,7 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '').strip()
+    return name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').strip()
 
 
 def main(dirs):

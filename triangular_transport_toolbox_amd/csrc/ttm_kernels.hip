@@ -26,9 +26,11 @@
 #include <type_traits>
 
 #include "ttm_eval.h"
+#include "ttm_dev.h"
 #include "ttm_rng.h"
 #include "ttm_uform.h"
 #include "ttm_band.h"
+#include "ttm_int.h"
 
 using namespace ttm;
 
@@ -58,136 +60,6 @@ static int check_launch(const char* what) {
 // ---------------------------------------------------------------------------
 // device-side helpers
 // ---------------------------------------------------------------------------
-
-struct DevProg {             // by-value kernel argument (all pointers are global memory)
-    const int* itab;
-    const int* ftab;
-    const int* fdesc;
-    const int* fints;
-    const double* dpar;
-    const double* qx;
-    const double* qw;
-    const int* off;          // 5 x (D+1): comp_off | dpar_off | coef_off | fold_off | ftab_off
-    int D;
-    int Q, family, mono, rect;
-    double delta;
-};
-
-struct LdsSlots {
-    double* base;
-    int stride;
-    __device__ __forceinline__ double get(int i) const { return base[i * stride]; }
-    __device__ __forceinline__ void set(int i, double v) { base[i * stride] = v; }
-};
-
-template <int NS> struct real_of { typedef VecD<NS> type; };
-template <> struct real_of<1> { typedef double type; };
-
-// per-thread scratch slots holding NS samples each
-template <class R>
-struct LdsSlotsN {
-    double* base;
-    int stride;
-    __device__ __forceinline__ R get(int i) const {
-        R r;
-#pragma unroll
-        for (int e = 0; e < lanes_of<R>::value; ++e) set_elem(r, e, base[(i * lanes_of<R>::value + e) * stride]);
-        return r;
-    }
-    __device__ __forceinline__ void set(int i, const R& v) {
-#pragma unroll
-        for (int e = 0; e < lanes_of<R>::value; ++e) base[(i * lanes_of<R>::value + e) * stride] = elem(v, e);
-    }
-};
-
-// NS samples of one thread: sample e is row n0 + e*step (rows beyond N are clamped to N-1 for loads)
-template <int NS>
-struct XSoAN {
-    typedef typename real_of<NS>::type R;
-    const double* X;
-    int64_t ld;
-    int64_t n[NS];
-    __device__ __forceinline__ R operator()(int var) const {
-        R r;
-#pragma unroll
-        for (int e = 0; e < NS; ++e) set_elem(r, e, X[(int64_t)var * ld + n[e]]);
-        return r;
-    }
-};
-
-__device__ __forceinline__ double wave_sum(double v);
-// accumulators of a WAVE: every add sums its argument over the lanes at once (all 64 lanes call, lanes without a sample
-// contribute zero) and lane 0 keeps the running sums in one LDS row per wave.  Per-thread accumulator columns would
-// be nacc x blockDim doubles of LDS - 22 of the 48 doubles per thread that capped the integrated objective kernel at
-// three workgroups (1.5 waves per SIMD) per CU.
-struct WaveAcc {
-    double* row;
-    bool active, first;
-    __device__ __forceinline__ void add(int i, double v) {
-        const double s = wave_sum(active ? v : 0.0);
-        if (first) row[i] += s;
-    }
-};
-
-struct XSoA {
-    const double* X;
-    int64_t ld;
-    int64_t n;
-    __device__ __forceinline__ double operator()(int var) const { return X[(int64_t)var * ld + n]; }
-};
-
-struct XFake {               // TM:4050-4051: zeros except column kc
-    int kc;
-    double t;
-    __device__ __forceinline__ double operator()(int var) const { return var == kc ? t : 0.0; }
-    __device__ __forceinline__ double get(int var) const { return var == kc ? t : 0.0; }
-    __device__ __forceinline__ void get_e(int var, double& xv, double& e) const { xv = get(var); e = fast_exp(-0.25 * (xv * xv)); }
-};
-
-__device__ const double g_erf_table[TTM_ERF_TABLE_LEN] = { TTM_ERF_TABLE_VALUES };
-__device__ const double g_expq_table[TTM_EXPQ_TABLE_LEN] = { TTM_EXPQ_TABLE_VALUES };
-
-extern __shared__ __align__(16) double g_smem[];
-
-#define TTM_CACHE_SLOTS 8     // per-thread column cache (VarCache): 4 x + 4 exp(-x^2/4)
-
-// LDS image: [erf table | column cache (8 x NS x blockDim) | per-thread slots ...]
-template <class R>
-__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots) {
-    double* et = g_smem;
-    for (int i = threadIdx.x; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
-    __syncthreads();
-    cache.base = et + TTM_ERF_TABLE_LEN + threadIdx.x;
-    cache.stride = blockDim.x;
-    slots = et + TTM_ERF_TABLE_LEN + (size_t)TTM_CACHE_SLOTS * lanes_of<R>::value * blockDim.x;
-    Prog g;
-    g.qx = (cdbl_p)P.qx;
-    g.qw = (cdbl_p)P.qw;
-    g.erf_tab = et;
-    g.Q = P.Q;
-    g.family = P.family;
-    g.mono = P.mono;
-    g.rect = P.rect;
-    g.delta = P.delta;
-    return g;
-}
-
-// component k of the program; coefficient / folded arrays are given relative to component kbase
-__device__ __forceinline__ Comp comp_at(const DevProg& P, int k, int kbase, const double* coef, const double* fold) {
-    cint_p off = (cint_p)P.off;
-    const int D1 = P.D + 1;
-    cint_p cb = (cint_p)P.itab + off[k];
-    cdbl_p dp = (cdbl_p)P.dpar + off[D1 + k];
-    cdbl_p cf = coef ? (cdbl_p)coef + (off[2 * D1 + k] - off[2 * D1 + kbase]) : (cdbl_p)P.dpar;
-    cdbl_p fo = fold ? (cdbl_p)fold + (off[3 * D1 + k] - off[3 * D1 + kbase]) : (cdbl_p)P.dpar;
-    return make_comp(cb, dp, cf, fo);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
 
 // ---------------------------------------------------------------------------
 // folded coefficients: block k handles component kfirst + k, one thread per slot
@@ -1937,63 +1809,6 @@ __global__ __launch_bounds__(256) void k_inverse_bisect(DevProg P, int k0, int k
 // K6/K7: objective + gradient partial sums ; K8: Gram partial sums
 // ---------------------------------------------------------------------------
 
-#define TTM_RED_BLOCKS 1024
-#define TTM_HOSTCOEF_MAX 64
-
-// "Which workgroup is the last one?" without a thousand atomics on one address (they serialise in the L2: ~75 ns each,
-// 77 us for the 977 workgroups of an N = 1e6 reduction): workgroups draw a ticket from one of 8 group counters
-// (counter[1 + (blockIdx & 7)], different addresses proceed in parallel), the last of a group draws one from
-// counter[0], and the last of those is the last workgroup of the grid.  Every workgroup has made its partial sums
-// visible (__threadfence) before it draws.  counter: 16 uint32, zero before the first launch; left zero.
-__device__ __forceinline__ bool last_workgroup(unsigned int* counter) {
-    __shared__ int is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int g = blockIdx.x & 7u, ngroups = gridDim.x < 8u ? gridDim.x : 8u;
-        const unsigned int in_group = (gridDim.x - g + 7u) / 8u;
-        int last = 0;
-        if (atomicAdd(counter + 1 + g, 1u) == in_group - 1u) {
-            __threadfence();
-            last = atomicAdd(counter, 1u) == ngroups - 1u ? 1 : 0;
-        }
-        is_last = last;
-    }
-    __syncthreads();
-    if (is_last) {
-        __threadfence();
-        if (threadIdx.x < 9) counter[threadIdx.x] = 0u;
-    }
-    return is_last != 0;
-}
-
-// Results of a finishing workgroup and the completion mark behind them (all threads of the workgroup call; fin: the n
-// results in LDS).  ONE wave stores the results, waits until every one of those stores has been acknowledged
-// (s_waitcnt vmcnt(0): the results span several cache lines, which travel through different L2 channels and would
-// otherwise be free to overtake each other and the mark) and only then stores the mark.  The destination is
-// fine-grained host memory and results and mark are written through at system scope, so the acknowledged stores are on
-// their way in order and a host that sees the mark sees the results.  (A workgroup-scope release alone does not wait for global stores;
-// device- or system-scope fences in every wave - an L2 write-back each - made this launch take 8.5 us.)
-__device__ __forceinline__ void publish(const double* fin, int n, double* out, double* flag, double mark) {
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        // (system-scope stores: write-through.  A plain store may stay dirty in the L2 until the end of the kernel while
-        // the mark - written through - is already visible: the host then reads the results of the evaluation before)
-        for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(out + i, fin[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (flag) {
-            // the mark behind the results: the ONE wave that wrote them drains its stores (gfx9 s_waitcnt encoding:
-            // vmcnt(0), the other counters untouched - this library is built for gfx950 only) and releases the mark at
-            // system scope; the host acquires it (csrc/ttm_optim.cpp: poll_mark)
-#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
-#error "publish(): the raw s_waitcnt immediate below is the gfx9 encoding"
-#endif
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (compiler ordering)
-            __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
-            if (threadIdx.x == 0) __hip_atomic_store(flag, mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
-#define TTM_FIN_MAX 72
 
 // LDS: erf table | per-thread columns [scratch (nscr) | acc (nacc)]
 __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const double* __restrict__ coef_k,
@@ -2019,7 +1834,7 @@ __global__ __launch_bounds__(256) void k_objective(DevProg P, int k, const doubl
     double* accbase = slots + (size_t)nscr * bd;                         // nw rows of nacc running sums
     for (int i = tid; i < nw * nacc; i += bd) accbase[i] = 0.0;
     __syncthreads();
-    WaveAcc acc{accbase + wv * nacc, true, lane == 0};
+    WaveAcc acc{accbase + wv * nacc, true, lane == 63};
     const bool shared_bv = g.mono == TTM_MONO_INTEGRATED && dense_B(c);      // (the host sized the scratch by the same rule)
     LdsSlots w{slots + tid, bd};
     LdsSlots Bv{slots + (shared_bv ? (size_t)0 : (size_t)nb1 * bd) + tid, bd};
@@ -2451,7 +2266,10 @@ static const DeviceInfo& device_info() {
     X(gram_mfma, -1)     /* 0: Gram matrices by the pairwise kernel instead of the matrix cores                      */ \
     X(band_fwd, -1)      /* 0: banded maps through k_forward_hl instead of the push-form kernel (csrc/ttm_band.hip)   */ \
     X(band_inv, -1)      /* 0: banded maps through k_inverse_rt instead of the push-form kernel                      */ \
-    X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */
+    X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */ \
+    X(int_dense, -1)     /* 0: integrated maps with dense B sets through the generic kernels instead of csrc/ttm_int.hip */ \
+    X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
+    X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2480,6 +2298,17 @@ static Tuning& tuning() {
 static int grid_for(int64_t N, int per_block) {
     int64_t tiles = (N + per_block - 1) / per_block;
     const int64_t cap = (int64_t)device_info().cus * 8;       // up to 8 resident workgroups per CU
+    if (tiles > cap) tiles = cap;
+    if (tiles < 1) tiles = 1;
+    return (int)tiles;
+}
+
+// grid of the dense integrated kernels: these spend ~1e3 vector instructions per sample and component, so a launch is a few
+// dozen tile-times per CU - one workgroup per tile lets the dispatcher balance the CUs (a capped persistent grid ends on
+// the slowest CU's whole extra tile)
+static int int_grid_for(int64_t N, int per_block) {
+    int64_t tiles = (N + per_block - 1) / per_block;
+    const int64_t cap = tuning().int_wgs > 0 ? (int64_t)device_info().cus * tuning().int_wgs : ((int64_t)1 << 20);
     if (tiles > cap) tiles = cap;
     if (tiles < 1) tiles = 1;
     return (int)tiles;
@@ -2737,6 +2566,21 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     while (NS > 1 && !pick_block(nsl, 0, NS)) NS >>= 1;
     const int bd = pick_block(nsl, 0, NS);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_forward: %s%lld scratch slots per sample do not fit the LDS budget", "", nsl);
+    if (!sep && tuning().int_dense != 0 && ttm_int::usable(p, k0, k1)) {
+        // every component an integrated one with a dense B set: monomial-form kernels (csrc/ttm_int.hip), one sample per lane
+        const int ibd = pick_block(nsl, 0, 1);
+        const char* name = nullptr;
+        // a small ensemble is split over the components as well, until the launch has ~16 workgroups per CU to balance with
+        const int tiles = ibd ? int_grid_for(N, ibd) : 1;
+        int nchunk = (int)(((int64_t)device_info().cus * 16 + tiles - 1) / tiles);
+        if (tuning().int_chunks > 0) nchunk = tuning().int_chunks;
+        if (nchunk > k1 - k0) nchunk = k1 - k0;
+        if (nchunk < 1) nchunk = 1;
+        const int chunk = (k1 - k0 + nchunk - 1) / nchunk;
+        if (ibd && ttm_int::forward(p, dev_prog(p), k0, k1, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, tiles, chunk, ibd,
+                                    lds_bytes(nsl, ibd, 0, 1), stream, &name) == TTM_OK)
+            return check_launch(name);
+    }
     if (sep && u_on(p) && all_fast(p, k0, k1) && N < ((int64_t)1 << 29)) {
         // U-form: monomial groups + special-term splines staged per component in LDS
         int tab_cap = 0;
@@ -3093,6 +2937,12 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
     const int ns = map_slots(p, k0, k1);
     const int bd = pick_block(ns, 0);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_bisect: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    if (tuning().int_dense != 0 && ttm_int::usable(p, k0, k1)) {
+        const char* name = nullptr;
+        if (ttm_int::root(p, dev_prog(p), k0, k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, cap, 0, int_grid_for(N, bd), bd, lds_bytes(ns, bd, 0),
+                          stream, &name) == TTM_OK)
+            return check_launch(name);
+    }
     auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, false> : k_inverse_bisect<TTM_MONO_INTEGRATED, false>;
     hipLaunchKernelGGL(kern, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1,
                        coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, cap);
@@ -3107,6 +2957,12 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
     const int ns = map_slots(p, k0, k1);
     const int bd = pick_block(ns, 0);
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_newton: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    if (tuning().int_dense != 0 && ttm_int::usable(p, k0, k1)) {
+        const char* name = nullptr;
+        if (ttm_int::root(p, dev_prog(p), k0, k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, nullptr, 1, int_grid_for(N, bd), bd, lds_bytes(ns, bd, 0),
+                          stream, &name) == TTM_OK)
+            return check_launch(name);
+    }
     auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, true> : k_inverse_bisect<TTM_MONO_INTEGRATED, true>;
     hipLaunchKernelGGL(kern, dim3(grid_for(N, bd)), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, (int)k1,
                        coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, (const int*)nullptr);
@@ -3142,11 +2998,15 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     double* fold_k = work;
     double* partial = work + TTM_OBJ_FOLD_MAX;
     hipLaunchKernelGGL(k_fold, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, (int)k, coef_k, fold_k);
+    const char* oname = "k_objective";
+    if (!(!sep && tuning().int_dense != 0 && ttm_int::usable(p, k, k + 1) &&
+          ttm_int::objective(p, P, k, coef_k, fold_k, Xsoa, ldx, N, nscr, nacc, partial, nullptr, nullptr, nullptr, 0.0, nb, bd,
+                             lds_bytes(nscr, bd, 4 * nacc), stream, &oname) == TTM_OK))
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr, bd, 4 * nacc), (hipStream_t)stream, P, (int)k, coef_k,
                        (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial, (unsigned int*)nullptr, (double*)nullptr,
                        (double*)nullptr, 0.0);
     hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
-    return check_launch("k_objective");
+    return check_launch(oname);
 }
 
 int ttm_objective_host(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa, int64_t ldx, int64_t N,
@@ -3185,6 +3045,10 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = i < ncoef ? h_coef_k[i] : 0.0;
     hipLaunchKernelGGL(k_fold_host, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, hc, ncoef, coef_dev, fold_k);
     const bool ticket = nb <= 64;                    // (see ttm_objective_sep_cached)
+    const char* oname = "k_objective";
+    if (!(!sep && tuning().int_dense != 0 && ttm_int::usable(p, k, k + 1) &&
+          ttm_int::objective(p, P, k, coef_dev, fold_k, Xsoa, ldx, N, nscr, nacc, partial, ticket ? (unsigned int*)counter : nullptr,
+                             ticket ? out : nullptr, flag, mark, nb, bd, lds_bytes(nscr, bd, 4 * nacc), stream, &oname) == TTM_OK))
     hipLaunchKernelGGL(k_objective, dim3(nb), dim3(bd), lds_bytes(nscr, bd, 4 * nacc), (hipStream_t)stream, P, (int)k,
                        (const double*)coef_dev, (const double*)fold_k, Xsoa, ldx, N, nscr, nacc, partial,
                        ticket ? (unsigned int*)counter : (unsigned int*)nullptr, ticket ? out : (double*)nullptr, flag, mark);
@@ -3194,7 +3058,7 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
         else
             hipLaunchKernelGGL(k_reduce_partials, dim3((nacc + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, nacc, out);
     }
-    return check_launch("k_objective");
+    return check_launch(oname);
 }
 
 int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,

@@ -612,8 +612,15 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         # per-sample weight slots: components with monotone cross terms, and integrated components whose B functions are
         # the dense order sets 1..P (ttm_eval.h "dense B set": their weights are copied there with the constants folded in)
         dense_b = (not separable and len(b_st) == 0 and len(b_hf) == hdr[HDR_MAXP_HF] and len(b_poly) == hdr[HDR_MAXP_POLY])
-        nslots.append(len(bfuns) + 1 if (len(mnt_idx) or len(xgroups) or dense_b) else 0)
-        complex_all.append(int(complex_comp) | (2 if dense_b else 0))
+        # integrated components whose x_k-functions are polynomials / Hermite functions only (any set of orders, no special
+        # terms): g(t) has the monomial form E(t) H(t) + A(t) that csrc/ttm_dense.h evaluates (flag bit 2); the weights of
+        # their B functions go through the per-sample slots as well
+        poly_b = (not separable and len(b_st) == 0 and len(b_hf) + len(b_poly) > 0)
+        nslots.append(len(bfuns) + 1 if (len(mnt_idx) or len(xgroups) or dense_b or poly_b) else 0)
+        # (bits 8-11 / 12-15: the largest Hermite-function / plain polynomial order among the x_k-functions - the dense
+        # integrated kernels of csrc/ttm_int.hip are instantiated per order class)
+        complex_all.append(int(complex_comp) | (2 if dense_b else 0) | (4 if poly_b else 0) |
+                           (min(int(hdr[HDR_MAXP_HF]), 15) << 8) | (min(int(hdr[HDR_MAXP_POLY]), 15) << 12))
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
         n_mon_all.append(len(mon_terms))
