@@ -78,9 +78,16 @@ def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails(ttm_opt):
     assert np.array_equal(tm.inverse_map(Zr[perm]), Xr[perm])                 # samples are independent: exact
     assert np.array_equal(tm.map(X[perm]), Z[perm])
     assert np.max(np.abs(Xi - X) / tm.X_std) < 5e-4                           # round trip at the table's resolution
+    ld_only, ld_fused = tm._empty(tm._N), tm._empty(tm._N)
+    tm.density_device(tm._Xs, tm._N, logdet=ld_only)
+    assert _last_kernel(tm) == 'k_band_logdet'
+    tm.density_device(tm._Xs, tm._N, logdet=ld_fused, sumsq=tm._empty(tm._N))
+    assert _last_kernel(tm) == 'k_band_density'
+    record_parity('c5_full/logdet(k_band_logdet)_vs_fused_density_pass', relerr(ld_only[:N].cpu().numpy(), ld_fused[:N].cpu().numpy()), 1e-13)
+    assert relerr(ld_only[:N].cpu().numpy(), ld_fused[:N].cpu().numpy()) < 1e-13
     pd, pdo = tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])
     ok = pdo > 0                                                              # (40 dimensions: the density itself underflows towards the tails -
-    record_parity('c5_full/log_pullback_density(k_band_density)_vs_oracle', relerr(np.log(pd[ok]), np.log(pdo[ok])), 1e-10)    # compare its logarithm)
+    record_parity('c5_full/log_pullback_density(k_band_density+k_band_logdet)_vs_oracle', relerr(np.log(pd[ok]), np.log(pdo[ok])), 1e-10)    # compare its logarithm)
     assert relerr(pd, pdo) < 1e-10 and np.array_equal(pd > 0, ok) and relerr(np.log(pd[ok]), np.log(pdo[ok])) < 1e-10
     # the kernels the band kernels replaced stay selectable and agree with them
     ttm_opt('band_fwd', 0); ttm_opt('band_inv', 0)
@@ -107,8 +114,14 @@ def test_c3_full_size_map_inverse_pullback_optimize():
     Xi = tm.inverse_map(Z)
     tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
     assert _last_kernel(tm) == 'k_band_few_inverse'
-    tm.density_device(tm._Xs, tm._N, logdet=tm._empty(tm._N))
+    ld_only = tm._empty(tm._N)
+    tm.density_device(tm._Xs, tm._N, logdet=ld_only)
+    assert _last_kernel(tm) == 'k_band_logdet'               # (the derivative of a separable component reads its own column only)
+    ld_fused = tm._empty(tm._N)
+    tm.density_device(tm._Xs, tm._N, logdet=ld_fused, sumsq=tm._empty(tm._N))
     assert _last_kernel(tm) == 'k_band_few<density>'
+    record_parity('c3_full/logdet(k_band_logdet)_vs_fused_density_pass', relerr(ld_only[:N].cpu().numpy(), ld_fused[:N].cpu().numpy()), 1e-13)
+    assert relerr(ld_only[:N].cpu().numpy(), ld_fused[:N].cpu().numpy()) < 1e-13
     record_parity('c3_full/table_inverse(k_band_few_inverse)_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
     assert relerr(Xi[idx], om.inverse_map(Z[idx])) < 1e-11
     pd, pdo = tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])

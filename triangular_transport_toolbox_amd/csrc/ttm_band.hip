@@ -573,6 +573,220 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
     }
 }
 
+// ---------------------------------------------------------------------------
+// log-determinant only (TM:2569-2712: sum_k log(dS_k/dx_k / sigma_k) per row, no map values): what the pullback /
+// pushforward densities take on the raw samples (the reference evaluates its derivative basis on un-standardised x).
+// dS_k/dx_k of a separable component is a function of x_k ALONE - the derivative of its special-term spline (+ the slope of
+// a linear own term) - so the pass needs no running sums, no exp(-x^2/4), no pushes: per evaluation the spline's column
+// (fma, cvt, med3, mad), its coefficients (six 16-byte LDS reads + the column offset), 21 FMAs for the derivative of the
+// degree-11 local polynomial, one multiplication into the row's running product.  29 vector instructions (the fused
+// density pass k_band_density: 65), bound by the LDS gathers (104 bytes per row and column) and the column stream.
+// The product is renormalised every TWO columns (mantissa kept, binary exponent counted): derivatives of 1e-150 - grid
+// points far outside the samples of a map whose monotone part saturates - cannot underflow it; ONE logarithm per row.
+// The uniform factors (2/h_k of a spline without a linear term beside it, 1/sigma_k) enter once per launch.
+// LDS: [splines of a block of components, as they stand in the U section]
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double band_spline_dd(const double* tab, int nI, double sp_a, double sp_b, double sp_ds, double x) {
+    const int col = band_med3((int)fma(x, sp_b, sp_a), 0, nI - 1);
+    const double* cp = (const double*)((const char*)tab + __umul24((unsigned int)col, TTM_U_TSTRIDE * 8));
+    double c[12];
+#pragma unroll
+    for (int i = 0; i < 12; i += 2) { const D2 v = *(const D2*)(cp + i); c[i] = v.x; c[i + 1] = v.y; }
+    // (c[0] is not part of the derivative; left unused, its half of the first 16-byte read is dropped and the remaining
+    // coefficients are re-paired (c1, c2), (c3, c4) ... as ds_read2_b64 - half the rate of ds_read_b128 and banked modulo 32:
+    // 36 % of the LDS cycles were bank conflicts.  The empty statement keeps the six aligned 16-byte reads.)
+    asm volatile("" :: "v"(c[0]));
+    const double s = fma(x, sp_ds, cp[12]);
+    double a = c[11], da = 0.0;
+#pragma unroll
+    for (int i = 10; i >= 1; --i) {
+        da = fma(da, s, a);
+        a = fma(a, s, c[i]);
+    }
+    return fma(da, s, a);
+}
+
+#ifndef BAND_LD_PF
+#define BAND_LD_PF 3
+#endif
+template <int LAG, int NS>
+__global__ __launch_bounds__(BAND_CT) void k_band_logdet(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0, int ps,
+                                                         const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                         double* __restrict__ logdet, const double* __restrict__ sigma,
+                                                         int64_t rows_per_wg, int Bc) {
+    constexpr int NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT;
+    extern __shared__ __align__(16) double g_lds[];
+    double* tabs = g_lds;
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
+    const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    const int64_t PS = ps;
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const unsigned int c1_32 = (unsigned int)c1;
+    const int64_t ldxb = ldx * 8;
+    // uniform part: sum_k [log(2 / h_k) for a spline without a linear term beside it] - sum_k log(sigma_k), one logarithm
+    // per thread, summed in component order by thread 0
+    __shared__ double s_uni[BAND_UNI];
+    double luni;
+    {
+        const int ncomp = k1 - k0;
+        for (int k = tid; k < ncomp; k += CT) {
+            cdbl_p rec = P + (int64_t)(k0 + k + LAG) * PS;
+            cint_p ri = (cint_p)rec;
+            double v = (ri[10] > 0 && rec[7] == 0.0) ? band_log(rec[4]) : 0.0;
+            if (sigma) v -= band_log(sigma[k]);
+            s_uni[k] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            for (int k = 0; k < ncomp; ++k) acc += s_uni[k];
+            s_uni[0] = acc;
+        }
+        __syncthreads();
+        luni = s_uni[0];
+    }
+    for (int kb = k0; kb < k1; kb += Bc) {
+        const int ke = kb + Bc < k1 ? kb + Bc : k1;
+        const bool first = kb == k0, last = ke == k1;
+        __syncthreads();
+        int tab0;
+        {
+            // (components without special terms have no spline: the block's splines lie between the first and the last that has one)
+            int tb = -1, te = 0;
+            for (int k = kb; k < ke; ++k) {
+                cint_p r = (cint_p)(P + (int64_t)(k + LAG) * PS);
+                if (r[10] > 0) { if (tb < 0) tb = r[11]; te = r[11] + TTM_U_TSTRIDE * r[10]; }
+            }
+            tab0 = tb < 0 ? 0 : tb;
+            const int n = tb < 0 ? 0 : te - tb;
+            for (int i = 2 * tid; i < n; i += 2 * CT) *(D2*)(tabs + i) = *(const D2*)(U_ + tab0 + i);
+        }
+        __syncthreads();
+        for (int tile = 0; tile < ntile; ++tile) {
+            const unsigned int tbase = (unsigned int)c0 + (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+            unsigned int roff[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                unsigned int n = tbase + (unsigned int)(q * HALF);
+                n = n < last_pair ? n : last_pair;
+                roff[q] = n * 8u;
+            }
+            double prod[NS], dmin[NS];
+            int pexp[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) { prod[e] = 1.0; dmin[e] = 0.0; pexp[e] = 0; }
+            const char* xcol = (const char*)X + (int64_t)(kcol0 + (kb - k0)) * ldxb;
+            cdbl_p rec = P + (int64_t)(kb + LAG) * PS;
+            // The column stream is latency bound (a step of a SIMD's four waves is shorter than a loaded memory round trip): the
+            // column of step j + PF is requested at the top of step j, PF + 1 register sets take turns (steps are issued
+            // PF + 1 at a time with the roles rotated: no set is ever copied).  This pass has the registers for PF = 3
+            // (six 1 KB loads in flight per wave: 96 KB per CU).
+            constexpr int PF = BAND_LD_PF, RING = PF + 1;
+            D2 xr[RING][NP];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const char* xc0 = xcol + (int64_t)(kb + i < ke ? i : 0) * ldxb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) xr[i][q] = band_load2(xc0 + roff[q]);
+            }
+            auto step = [&](int j, const D2 (&xc)[NP], D2 (&xn)[NP]) {
+                {
+                    const char* xnext = j + PF < ke ? xcol + PF * ldxb : xcol;       // (past the block: a harmless re-read)
+#if defined(BAND_XL) && BAND_XL == 2                          /* (timing experiment: no column stream) */
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) { xn[q].x = xc[q].x + 1e-9; xn[q].y = xc[q].y - 1e-9; }
+                    (void)xnext;
+#else
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) xn[q] = band_load2(xnext + roff[q]);
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4], own1 = rec[7];
+                cint_p ri = (cint_p)rec;
+                const int nI = ri[10];
+                const double* tab = tabs + (ri[11] - tab0);
+                if (nI > 0 && own1 == 0.0) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int e = 2 * q + h;
+#if defined(BAND_XL) && BAND_XL == 1                          /* (timing experiment: results wrong by construction) */
+                            const double dm = h ? xc[q].y : xc[q].x;
+#else
+                            const double dm = band_spline_dd(tab, nI, sp_a, sp_b, sp_ds, h ? xc[q].y : xc[q].x);
+#endif
+                            prod[e] *= dm;
+                            dmin[e] = fmin(dmin[e], dm);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int e = 2 * q + h;
+                            const double x = h ? xc[q].y : xc[q].x;
+                            const double dm = nI > 0 ? band_spline_dd(tab, nI, sp_a, sp_b, sp_ds, x) : 0.0;
+                            const double dx = fma(dm, sp_ds, fma(x, 0.0, own1));     // (x 0: a NaN / infinite sample stays NaN)
+                            prod[e] *= dx;
+                            dmin[e] = fmin(dmin[e], dx);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                rec += PS; xcol += ldxb;
+            };
+            auto flush = [&]() {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) { int ex; prod[e] = frexp(prod[e], &ex); pexp[e] += ex; }
+            };
+            int j = kb;
+            for (; j + RING <= ke; j += RING) {
+#pragma unroll
+                for (int i = 0; i < RING; ++i) {
+                    step(j + i, xr[i], xr[(i + PF) % RING]);
+                    if (i & 1) flush();
+                }
+                if (RING & 1) flush();
+            }
+#pragma unroll
+            for (int i = 0; i < RING - 1; ++i) {
+                if (j + i < ke) {
+                    step(j + i, xr[i], xr[(i + PF) % RING]);
+                    if (i & 1) flush();
+                }
+            }
+            flush();
+            // a block's share of the row's log-determinant: kept in the output between the blocks (one block at C5)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const unsigned int n = tbase + (unsigned int)(q * HALF);
+                double lv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * q + h;
+                    lv[h] = fma((double)pexp[e], 6.93147180559945286e-01, band_log(prod[e]));
+                    lv[h] = dmin[e] < 0.0 ? NAN : lv[h];
+                    if (last) lv[h] += luni;
+                }
+                if (!first) {
+                    if (n + 1 < c1_32) { const D2 o = *(const D2*)(logdet + n); lv[0] += o.x; lv[1] += o.y; }
+                    else if (n < c1_32) lv[0] += logdet[n];
+                }
+                if (n + 1 < c1_32) band_store2<false>((char*)(logdet + n), lv[0], lv[1]);
+                else if (n < c1_32) logdet[n] = lv[0];
+            }
+        }
+    }
+}
+
 // LDS: [E table: 2 x 801 | splines of the block's components, as they stand in the U section]
 template <int CLS, int LAG>
 __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
@@ -798,10 +1012,18 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
             }
         }
         double ss[NS], prod[NS], dmin[NS];
+        int pexp[NS];
 #pragma unroll
-        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; dmin[e] = 0.0; }
+        for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; dmin[e] = 0.0; pexp[e] = 0; }
 #pragma unroll
         for (int j = 0; j < FD; ++j) {
+            if (DENS && j == 2 && nc > 2) {
+                // the product of a row's derivatives is renormalised after two factors (mantissa kept, binary exponent counted):
+                // derivatives of 1e-150 in every column - grid points far outside the samples of a monotone part that saturates -
+                // would underflow a product of four where the reference's sum of logarithms is finite
+#pragma unroll
+                for (int e = 0; e < NS; ++e) { int ex; prod[e] = frexp(prod[e], &ex); pexp[e] = ex; }
+            }
             if (j < nc) {
                 cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
                 const double start = P[(int64_t)(k0 + j + LAGE) * PS];        // (of the component LAGE columns on)
@@ -843,14 +1065,13 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
             }
         }
         if (DENS) {
-            // (a product of at most four derivatives cannot leave the fp64 range unless one of them does)
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const unsigned int n = tbase + (unsigned int)(q * HALF);
                 if (logdet) {
                     // (a negative derivative makes the row NaN, as the reference's log does: two would cancel in the product)
-                    const double la = dmin[2 * q] < 0.0 ? NAN : band_log(prod[2 * q]) + luni;
-                    const double lb = dmin[2 * q + 1] < 0.0 ? NAN : band_log(prod[2 * q + 1]) + luni;
+                    const double la = dmin[2 * q] < 0.0 ? NAN : fma((double)pexp[2 * q], 6.93147180559945286e-01, band_log(prod[2 * q])) + luni;
+                    const double lb = dmin[2 * q + 1] < 0.0 ? NAN : fma((double)pexp[2 * q + 1], 6.93147180559945286e-01, band_log(prod[2 * q + 1])) + luni;
                     if (n + 1 < N32) band_store2<false>((char*)(logdet + n), la, lb);
                     else if (n < N32) logdet[n] = la;
                 }
@@ -1661,6 +1882,43 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
         lds = s > lds ? s : lds;
     }
     lds += fixed - stat;                                      // (dynamic part)
+    // log-determinant only: the derivative of a separable component is a function of its own column alone (k_band_logdet)
+    static const int ld_on = [] { const char* e = getenv("TTM_BAND_LOGDET"); return e ? atoi(e) : 1; }();
+    if (logdet && !Zsoa && !sumsq && ld_on && k1 - k0 <= BAND_UNI) {
+        const size_t lbudget = lds_per_cu - (size_t)BAND_UNI * 8;
+        int lblk = 0;
+        int LBc = plan_blocks(p, k0, k1, lbudget, &lblk);
+        if (LBc <= 0) {                                       // (a range without any spline: one block)
+            bool any = false;
+            for (int k = k0; k < k1; ++k) any = any || p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > 0;
+            if (!any) LBc = k1 - k0;
+        }
+        if (LBc > 0) {
+            if (block > 0 && block < LBc) LBc = block;
+            size_t llds = 16;
+            for (int kb = k0; kb < k1; kb += LBc) {
+                int tb = -1, te = 0;
+                for (int k = kb; k < kb + LBc && k < k1; ++k) {
+                    const int ni = p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI], to = p->h_ucomp[k * TTM_UC_LEN + TTM_UC_TAB_OFF];
+                    if (ni > 0) { if (tb < 0) tb = to; te = to + TTM_U_TSTRIDE * ni; }
+                }
+                const size_t sbytes = tb < 0 ? 0 : (size_t)(te - tb) * 8;
+                llds = sbytes + 16 > llds ? sbytes + 16 : llds;
+            }
+            if (llds <= lbudget) {
+                typedef void (*lkern_t)(const double*, int64_t, int, int, int, int, const double*, int64_t, int64_t, double*, const double*, int64_t, int);
+                int64_t rows = chunk_rows(N, cus);
+                const bool wide = rows >= 3 * BAND_CT;
+                lkern_t lk = p->u_p_lag == 3 ? (wide ? k_band_logdet<3, 4> : k_band_logdet<3, 2>) : (wide ? k_band_logdet<2, 4> : k_band_logdet<2, 2>);
+                const int64_t grid = (N + rows - 1) / rows;
+                allow_lds((const void*)lk, llds);
+                hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(BAND_CT), llds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                                   (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], (int)p->u_p_stride, Xsoa, ldx, N, logdet, sigma, rows, LBc);
+                if (kernel_name) *kernel_name = "k_band_logdet";
+                return 0;
+            }
+        }
+    }
     const int cls = p->u_h_cls;
     // a few components: everything requested at once, tiles of 2048 rows (k_band_few)
     static const int few_on = [] { const char* e = getenv("TTM_BAND_FEW"); return e ? atoi(e) : 1; }();
