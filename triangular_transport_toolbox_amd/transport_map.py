@@ -33,6 +33,7 @@ when ``standardize_samples`` is False.
 
 import copy
 import ctypes
+import os
 
 import numpy as np
 
@@ -44,6 +45,29 @@ __all__ = ['transport_map']
 def _torch():
     import torch
     return torch
+
+
+_COPY_POOL = None
+
+
+def _parallel_copy(dst, src, threads=8):
+    """dst[...] = src for two host matrices with the same number of rows, split over a few threads (NumPy's copy releases the
+    GIL; one thread moves ~23 GB/s on the GPU boxes, eight ~110 GB/s)."""
+    global _COPY_POOL
+    n = dst.shape[0]
+    if n < 8192:
+        np.copyto(dst, src)
+        return
+    if _COPY_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            usable = os.cpu_count() or 1
+        _COPY_POOL = ThreadPoolExecutor(max(1, min(threads, usable)))
+    parts = _COPY_POOL._max_workers
+    step = -(-n // parts)
+    list(_COPY_POOL.map(lambda r0: np.copyto(dst[r0:r0 + step], src[r0:r0 + step]), range(0, n, step)))
 
 
 class transport_map():
@@ -359,7 +383,87 @@ class transport_map():
         sd = self._std_d if destandardize else None
         _capi.check(self._lib.ttm_export(self._ptr(Xs), Xs.shape[1], N, j0, dout, self._ptr(mean), self._ptr(sd),
                                          self._ptr(out), self._stream()))
-        return out.cpu().numpy() if to_host else out
+        if not to_host:
+            return out
+        if self._dev.type == 'cuda' and out.numel() >= (1 << 17):
+            # a fresh pageable result pays a page fault per 4 KB on its first touch (37 ms for 320 MB against 5.6 ms on the
+            # link): the result is a page-locked buffer of torch's caching host allocator, handed out as the NumPy array
+            torch = _torch()
+            host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+            host.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(self._dev).synchronize()
+            return host.numpy()
+        return out.cpu().numpy()
+
+    # ---- pipelined host boundary of map() / inverse_map() (TM:2391-2437, 3639-3796 take and return NumPy arrays) -------------
+    # A row-major host matrix is cut into chunks of rows; chunk c+1 crosses PCIe (side stream) while chunk c runs through the
+    # layout change, the map kernels and the layout change back (the caller's stream) and chunk c-1 returns (second side
+    # stream) into ONE page-locked result buffer, handed out as the NumPy array - PCIe is full duplex, so a call costs about
+    # one crossing of its larger operand instead of two crossings plus 37 ms of first-touch page faults for a fresh pageable
+    # 320 MB result (tools/pcie_probe.py: 5.6 ms per direction, 6.6 ms for both at once).
+    PIPE_MIN_ROWS = 1 << 18          # below this the plain path (one copy in, one copy out)
+    PIPE_CHUNKS = 8
+
+    def _pipe_ok(self, N):
+        return self._dev.type == 'cuda' and self.host_pipeline and N >= self.PIPE_MIN_ROWS and self._dist() is None
+
+    def _host_pipeline(self, Xhost, dout, stage):
+        """out[r0:r0+n] = stage(rows (n x d_in row-major device tensor), r0, n) for every chunk of rows of the host matrix
+        Xhost; stage launches on the current stream and returns an (n x dout) row-major device tensor.  Returns the
+        (N x dout) result as a NumPy array over page-locked memory."""
+        torch = _torch()
+        N, d_in = Xhost.shape
+        streams = getattr(self, '_pipe_streams', None)
+        if streams is None:
+            streams = self._pipe_streams = (torch.cuda.Stream(device=self._dev), torch.cuda.Stream(device=self._dev))
+        s_in, s_out = streams
+        cur = torch.cuda.current_stream(self._dev)
+        nchunk = max(1, min(self.PIPE_CHUNKS, N // (self.PIPE_MIN_ROWS // 2)))
+        rows = -(-N // nchunk)
+        rows = -(-rows // 4096) * 4096                      # (whole tiles: every chunk starts on an even, 32 KB aligned row)
+        bounds = [(r0, min(N, r0 + rows)) for r0 in range(0, N, rows)]
+        rows_dev = self._empty(N, d_in)
+        out_pin = torch.empty((N, dout), dtype=torch.float64, pin_memory=True)
+        # a pageable source does not overlap with anything (the runtime stages it synchronously: H2D + D2H took their sum): the
+        # chunk is copied into a ring of page-locked staging buffers by a few host threads (320 MB: 2.9 ms with 8 threads
+        # against 5.6 ms on the link) and crosses asynchronously from there
+        ring = getattr(self, '_pipe_ring', None)
+        if ring is None or ring[0][0].numel() < rows * d_in:
+            ring = self._pipe_ring = [[torch.empty(rows * d_in, dtype=torch.float64, pin_memory=True), None] for _ in range(3)]
+        s_in.wait_stream(cur)
+        ev_in = []
+        keep = []
+        for i, (r0, r1) in enumerate(bounds):
+            slot = ring[i % len(ring)]
+            if slot[1] is not None:
+                slot[1].synchronize()                     # (the crossing that last read this buffer is done)
+            stage_in = slot[0][:(r1 - r0) * d_in].view(r1 - r0, d_in)
+            _parallel_copy(stage_in.numpy(), Xhost[r0:r1])
+            with torch.cuda.stream(s_in):
+                rows_dev[r0:r1].copy_(stage_in, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s_in)
+            slot[1] = ev
+            ev_in.append(ev)
+            if i >= 1:                                        # (chunk i - 1 computes while chunk i crosses)
+                self._pipe_step(bounds[i - 1], ev_in[i - 1], rows_dev, stage, out_pin, cur, s_out, keep)
+        self._pipe_step(bounds[-1], ev_in[-1], rows_dev, stage, out_pin, cur, s_out, keep)
+        s_out.synchronize()
+        cur.synchronize()
+        del keep
+        return out_pin.numpy()
+
+    def _pipe_step(self, bound, ev_in, rows_dev, stage, out_pin, cur, s_out, keep):
+        torch = _torch()
+        r0, r1 = bound
+        cur.wait_event(ev_in)
+        out_dev = stage(rows_dev[r0:r1], r0, r1 - r0)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        keep.append(out_dev)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev)
+            out_pin[r0:r1].copy_(out_dev, non_blocking=True)
 
     def _load_samples(self, X):
         torch = _torch()
@@ -789,6 +893,24 @@ class transport_map():
 
     def map(self, X=None):
         """TM:2391-2437: Z[:, k] = S_k(x) for all map components."""
+        if X is not None and self.standardize_samples and not isinstance(X, _torch().Tensor) and self._pipe_ok(np.shape(X)[0]):
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            if X.ndim != 2 or X.shape[1] != self._cm.d_cols:
+                raise ValueError('X must have shape (N, %d)' % self._cm.d_cols)
+            coef = self._pack_coeffs()
+            N, d, D = X.shape[0], self._cm.d_cols, self.D
+            Xs, Z = self._cols(d, N), self._cols(D, N)
+            st = self._stream()
+
+            def stage(rows, r0, n):
+                _capi.check(self._lib.ttm_import(self._ptr(rows), n, d, self._ptr(self._mean_d), self._ptr(self._std_d),
+                                                 self._ptr(Xs, r0), Xs.shape[1], st))
+                _capi.check(self._lib.ttm_forward(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs, r0), Xs.shape[1], n,
+                                                  0, D, self._ptr(Z, r0), Z.shape[1], None, None, None, st))
+                out = self._empty(n, D)
+                _capi.check(self._lib.ttm_export(self._ptr(Z, r0), Z.shape[1], n, 0, D, None, None, self._ptr(out), st))
+                return out
+            return self._host_pipeline(X, D, stage)
         Xs, N = self._samples_for(X)
         coef = self._pack_coeffs()
         Z = self._cols(self.D, N)
@@ -910,7 +1032,7 @@ class transport_map():
         """TM:3639-3796: sequential inversion of the components; the three
         conditioning shapes of the reference."""
         torch = _torch()
-        Z = np.array(Z, dtype=float, copy=True)
+        Z = np.asarray(Z, dtype=float)                   # (never written to: no copy)
         N = Z.shape[0]
         d = self._cm.d_cols
         skip = self.skip_dimensions
@@ -931,6 +1053,24 @@ class transport_map():
         ncomp = k1 - k0
         if Z.shape[-1] < ncomp:
             raise IndexError('Z has %d columns, %d are needed' % (Z.shape[-1], ncomp))
+        coef = self._pack_coeffs()
+        table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
+        if table and Xstar_cols is None and Z.shape[1] == ncomp and Z.flags.c_contiguous and self._pipe_ok(N):
+            # rows are independent in the table inverse (no sample-0 guard): chunks of rows stream through
+            # layout change -> lookups -> layout change back while their neighbours cross PCIe
+            st = self._stream()
+            Xs, Zs = self._cols(d, N, zero=True), self._cols(ncomp, N)
+            self._inverse_table(coef, k0, k1, Zs, Xs, 0)            # (tables of this coefficient vector: built once, no rows)
+            mean = self._mean_d if self.standardize_samples else None
+            sd = self._std_d if self.standardize_samples else None
+
+            def stage(rows, r0, n):
+                _capi.check(self._lib.ttm_import(self._ptr(rows), n, ncomp, None, None, self._ptr(Zs, r0), Zs.shape[1], st))
+                self._inverse_table(coef, k0, k1, Zs, Xs, n, row0=r0)
+                out = self._empty(n, d)
+                _capi.check(self._lib.ttm_export(self._ptr(Xs, r0), Xs.shape[1], n, 0, d, self._ptr(mean), self._ptr(sd), self._ptr(out), st))
+                return out
+            return self._host_pipeline(Z, d, stage)[:, skip:]
         Xs = self._cols(d, N, zero=True)
         if Xstar_cols is not None and E > 0:
             cols = np.array(Xstar_cols, dtype=float, copy=True)
@@ -938,9 +1078,11 @@ class transport_map():
                 cols -= self.X_mean[:E]
                 cols /= self.X_std[:E]
             Xs[:E, :N].copy_(torch.from_numpy(np.ascontiguousarray(cols.T)))
-        Zs = self._to_dev(np.ascontiguousarray(Z[:, :ncomp].T))
-        coef = self._pack_coeffs()
-        table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity'
+        # the layout change runs on the device, into a matrix with a padded (even) leading dimension: what the large-ensemble
+        # kernels need (a host transpose gave odd ensemble sizes an odd leading dimension, i.e. the generic kernel)
+        Zrow = self._to_dev(np.ascontiguousarray(Z[:, :ncomp]))
+        Zs = self._cols(ncomp, N)
+        _capi.check(self._lib.ttm_import(self._ptr(Zrow), N, ncomp, None, None, self._ptr(Zs), Zs.shape[1], self._stream()))
         if table:
             self._inverse_table(coef, k0, k1, Zs, Xs, N)
         else:
@@ -948,7 +1090,7 @@ class transport_map():
         X = self._export(Xs, N, 0, d, self.standardize_samples)
         return X[:, skip:]
 
-    def _inverse_table(self, coef, k0, k1, Zs, Xs, N, resolution=1001, start_distance=10):
+    def _inverse_table(self, coef, k0, k1, Zs, Xs, N, resolution=1001, start_distance=10, row0=0):
         """TM:3987-4084 for all components: tabulate, index and look up on the device.  interp1d sorts its
         abscissae (stable) first; monotone tables are already sorted, which the index kernel verifies -
         only an unsorted table (flat, noisy tails) takes the host detour that applies the sort."""
@@ -976,9 +1118,11 @@ class transport_map():
                                                           ctypes.c_void_p(uns_d.data_ptr()), st))
             cache[tkey] = (out_d, tmin_d, tmax_d, bkt_d, int(uns_d.cpu().max().item()) == 0)    # (one copy of D flags, no reduction launch)
         out_d, tmin_d, tmax_d, bkt_d, is_sorted = cache[tkey]
+        if N == 0:
+            return                                      # (tables only)
         if is_sorted:
             _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                    self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(out_d),
+                                                    self._ptr(Zs, row0), Zs.shape[1], self._ptr(Xs, row0), Xs.shape[1], N, self._ptr(out_d),
                                                     self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
                                                     self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
             return
@@ -995,7 +1139,7 @@ class transport_map():
         bkt_d = self._to_dev(bkt, dtype=torch.int32)
         tmin_d, tmax_d = self._to_dev(tmin), self._to_dev(tmax)
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                self._ptr(Zs), Zs.shape[1], self._ptr(Xs), Xs.shape[1], N, self._ptr(tab_x_d),
+                                                self._ptr(Zs, row0), Zs.shape[1], self._ptr(Xs, row0), Xs.shape[1], N, self._ptr(tab_x_d),
                                                 self._ptr(tab_y_d), resolution, resolution, None, self._ptr(tmin_d),
                                                 self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
 
@@ -1525,6 +1669,10 @@ class transport_map():
     # device entry points: read the per-vector checks (spline fit errors, table sortedness) at validate() instead of
     # behind every new coefficient vector (see validate())
     deferred_checks = False
+
+    # map() / inverse_map() on host arrays of PIPE_MIN_ROWS rows or more: chunks of rows stream over PCIe, through the
+    # kernels and back on three streams (see _host_pipeline); False = one copy in, one copy out
+    host_pipeline = True
 
     def _optimize_separable_native(self, A, k, x0, bounds):
         """TM:3108-3114 for one component without leaving the library; None when the native loop does not apply
