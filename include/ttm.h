@@ -410,6 +410,12 @@ int ttm_inverse_table_build(const ttm_program* p, const double* coef, const doub
  * the host does that rare case - and tmin/tmax/bkt of that row are not valid).                          */
 int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32_t nb, double* tmin, double* tmax,
                             int32_t* bkt, int32_t* unsorted, void* stream);
+/* ttm_inverse_table_build_index: ttm_inverse_table_build followed by ttm_inverse_table_index of its output as ONE launch
+ * (one workgroup per component; T <= 2048): what a new coefficient vector costs before its first table lookup
+ * (TM:4047-4058 rebuilds the table in every inverse_map).  Same bits as the two calls.                      */
+int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
+                                  const double* pts, int32_t T, int32_t nb, double* out, double* tmin, double* tmax,
+                                  int32_t* bkt, int32_t* unsorted, void* stream);
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                       const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,

@@ -728,6 +728,13 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
     return 0;
 }
 
+int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
+                                  int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
+                                  void* stream) {
+    const int rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
+    return rc ? rc : ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+}
+
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
                       int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,

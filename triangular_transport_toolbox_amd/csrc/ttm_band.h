@@ -24,6 +24,9 @@ namespace ttm_band {
 // column into its padding slot.  U: the U section of the folded-coefficient buffer.
 int build_records(const ttm_program* p, double* U, void* stream);
 
+// doubles per push record of degree class `cls` with `lag` groups (what u_p_stride must be)
+int record_stride(int cls, int lag);
+
 // can [k0, k1) of this program run through the band kernels?
 bool usable(const ttm_program* p, int k0, int k1);
 

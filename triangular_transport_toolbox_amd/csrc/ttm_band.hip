@@ -1812,6 +1812,8 @@ static int64_t chunk_rows(int64_t N, int cus) {
     return rows;
 }
 
+int record_stride(int cls, int lag) { return rec_stride(cls, lag); }
+
 bool usable(const ttm_program* p, int k0, int k1) {
     return p && p->u_enabled && (p->u_p_lag == 2 || (p->u_p_lag == 3 && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 && p->u_h_cls <= 3 &&
            p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 && p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);

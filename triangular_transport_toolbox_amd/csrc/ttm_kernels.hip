@@ -444,14 +444,26 @@ struct UTabs {               // by-value kernel argument
 // one workgroup per component: monomial coefficients of the groups, spline of the summed special terms, fit check
 // (1024 threads per component: the node, fit and verification phases each hand out nI x 12..13 independent evaluations -
 // ~450 at C5 - and a workgroup of four waves walked them in two dependent rounds: 15.8 us per launch, 9 with sixteen)
-__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ fold, double* __restrict__ U,
-                                                int64_t err_off, int64_t h_off, int h_cls, int h_ng) {
+// coef != nullptr: the workgroup first folds the component's coefficients itself (what k_fold does: one thread per slot, fixed
+// summation order - the same bits) - a new coefficient vector then costs ONE launch for fold + U-form + push records instead
+// of three (k_fold 6.3 us, k_uform 10 us, k_band_records 4.9 us and the gaps between them: profiles/r03_v2_*).
+// p_lag > 0: the component's share of the push records (uform_scatter_push_records) behind its hot record.
+__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ coef, double* __restrict__ fold,
+                                                double* __restrict__ U, int64_t err_off, int64_t h_off, int h_cls, int h_ng,
+                                                int64_t p_off, int p_lag, int p_stride) {
     __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
     __shared__ double red[2][16];
     const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
     const int D1 = P.D + 1;
     const int* uc = T.ucomp + k * TTM_UC_LEN;
     const int* fd = P.fdesc + k * TTM_FDESC_LEN;
+    if (coef) {
+        const int* off = P.off;
+        fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k], coef + off[2 * D1 + k], fold + off[3 * D1 + k], tid, bd);
+        __syncthreads();
+        fold_st8(fd, P.fints, fold + off[3 * D1 + k], tid, bd);
+        __syncthreads();
+    }
     const double* foldk = fold + P.off[3 * D1 + k];
     const double* geo = T.ugeo + 2 * k;
     uform_build_groups(uc, T.ugrp, fd, T.umono, geo, foldk, U, tid, bd);
@@ -466,6 +478,11 @@ __global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double
         uform_spline_fit(uc, fd, geo, foldk, ybuf, U, tid, bd);
         __syncthreads();
         uform_spline_verify(uc, fd, geo, foldk, U, tid, bd, ev, ed);
+    }
+    if (h_cls > 0 && p_lag > 0) {
+        // (behind the spline fit: it writes whole columns, the padding slot that takes the column's offset included)
+        __syncthreads();
+        uform_scatter_push_records(T.ucomp, T.ugrp, U, h_off, h_cls, h_ng, p_off, p_lag, p_stride, P.D, k, tid, bd);
     }
     if (ev != ev) ev = INFINITY;
     if (ed != ed) ed = INFINITY;
@@ -1665,6 +1682,61 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
     }
 }
 
+// k_table_build + k_table_index as ONE launch, one workgroup per component (blockIdx.x = component k0 + x): the table's T
+// points by the same evaluator as k_table_build (the same bits), kept in LDS for the index phase of k_table_index behind a
+// barrier - a new coefficient vector's inverse tables cost one launch instead of two (6.8 + 6.9 us and the gap).
+__global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, const double* __restrict__ coef,
+                                                           const double* __restrict__ fold, const double* __restrict__ pts, int T,
+                                                           int nb, double* __restrict__ out, double* __restrict__ tmin,
+                                                           double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted) {
+    __shared__ double xs[2048];
+    __shared__ int bq[2048];
+    __shared__ int bad;
+    double* slots;
+    CacheStore<double> cst;
+    Prog g = make_prog_lds(P, cst, slots);
+    g.mono = TTM_MONO_SEPARABLE;
+    LdsSlots w{slots + threadIdx.x, (int)blockDim.x};
+    const int k = k0 + blockIdx.x;
+    const Comp c = comp_at(P, k, 0, coef, fold);
+    if (threadIdx.x == 0) bad = 0;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const double t = pts[i];
+        double v, dv;
+        if (c.n_mnt == 0 && c.n_xgrp == 0) {
+            const UniformW uw{c.fold + c.off_wb};
+            g_eval<false>(c, g, t, uw, v, dv);
+        } else {
+            XFake x{c.kc, t};
+            mon_weights<double>(c, g, x, w);
+            g_eval<false>(c, g, t, w, v, dv);
+        }
+        out[(int64_t)blockIdx.x * T + i] = v;
+        xs[i] = v;
+    }
+    __syncthreads();
+    int mybad = 0;
+    for (int i = threadIdx.x + 1; i < T; i += blockDim.x) mybad |= !(xs[i - 1] <= xs[i]);   // also flags NaN
+    if (mybad) atomicOr(&bad, 1);
+    const double lo = xs[0], hi = xs[T - 1];
+    double scale, bias;
+    table_bucket_params(lo, hi, nb, scale, bias);
+    for (int i = threadIdx.x; i < T; i += blockDim.x) bq[i] = table_bucket(xs[i], scale, bias, nb);
+    __syncthreads();
+    if (threadIdx.x == 0) { tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad; }
+    for (int q = threadIdx.x; q <= nb; q += blockDim.x) {
+        int a = 0, b = T;
+        if (q == nb) a = T;
+        else if (q > 0) {
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (bq[mid] < q) a = mid + 1; else b = mid;
+            }
+        }
+        bkt[(int64_t)blockIdx.x * (nb + 1) + q] = a;
+    }
+}
+
 // One sample per thread, no workgroup-level staging: the 1001-point tables of all components stay in
 // L2 / L1 (8 KB each, shared by every wave) and each sample gathers the handful of entries its search
 // needs: one 16-byte gather of the bucket index narrows the range to a few entries, two or three
@@ -2269,7 +2341,9 @@ static const DeviceInfo& device_info() {
     X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */ \
     X(int_dense, -1)     /* 0: integrated maps with dense B sets through the generic kernels instead of csrc/ttm_int.hip */ \
     X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
-    X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */
+    X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
+    X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
+    X(table_fused, -1)   /* 0: inverse tables as two launches (k_table_build, k_table_index) instead of one               */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2530,16 +2604,23 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* strea
     int rc = validate(p, 0, p ? p->D : 0);
     if (rc) return rc;
     if (!coef || !fold) return set_err(TTM_E_ARG, "ttm_fold: bad arguments%s");
-    hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
     if (p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo) {
         for (int k = 0; k < p->D; ++k)
             if (p->h_ucomp && p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > TTM_U_NI_MAX)
                 return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
         const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
-        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)fold,
-                           fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng);
-        if (p->u_p_lag > 0 && p->u_h_cls > 0) ttm_band::build_records(p, fold + fold_base_size(p), stream);       // push records of banded maps
+        // ONE launch, one workgroup per component: fold -> monomial groups, special-term spline, fit check -> hot record ->
+        // the component's share of the push records of a banded map (option fold_fused = 0: the three launches of round 3)
+        const bool fused = tuning().fold_fused != 0;
+        const bool records = p->u_p_lag > 0 && p->u_h_cls > 0 && p->u_p_stride == ttm_band::record_stride(p->u_h_cls, p->u_p_lag);
+        if (!fused) hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
+        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, fused ? coef : (const double*)nullptr, fold,
+                           fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng,
+                           (int64_t)p->u_p_off, (fused && records) ? (int)p->u_p_lag : 0, (int)p->u_p_stride);
+        if (!fused && p->u_p_lag > 0 && p->u_h_cls > 0) ttm_band::build_records(p, fold + fold_base_size(p), stream);       // push records of banded maps
+        return check_launch(fused ? "k_uform<fold, records>" : "k_fold");
     }
+    hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
     return check_launch("k_fold");
 }
 
@@ -2790,6 +2871,29 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
     hipLaunchKernelGGL(k_table_index, dim3(ncomp), dim3(256), 0, (hipStream_t)stream, tab_x, (int)T, (int)nb, tmin, tmax, bkt,
                        unsorted);
     return check_launch("k_table_index");
+}
+
+int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
+                                  int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
+                                  void* stream) {
+    int rc = validate(p, k0, k1);
+    if (rc) return rc;
+    if (!coef || !fold || !pts || !out || !tmin || !tmax || !bkt || !unsorted || T < 2 || T > 2048 || nb < 1 || nb > 4096)
+        return set_err(TTM_E_ARG, "ttm_inverse_table_build_index: bad arguments%s");
+    if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
+    if (tuning().table_fused == 0) {
+        rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
+        return rc ? rc : ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+    }
+    const int ns = map_slots(p, k0, k1);
+    const size_t stat = 2048 * 8 + 2048 * 4 + 64;               // (the kernel's static arrays)
+    int bd = 0;
+    for (int b = 256; b >= 64; b >>= 1)
+        if (lds_bytes(ns, b, 0) + stat <= (size_t)kLdsBudget) { bd = b; break; }
+    if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_table_build_index: %s%lld scratch slots do not fit the LDS budget", "", ns);
+    hipLaunchKernelGGL(k_table_build_index, dim3(k1 - k0), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, coef,
+                       fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted);
+    return check_launch("k_table_build_index");
 }
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,

@@ -215,6 +215,91 @@ TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_o
     }
 }
 
+// Push records (include/ttm.h "push records", csrc/ttm_band.hip) from the hot record of ONE component: every slot of the
+// P section has exactly one writer - the component it describes - so the workgroup that has just built a component's hot
+// record scatters its share at once (no second launch behind the U-form builder):
+//   * record r = k            : [0], [1]  chain starts of component k (its constants + the constant terms of its groups)
+//   * record r = k + lag      : [2..7]    spline geometry, {NI, TAB_OFF}, {k, 0}, slope of the linear own term; padding zeros
+//   * record r = k + lag - lg : block lg-1: the group of component k that reads the column lg in front of it (zeros: none)
+//   * the local-coordinate offset of every spline column of component k (padding slot 12 of the column)
+// Slots that describe no component - the records of the lag columns in front of the first component, chain starts and
+// blocks beyond the last - are zeroed by the first / last component's workgroup.  Values and summation order are those of
+// the stand-alone builder it replaces (k_band_records), bit for bit.  Call after the hot record is complete (barrier).
+TTM_HD void uform_scatter_push_records(const int* ucomp, const int* ugrp, double* U, int64_t h_off, int cls, int ng, int64_t p_off,
+                                       int lag, int ps, int D, int k, int first, int stride) {
+    const int DB = u_h_db(cls), DA = u_h_da(cls), GS = u_h_gs(cls), GP = DB + 1 + DA;
+    const int hs = TTM_H_HDR + ng * GS;
+    const int* uc = ucomp + k * TTM_UC_LEN;
+    const double* h = U + h_off + (int64_t)k * hs;
+    double* P = U + p_off;
+    const int n_grp = uc[TTM_UC_N_GRP];
+    const bool own = (uc[TTM_UC_FLAGS] & TTM_UCF_OWN) != 0;
+    const double* ownc = U + uc[TTM_UC_DBL_OFF] + 4 + 16 * n_grp + 8;          // {constant, slope} of the linear own term
+    // chain starts of component k -> record k
+    for (int i = first; i < 2; i += stride) {
+        double v = i == 0 ? h[2] : h[7];
+        for (int g = 0; g < n_grp; ++g) v += h[TTM_H_HDR + g * GS + 2 + DB];
+        if (i == 0) v += own ? ownc[0] : 0.0;
+        P[(int64_t)k * ps + i] = v;
+    }
+    // header and padding of record k + lag
+    {
+        double* rec = P + (int64_t)(k + lag) * ps;
+        for (int i = 2 + first; i < ps; i += stride) {
+            if (i >= TTM_P_HDR && i < TTM_P_HDR + lag * GP) continue;
+            double v = 0.0;
+            if (i == 2) v = h[3] + 1.0;
+            else if (i == 3) v = h[4];
+            else if (i == 4) v = h[5];
+            else if (i == 5) v = u_pack2(uc[TTM_UC_NI], uc[TTM_UC_TAB_OFF]);
+            else if (i == 6) v = u_pack2(k, 0);
+            else if (i == 7) v = own ? ownc[1] : 0.0;
+            rec[i] = v;
+        }
+    }
+    // group blocks
+    for (int idx = first; idx < lag * GP; idx += stride) {
+        const int l = idx / GP, j = idx % GP;
+        int g = -1;
+        for (int q = 0; q < n_grp; ++q)
+            if (uc[TTM_UC_KC] - ugrp[(uc[TTM_UC_GRP_OFF] + q) * TTM_UG_LEN + TTM_UG_VAR] == l + 1) { g = q; break; }
+        double v = 0.0;
+        if (g >= 0) {
+            const double* gr = h + TTM_H_HDR + g * GS;
+            v = j <= DB ? gr[1 + j] : gr[2 + DB + (j - DB)];
+        }
+        P[(int64_t)(k - (l + 1) + lag) * ps + TTM_P_HDR + idx] = v;
+    }
+    // local-coordinate offsets of the spline columns
+    {
+        double* tab = U + uc[TTM_UC_TAB_OFF];
+        for (int c = first; c < uc[TTM_UC_NI]; c += stride) tab[c * TTM_U_TSTRIDE + 12] = fma(2.0, h[3], -(double)(2 * c - 1));
+    }
+    // what belongs to no component
+    if (k == 0) {
+        for (int idx = first; idx < lag * ps; idx += stride) {
+            const int r = idx / ps, i = idx % ps;
+            if (i < 2) continue;                                              // (chain starts: component r's)
+            if (i >= TTM_P_HDR && i < TTM_P_HDR + lag * GP) {
+                const int l = (i - TTM_P_HDR) / GP;
+                if ((r - lag) + l + 1 >= 0) continue;                         // (a component's block)
+            }
+            P[(int64_t)r * ps + i] = i == 6 ? u_pack2(-1, 0) : 0.0;
+        }
+    }
+    if (k == D - 1) {
+        for (int idx = first; idx < (D + lag) * ps; idx += stride) {
+            const int r = idx / ps, i = idx % ps;
+            if (i < 2) {
+                if (r >= D) P[(int64_t)r * ps + i] = 0.0;
+            } else if (i >= TTM_P_HDR && i < TTM_P_HDR + lag * GP) {
+                const int l = (i - TTM_P_HDR) / GP;
+                if ((r - lag) + l + 1 >= D) P[(int64_t)r * ps + i] = 0.0;
+            }
+        }
+    }
+}
+
 // one column of the spline at local coordinate s: value and d/ds
 TTM_HD void u_spline_column(const double* col, double s, double& p, double& dp) {
     double a = col[TTM_U_DEG], da = 0.0;

@@ -840,11 +840,10 @@ class transport_map():
         tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
         bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
         uns_d = self._empty(ncomp, dtype=torch.int32)
-        _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), 0, ncomp,
-                                                      self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
-        _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
-                                                      self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
-                                                      ctypes.c_void_p(uns_d.data_ptr()), st))
+        _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), 0, ncomp,
+                                                            self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
+                                                            self._ptr(tmin_d), self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
+                                                            ctypes.c_void_p(uns_d.data_ptr()), st))
         return (0, ncomp, resolution, start_distance, nb), (out_d, tmin_d, tmax_d, bkt_d, uns_d)
 
     def _inv_nb(self):
@@ -1111,11 +1110,18 @@ class transport_map():
             tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
             bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
             uns_d = self._empty(ncomp, dtype=torch.int32)
-            _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
-                                                          self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
-            _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
-                                                          self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
-                                                          ctypes.c_void_p(uns_d.data_ptr()), st))
+            if resolution <= 2048:
+                # table + its index (range, sortedness, bucket index) in one launch
+                _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                                    self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
+                                                                    self._ptr(tmin_d), self._ptr(tmax_d),
+                                                                    ctypes.c_void_p(bkt_d.data_ptr()), ctypes.c_void_p(uns_d.data_ptr()), st))
+            else:
+                _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
+                                                              self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
+                _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
+                                                              self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
+                                                              ctypes.c_void_p(uns_d.data_ptr()), st))
             cache[tkey] = (out_d, tmin_d, tmax_d, bkt_d, int(uns_d.cpu().max().item()) == 0)    # (one copy of D flags, no reduction launch)
         out_d, tmin_d, tmax_d, bkt_d, is_sorted = cache[tkey]
         if N == 0:
