@@ -382,6 +382,44 @@ def entf_config(torch, N=100000, cycles=2000):
                 rmse_last=float(np.sqrt(np.mean((ens.mean(axis=0) - truth) ** 2))))
 
 
+def ents_block_config(torch, N=100000, steps=20):
+    """BASELINE configs[3], second half: the 6-column block map of the Ensemble Transport Smoother (example_07.py:368-465:
+    X is N x 6, skip_dimensions 3, D = 3, dense nonmonotone blocks over all earlier columns, linear monotone terms, L2 0.05),
+    N = 1e5.  One backward step = reset -> optimize -> map -> inverse_map with X_star through the class (host arrays in and
+    out, as entf.smooth drives it); the filtering ensembles are Lorenz-63 forecasts / analyses of a synthetic run."""
+    from triangular_transport_toolbox_amd import entf
+    rng = np.random.default_rng(0)
+    ana = rng.standard_normal((N, 3)) * [8.0, 9.0, 8.0] + [0.0, 0.0, 25.0]
+    fc = entf.rk4(ana, 0.05, 2)
+    fc_next = entf.rk4(fc, 0.05, 2)
+    tm = entf.make_smoother_map(N, maxorder=3, lmbda=0.05)
+    import copy
+
+    def step(Xnext):
+        map_input = np.column_stack((fc_next, fc))
+        tm.reset(copy.copy(map_input))
+        tm.optimize()
+        Zp = tm.map(map_input)
+        return tm.inverse_map(X_star=Xnext, Z=Zp)
+    Xs = fc_next + 0.1 * rng.standard_normal((N, 3))
+    for _ in range(3):
+        out = step(Xs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step(Xs)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tm.forward_device(tm._Xs, tm._N)
+    fk = _last_kernel(tm)
+    tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
+    ik = _last_kernel(tm)
+    return dict(workload='C4 block map: Ensemble Transport Smoother backward step, Example-07 map (6 columns, D = 3, skip 3, order 3, '
+                         'L2 0.05), reset -> optimize -> map -> inverse_map with X_star through the class (host arrays)',
+                N=N, steps=steps, ms_per_step=1e3 * el / steps, forward_kernel=fk, inverse_kernel=ik,
+                finite=bool(np.all(np.isfinite(out))))
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -928,6 +966,10 @@ def main():
             extra['other_configs']['C4'] = entf_config(torch)
         except Exception as exc:                       # noqa: BLE001
             extra['other_configs_C4_error'] = repr(exc)
+        try:
+            extra['other_configs']['C4_block_map'] = ents_block_config(torch)
+        except Exception as exc:                       # noqa: BLE001
+            extra['other_configs_C4_block_map_error'] = repr(exc)
     fl_pre = flops_per_eval(tm) if separable else None
     out = None
     if rank == 0:

@@ -270,6 +270,7 @@ typedef struct ttm_program {
                                    bit 1 = integrated component with a dense B set (orders 1..P, no special terms),
                                    bit 2 = integrated component whose functions of x_k are polynomials / Hermite functions
                                    only (any orders): the monomial-form kernels of csrc/ttm_int.hip apply,
+                                   bit 3 = the component has special terms (LET / RET / RBF / iRBF) somewhere,
                                    bits 8-11 / 12-15 = largest Hermite-function / plain polynomial order among the
                                    functions of x_k (saturating at 15)                                          */
     /* device copy of the five prefix tables, 5 x (D+1) int32:

@@ -58,7 +58,7 @@ for w in sys.argv[2:]:
     inv = [k for k in kernels if k.startswith(('k_inverse_bisect', 'k_int_root'))]
     bis = [k for k in inv if launches_per_call(k) == 2]
     newt = [k for k in inv if launches_per_call(k) == 1]
-    out[w] = {'N': N, 'kernels': kernels, 'forward_kernel': pick('k_int_forward') or pick('k_forward') or pick('k_band_forward'),
+    out[w] = {'N': N, 'kernels': kernels, 'forward_kernel': pick('k_int_forward') or pick('k_band_forward') or pick('k_forward'),
               'inverse_kernel': bis[0] if bis else (pick('k_band_inverse') or pick('k_inverse_rt')),
               'newton_kernel': newt[0] if newt else None,
               'definition': 'flop_per_call = 64 lanes x (2 FMA + ADD + MUL + TRANS) fp64 wave-instructions summed over the launches '

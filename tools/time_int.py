@@ -35,12 +35,12 @@ def main():
         Xs, Z, Xinv = tm._Xs, tm._cols(D, N), tm._cols(d, N, zero=True)
         res = {}
         keep = {}
-        for mode in (0, 8, -1):
+        for mode in (0, 12, 16, -1):
             tm._lib.ttm_reset_options()
             if mode == 0:
                 tm._lib.ttm_set_option(b'int_dense', 0)
             elif mode > 0:
-                tm._lib.ttm_set_option(b'int_chunks', 1)
+                tm._lib.ttm_set_option(b'int_wgs', mode)
             r = {}
             r['forward_ms'] = ev_ms(lambda: tm.forward_device(Xs, N, coef=coef, Z=Z), 10)
             r['forward_kernel'] = bench._last_kernel(tm)
@@ -66,7 +66,7 @@ def main():
             r['objective_call_ms'] = 1e3 * (time.perf_counter() - t0) / nrep
             keep[(mode, 'G')] = np.array(G)
             keep[(mode, 'J')] = tm.objective_function(c, k, div)
-            res['generic' if mode == 0 else ('dense_1chunk' if mode > 0 else 'dense')] = r
+            res['generic' if mode == 0 else ('dense_wgs%d' % mode if mode > 0 else 'dense')] = r
         tm._lib.ttm_reset_options()
         res['max_abs_diff'] = {'Z': float((keep[(0, 'Z')] - keep[(-1, 'Z')]).abs().max().item()),
                                'X_bisect': float((keep[(0, 'Xb')] - keep[(-1, 'Xb')])[:, 1:N].abs().max().item()),

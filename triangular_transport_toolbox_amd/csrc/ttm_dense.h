@@ -223,9 +223,12 @@ TTM_HD void dense_sample_forward(const Comp& c, const Prog& p, double qw_sum, Va
     DenseMonoSet<PH, PP, RECT> s;
     dense_monomials<PH, PP>(c, p, w, s.d);
     s.qw_sum = qw_sum;
+    // (the nonmonotone part first: behind the node loop it would keep the component's table pointers alive across it)
+    const double xk = x.get(c.kc);
+    const double nm = want_value ? nonmon_sum<double>(c, p, x) : 0.0;
     double m, dm;
-    mon_eval<TTM_MONO_INTEGRATED, DER>(c, p, x.get(c.kc), s, m, dm);
-    S = want_value ? nonmon_sum<double>(c, p, x) + m : m;
+    mon_eval<TTM_MONO_INTEGRATED, DER>(c, p, xk, s, m, dm);
+    S = want_value ? nm + m : m;
     dS = dm;
 }
 

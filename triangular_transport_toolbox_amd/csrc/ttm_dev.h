@@ -103,11 +103,15 @@ extern __shared__ __align__(16) double g_smem[];
 #define TTM_CACHE_SLOTS 8     // per-thread column cache (VarCache): 4 x + 4 exp(-x^2/4)
 
 // LDS image: [erf table | column cache (8 x NS x blockDim) | per-thread slots ...]
+// stage_erf = false: the launch evaluates no special term (the erf table is neither loaded nor read; its LDS stays reserved so
+// that the image layout - and lds_bytes() on the host - is the same)
 template <class R>
-__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots) {
+__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots, bool stage_erf = true) {
     double* et = g_smem;
-    for (int i = threadIdx.x; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
-    __syncthreads();
+    if (stage_erf) {
+        for (int i = threadIdx.x; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
+        __syncthreads();
+    }
     cache.base = et + TTM_ERF_TABLE_LEN + threadIdx.x;
     cache.stride = blockDim.x;
     slots = et + TTM_ERF_TABLE_LEN + (size_t)TTM_CACHE_SLOTS * lanes_of<R>::value * blockDim.x;

@@ -27,7 +27,7 @@ namespace {
 // grid: x = tiles of blockDim samples, y = chunks of `chunk` components (the components of a forward map are independent:
 // a small ensemble still fills the chip; the fused log-determinant / sum of squares run over all components: one chunk)
 template <int PH, int PP, int RECT, bool WANT_LD>
-__global__ __launch_bounds__(256) void k_int_forward(DevProg P, int kfirst, int klast, int chunk, const double* __restrict__ coef,
+__global__ __launch_bounds__(256) void k_int_forward(DevProg P, int kfirst, int klast, int chunk, int erf, const double* __restrict__ coef,
                                                      const double* __restrict__ fold, const double* __restrict__ X, int64_t ldx,
                                                      int64_t N, double* __restrict__ Z, int64_t ldz, double* __restrict__ logdet,
                                                      const double* __restrict__ sigma, double* __restrict__ sumsq) {
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_int_forward(DevProg P, int kfirst, int 
     const int k1 = (k0 + chunk < klast) ? k0 + chunk : klast;
     double* slots;
     CacheStore<double> cst;
-    const Prog g = make_prog_lds(P, cst, slots);
+    const Prog g = make_prog_lds(P, cst, slots, erf != 0);
     const int bd = blockDim.x;
     LdsSlots w{slots + threadIdx.x, bd};
     const bool want_val = (Z != nullptr) || (sumsq != nullptr);
@@ -68,13 +68,13 @@ __global__ __launch_bounds__(256) void k_int_forward(DevProg P, int kfirst, int 
 }
 
 template <int PH, int PP, int RECT, bool NEWTON>
-__global__ __launch_bounds__(256) void k_int_root(DevProg P, int k0, int k1, const double* __restrict__ coef,
+__global__ __launch_bounds__(256) void k_int_root(DevProg P, int k0, int k1, int erf, const double* __restrict__ coef,
                                                   const double* __restrict__ fold, const double* __restrict__ Z, int64_t ldz,
                                                   double* X, int64_t ldx, int64_t N, int* __restrict__ iters,
                                                   const int* __restrict__ cap) {
     double* slots;
     CacheStore<double> cst;
-    const Prog g = make_prog_lds(P, cst, slots);
+    const Prog g = make_prog_lds(P, cst, slots, erf != 0);
     LdsSlots w{slots + threadIdx.x, (int)blockDim.x};
     const double qws = dense_qw_sum(g);
     for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += (int64_t)gridDim.x * blockDim.x) {
@@ -160,6 +160,13 @@ __global__ __launch_bounds__(256) void k_int_objective(DevProg P, int k, const d
 
 namespace ttm_int {
 
+// does any component of [k0, k1) evaluate a special term (erf table in LDS)?
+static int needs_erf(const ttm_program* p, int k0, int k1) {
+    for (int k = k0; k < k1; ++k)
+        if (p->h_complex[k] & 8) return 1;
+    return 0;
+}
+
 bool usable(const ttm_program* p, int k0, int k1) {
     if (!p || p->monotonicity != TTM_MONO_INTEGRATED || p->family < 0 || p->family > 5) return false;
     DenseClass cls;
@@ -172,13 +179,14 @@ int forward(const ttm_program* p, const DevProg& P, int k0, int k1, const double
     DenseClass cls;
     if (!dense_range_class(p->h_complex, k0, k1, cls)) return TTM_E_UNSUPPORTED;
     if (chunk < 1 || logdet || sumsq) chunk = k1 - k0;
+    const int erf = needs_erf(p, k0, k1);
     const dim3 g3(grid, (k1 - k0 + chunk - 1) / chunk);
 #define TTM_CALL(PH, PP, RECT)                                                                                              \
     do {                                                                                                                    \
         if (logdet) hipLaunchKernelGGL((k_int_forward<PH, PP, RECT, true>), g3, dim3(bd), lds, (hipStream_t)stream, P, k0,  \
-                                       k1, chunk, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);               \
+                                       k1, chunk, erf, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);          \
         else hipLaunchKernelGGL((k_int_forward<PH, PP, RECT, false>), g3, dim3(bd), lds, (hipStream_t)stream, P, k0, k1,    \
-                                chunk, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);                          \
+                                chunk, erf, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);                     \
     } while (0)
     TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
 #undef TTM_CALL
@@ -191,12 +199,13 @@ int root(const ttm_program* p, const DevProg& P, int k0, int k1, const double* c
          size_t lds, void* stream, const char** kernel_name) {
     DenseClass cls;
     if (!dense_range_class(p->h_complex, k0, k1, cls)) return TTM_E_UNSUPPORTED;
+    const int erf = needs_erf(p, k0, k1);
 #define TTM_CALL(PH, PP, RECT)                                                                                              \
     do {                                                                                                                    \
         if (newton) hipLaunchKernelGGL((k_int_root<PH, PP, RECT, true>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k0, k1, \
-                                       coef, fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);                   \
-        else hipLaunchKernelGGL((k_int_root<PH, PP, RECT, false>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k0, k1, coef, \
-                                fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);                                \
+                                       erf, coef, fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);              \
+        else hipLaunchKernelGGL((k_int_root<PH, PP, RECT, false>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k0, k1, erf,  \
+                                coef, fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);                          \
     } while (0)
     TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
 #undef TTM_CALL

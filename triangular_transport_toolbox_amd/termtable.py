@@ -619,7 +619,9 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         nslots.append(len(bfuns) + 1 if (len(mnt_idx) or len(xgroups) or dense_b or poly_b) else 0)
         # (bits 8-11 / 12-15: the largest Hermite-function / plain polynomial order among the x_k-functions - the dense
         # integrated kernels of csrc/ttm_int.hip are instantiated per order class)
-        complex_all.append(int(complex_comp) | (2 if dense_b else 0) | (4 if poly_b else 0) |
+        # (bit 3: the component has special terms somewhere - a kernel without any needs no erf table in LDS)
+        has_st = any(f[0] == 'st' for t in list(nm_terms) + list(mon_terms) for f in t)
+        complex_all.append(int(complex_comp) | (2 if dense_b else 0) | (4 if poly_b else 0) | (8 if has_st else 0) |
                            (min(int(hdr[HDR_MAXP_HF]), 15) << 8) | (min(int(hdr[HDR_MAXP_POLY]), 15) << 12))
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))
