@@ -88,7 +88,7 @@ def _run(em, coef, X, k0=0, k1=None):
 @pytest.mark.parametrize('name', ['c5_sep', 'c3_sep', 'c2b_sep', 'c5_int', 'misc_family_hermite'])
 def test_planned_equals_tagged_and_partial_sweeps(name):
     npz, desc, om, cm, em, special = build(name)
-    if cm.complex.any():
+    if (cm.complex & 1).any():
         pytest.skip('map has components that need the generic interpreter')
     from tests.util import coeff_lists
     mon, non = coeff_lists(npz, cm.D)

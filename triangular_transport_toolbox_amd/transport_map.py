@@ -805,6 +805,9 @@ class transport_map():
         coef = self._pack_memo[2] if coef is None and getattr(self, '_pack_memo', None) is not None else coef
         pend = getattr(coef, '_ttm_pending', None) if coef is not None else None
         if pend is None:
+            if coef is not None and getattr(coef, '_ttm_failed', False):
+                coef._ttm_failed = False              # (a check that failed when it was consumed early, see _current)
+                return False
             return True
         fold, pending, errs, flags, done = pend
         coef._ttm_pending = None
@@ -825,8 +828,11 @@ class transport_map():
         return ok
 
     def _eager_tables(self):
+        # the default inverse tables ride along with the fold of a new coefficient vector (their flags come back behind the same
+        # synchronisation) - once this map HAS been inverted by table: a caller that only runs forward / density passes over
+        # many coefficient vectors pays neither the launch nor the allocations
         return (self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity' and self._cm.u_enabled and
-                getattr(self, '_cm', None) is not None and self._cm.u_h_cls > 0)
+                getattr(self, '_cm', None) is not None and self._cm.u_h_cls > 0 and getattr(self, '_inverse_seen', False))
 
     def _launch_default_tables(self, coef, resolution=1001, start_distance=10):
         """Build + index the inverse tables of all components for the default table geometry (TM:4047-4058), no host visit:
@@ -871,6 +877,12 @@ class transport_map():
     def _current(self, coef):
         if coef is None:
             return self._pack_coeffs()
+        pend = getattr(coef, '_ttm_pending', None)
+        if pend is not None and pend[4].query():
+            # deferred checks whose copies have landed are read at the next use of the vector, not only at an explicit validate():
+            # a failed one repairs the state now and is reported by the validate() the caller still owes
+            if not self.validate(coef):
+                coef._ttm_failed = True
         if getattr(coef, '_ttm_epoch', None) != self._epoch:
             if coef.numel() != int(self._cm.coef_off[-1]):
                 raise ValueError('packed coefficient vector belongs to a different specification of the map')
@@ -1096,6 +1108,7 @@ class transport_map():
         torch = _torch()
         ncomp = k1 - k0
         nb = self._inv_nb()
+        self._inverse_seen = True
         self._ensure_pts(resolution, start_distance)
         st = self._stream()
         trunc = 1 if self.root_search_truncation else 0
