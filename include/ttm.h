@@ -370,6 +370,12 @@ int64_t ttm_fold_size(const ttm_program* p);
  * tolerance - the direct kernels then run instead.                                                               */
 int64_t ttm_uform_offset(const ttm_program* p);
 int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* stream);
+/* ttm_fold_staged: ttm_fold for a U-form map whose packed coefficient vector is still in page-locked HOST memory the device
+ * can read (h_coef: hipHostMalloc / torch pinned memory): the fold kernel copies the vector into `coef` (device, written) itself,
+ * so a new coefficient vector costs no host-to-device copy in the stream; h_err (page-locked host, nullable) also receives
+ * the 2 D fit errors {value, derivative} of the special-term splines - readable behind an event on `stream`, no device-to-host
+ * copy.  TTM_E_UNSUPPORTED when the map has no U-form (copy the coefficients and call ttm_fold).                      */
+int ttm_fold_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* h_err, void* stream);
 
 /* ---- K2/K3: forward map ------------------------------------------------------
  * TM:2391-2437 map(), TM:2439-2567 s(), TM:4238-4258 GaussQuadrature (fused),
@@ -416,7 +422,8 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
  * (TM:4047-4058 rebuilds the table in every inverse_map).  Same bits as the two calls.                      */
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                                   const double* pts, int32_t T, int32_t nb, double* out, double* tmin, double* tmax,
-                                  int32_t* bkt, int32_t* unsorted, void* stream);
+                                  int32_t* bkt, int32_t* unsorted, int32_t* h_unsorted, void* stream);
+/* (h_unsorted: page-locked host memory, nullable - the sortedness flags also land there, readable behind an event on `stream`) */
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                       const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,

@@ -366,6 +366,14 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void*) {
     return 0;
 }
 
+int ttm_fold_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* h_err, void* stream) {
+    if (!p->u_enabled) return TTM_E_UNSUPPORTED;
+    memcpy(coef, h_coef, sizeof(double) * (size_t)p->h_coef_off[p->D]);
+    const int rc = ttm_fold(p, coef, fold, stream);
+    if (!rc && h_err) memcpy(h_err, fold + fold_base_size(p) + p->u_err_off, sizeof(double) * 2 * (size_t)p->D);
+    return rc;
+}
+
 int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* X, int64_t ldx, int64_t N,
                 int32_t k0, int32_t k1, double* Z, int64_t ldz, double* logdet, const double* sigma, double* sumsq, void*) {
     const Prog g = make_prog(p);
@@ -730,9 +738,11 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
                                   int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
-                                  void* stream) {
-    const int rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
-    return rc ? rc : ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+                                  int32_t* h_unsorted, void* stream) {
+    int rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
+    if (!rc) rc = ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+    if (!rc && h_unsorted) memcpy(h_unsorted, unsorted, sizeof(int32_t) * (size_t)(k1 - k0));
+    return rc;
 }
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,

@@ -314,3 +314,34 @@ def test_fused_setup_launches_write_the_same_bits_as_the_separate_ones(case, ttm
     assert fold_f.view(torch.int64).equal(fold_s.view(torch.int64))                  # (packed int32 pairs included)
     for a, b in zip(tabs_f, tabs_s):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_staged_fold_with_recycled_buffers_equals_the_copying_path(ttm_opt):
+    """A new coefficient vector of a U-form map reaches the device without a copy in the stream (ttm_fold_staged: the fold kernel
+    reads the packed vector from page-locked host memory; fit errors and table flags come back the same way) and takes over
+    the fold buffer of a vector that is gone without a zero-fill.  Twelve vectors in a row (the ring has eight slots): each
+    fold buffer, the device copy of the vector, the tables and the checks are those of the copying path, bit for bit."""
+    import torch
+    tm, om, X, rng = _build('c5_shape')
+    tm.inverse_map(rng.standard_normal((8, tm.D)))           # (tables are built with the fold from the first inversion on)
+    base_mon = [c.copy() for c in tm.coeffs_mon]
+    for i in range(12):
+        for k in range(tm.D):
+            tm.coeffs_mon[k] = base_mon[k] * (1.0 + 0.01 * (i + 1))
+        tm._pack_memo = None
+        coef = tm._pack_coeffs()
+        assert tm._lib.ttm_last_kernel().decode() == 'k_table_build_index'
+        torch.cuda.synchronize()
+        got = (coef.clone(), coef._ttm_fold.clone(), [t.clone() if hasattr(t, 'clone') else t for t in list(coef._ttm_tables.values())[0]])
+        del coef
+        ttm_opt('fold_fused', 0)                              # -> ttm_fold_staged declines: H2D copy + k_fold + k_uform + k_band_records
+        tm._pack_memo = None
+        ref = tm._pack_coeffs()
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref)
+        assert got[1].view(torch.int64).equal(ref._ttm_fold.view(torch.int64))
+        for a, b in zip(got[2], list(ref._ttm_tables.values())[0]):
+            assert (torch.equal(a, b) if hasattr(a, 'clone') else a == b)
+        del ref
+        ttm_opt('fold_fused', -1)

@@ -64,12 +64,13 @@ _SIGNATURES = {
     'ttm_fold_size': (c_i64, [ctypes.POINTER(ttm_program)]),
     'ttm_uform_offset': (c_i64, [ctypes.POINTER(ttm_program)]),
     'ttm_fold': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp]),
+    'ttm_fold_staged': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ttm_forward': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i64,
                                    c_vp, c_vp, c_vp, c_vp]),
     'ttm_basis': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'ttm_inverse_table_build': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     'ttm_inverse_table_index': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'ttm_inverse_table_build_index': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_inverse_table_build_index': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ttm_inverse_table': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                          c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     'ttm_inverse_bisect': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,

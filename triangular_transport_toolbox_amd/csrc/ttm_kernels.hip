@@ -448,9 +448,14 @@ struct UTabs {               // by-value kernel argument
 // summation order - the same bits) - a new coefficient vector then costs ONE launch for fold + U-form + push records instead
 // of three (k_fold 6.3 us, k_uform 10 us, k_band_records 4.9 us and the gaps between them: profiles/r03_v2_*).
 // p_lag > 0: the component's share of the push records (uform_scatter_push_records) behind its hot record.
-__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ coef, double* __restrict__ fold,
-                                                double* __restrict__ U, int64_t err_off, int64_t h_off, int h_cls, int h_ng,
-                                                int64_t p_off, int p_lag, int p_stride) {
+// coef_src != nullptr: `coef_src` is page-locked HOST memory the device can read (the packed coefficient vector as the host
+// wrote it): the workgroup first copies its component's slice into the device vector `coef` - the upload of a new vector
+// costs no copy in the stream (an H2D copy between two kernels sits between two engine switches: 3.7 us + 10.8 us of gap in
+// front of it, tools/trace_uncached.sh).  err_host != nullptr: the component's two fit errors also go to page-locked host
+// memory by system-scope stores (the host reads them behind an event instead of behind a D2H copy).
+__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ coef_src, double* coef,
+                                                double* __restrict__ fold, double* __restrict__ U, int64_t err_off, int64_t h_off,
+                                                int h_cls, int h_ng, int64_t p_off, int p_lag, int p_stride, double* err_host) {
     __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
     __shared__ double red[2][16];
     const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
@@ -459,6 +464,10 @@ __global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double
     const int* fd = P.fdesc + k * TTM_FDESC_LEN;
     if (coef) {
         const int* off = P.off;
+        if (coef_src) {
+            for (int i = off[2 * D1 + k] + tid; i < off[2 * D1 + k + 1]; i += bd) coef[i] = coef_src[i];
+            __syncthreads();
+        }
         fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k], coef + off[2 * D1 + k], fold + off[3 * D1 + k], tid, bd);
         __syncthreads();
         fold_st8(fd, P.fints, fold + off[3 * D1 + k], tid, bd);
@@ -498,6 +507,10 @@ __global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double
         for (int w = 1; w < nw; ++w) { ev = fmax(ev, red[0][w]); ed = fmax(ed, red[1][w]); }
         U[err_off + 2 * k] = ev;
         U[err_off + 2 * k + 1] = ed;
+        if (err_host) {
+            __hip_atomic_store(err_host + 2 * k, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(err_host + 2 * k + 1, ed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1688,7 +1701,8 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, const double* __restrict__ coef,
                                                            const double* __restrict__ fold, const double* __restrict__ pts, int T,
                                                            int nb, double* __restrict__ out, double* __restrict__ tmin,
-                                                           double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted) {
+                                                           double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted,
+                                                           int* unsorted_host) {
     __shared__ double xs[2048];
     __shared__ int bq[2048];
     __shared__ int bad;
@@ -1723,7 +1737,10 @@ __global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, co
     table_bucket_params(lo, hi, nb, scale, bias);
     for (int i = threadIdx.x; i < T; i += blockDim.x) bq[i] = table_bucket(xs[i], scale, bias, nb);
     __syncthreads();
-    if (threadIdx.x == 0) { tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad; }
+    if (threadIdx.x == 0) {
+        tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad;
+        if (unsorted_host) __hip_atomic_store(unsorted_host + blockIdx.x, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int q = threadIdx.x; q <= nb; q += blockDim.x) {
         int a = 0, b = T;
         if (q == nb) a = T;
@@ -2614,14 +2631,32 @@ int ttm_fold(const ttm_program* p, const double* coef, double* fold, void* strea
         const bool fused = tuning().fold_fused != 0;
         const bool records = p->u_p_lag > 0 && p->u_h_cls > 0 && p->u_p_stride == ttm_band::record_stride(p->u_h_cls, p->u_p_lag);
         if (!fused) hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
-        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, fused ? coef : (const double*)nullptr, fold,
+        hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, (const double*)nullptr,
+                           fused ? (double*)coef : (double*)nullptr, fold,
                            fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng,
-                           (int64_t)p->u_p_off, (fused && records) ? (int)p->u_p_lag : 0, (int)p->u_p_stride);
+                           (int64_t)p->u_p_off, (fused && records) ? (int)p->u_p_lag : 0, (int)p->u_p_stride, (double*)nullptr);
         if (!fused && p->u_p_lag > 0 && p->u_h_cls > 0) ttm_band::build_records(p, fold + fold_base_size(p), stream);       // push records of banded maps
         return check_launch(fused ? "k_uform<fold, records>" : "k_fold");
     }
     hipLaunchKernelGGL(k_fold, dim3(p->D), dim3(64), 0, (hipStream_t)stream, dev_prog(p), 0, 0, coef, fold);
     return check_launch("k_fold");
+}
+
+int ttm_fold_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* h_err, void* stream) {
+    int rc = validate(p, 0, p ? p->D : 0);
+    if (rc) return rc;
+    if (!h_coef || !coef || !fold) return set_err(TTM_E_ARG, "ttm_fold_staged: bad arguments%s");
+    if (!(p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo) || tuning().fold_fused == 0)
+        return set_err(TTM_E_UNSUPPORTED, "ttm_fold_staged: the map has no U-form (copy the coefficients and call ttm_fold)%s");
+    for (int k = 0; k < p->D; ++k)
+        if (p->h_ucomp && p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > TTM_U_NI_MAX)
+            return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
+    const UTabs T{p->ucomp, p->ugrp, p->umono, p->ugeo};
+    const bool records = p->u_p_lag > 0 && p->u_h_cls > 0 && p->u_p_stride == ttm_band::record_stride(p->u_h_cls, p->u_p_lag);
+    hipLaunchKernelGGL(k_uform, dim3(p->D), dim3(1024), 0, (hipStream_t)stream, dev_prog(p), T, h_coef, coef, fold,
+                       fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng,
+                       (int64_t)p->u_p_off, records ? (int)p->u_p_lag : 0, (int)p->u_p_stride, h_err);
+    return check_launch("k_uform<staged, fold, records>");
 }
 
 int ttm_forward(const ttm_program* p, const double* coef, const double* fold, const double* Xsoa, int64_t ldx, int64_t N,
@@ -2875,7 +2910,7 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
                                   int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
-                                  void* stream) {
+                                  int32_t* h_unsorted, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
     if (!coef || !fold || !pts || !out || !tmin || !tmax || !bkt || !unsorted || T < 2 || T > 2048 || nb < 1 || nb > 4096)
@@ -2883,7 +2918,10 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
     if (tuning().table_fused == 0) {
         rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
-        return rc ? rc : ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+        if (!rc) rc = ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
+        if (!rc && h_unsorted && hipMemcpyAsync(h_unsorted, unsorted, sizeof(int32_t) * (size_t)(k1 - k0), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+            return set_err(TTM_E_HIP, "ttm_inverse_table_build_index: copy of the flags failed%s");
+        return rc;
     }
     const int ns = map_slots(p, k0, k1);
     const size_t stat = 2048 * 8 + 2048 * 4 + 64;               // (the kernel's static arrays)
@@ -2892,7 +2930,7 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
         if (lds_bytes(ns, b, 0) + stat <= (size_t)kLdsBudget) { bd = b; break; }
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_table_build_index: %s%lld scratch slots do not fit the LDS budget", "", ns);
     hipLaunchKernelGGL(k_table_build_index, dim3(k1 - k0), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, coef,
-                       fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted);
+                       fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted, (int*)h_unsorted);
     return check_launch("k_table_build_index");
 }
 

@@ -722,7 +722,9 @@ class transport_map():
         memo = getattr(self, '_pack_memo', None)
         if override_k is None and memo is not None and memo[0] == self._epoch and np.array_equal(memo[1], host):
             return memo[2]
-        coef = self._fold(self._to_dev_staged(host))
+        coef = self._fold_staged(host) if (self._dev.type == 'cuda' and self._cm.u_enabled) else None
+        if coef is None:
+            coef = self._fold(self._to_dev_staged(host))
         if override_k is None:
             self._pack_memo = (coef._ttm_epoch, host, coef)
         return coef
@@ -749,6 +751,75 @@ class transport_map():
         ev.record()
         slot[1] = ev
         return dev
+
+    def _fold_staged(self, host):
+        """A new coefficient vector of a U-form map with NO copy in the launch stream (an H2D copy between two kernels sits
+        between two engine switches: 3.7 us + an 11 us gap, tools/trace_uncached.sh): the packed vector is written into a
+        page-locked ring slot, the fold kernel reads it from there and fills the device vector itself (ttm_fold_staged); the
+        spline fit errors and the sortedness flags of the default inverse tables come back the same way - written to
+        page-locked memory by the kernels, read behind an event (eager mode: behind one stream synchronisation).
+        None: not applicable (the caller takes the copying path)."""
+        torch = _torch()
+        n = int(host.shape[0])
+        D = self._cm.D
+        ring = getattr(self, '_fold_ring', None)
+        if ring is None or ring[0][0].numel() < n or ring[0][1].numel() < 2 * D:
+            ring = self._fold_ring = [[torch.empty(max(n, 64), dtype=torch.float64, pin_memory=True),
+                                       torch.empty(2 * D, dtype=torch.float64, pin_memory=True),
+                                       torch.empty(max(D, 16), dtype=torch.int32, pin_memory=True), None, None, None, None]
+                                      for _ in range(8)]
+            self._fold_ring_next = 0
+        slot = ring[self._fold_ring_next]
+        self._fold_ring_next = (self._fold_ring_next + 1) % len(ring)
+        if slot[3] is not None:
+            slot[3].synchronize()                       # (the kernels that last used this slot - eight vectors ago - are done)
+            prev = slot[4]() if slot[4] is not None else None
+            if prev is not None and getattr(prev, '_ttm_pending', None) is not None and not self.validate(prev):
+                prev._ttm_failed = True                 # (its deferred checks live in this slot: read before the slot is reused)
+        slot[0][:n].numpy()[:] = host
+        coef = torch.empty(n, dtype=torch.float64, device=self._dev)
+        # The fold buffer of the vector that used this slot eight vectors ago is taken over when that vector is gone and the
+        # layout is still the same (`_epoch`): the set of slots a fold writes is a function of the layout alone, so every
+        # slot the old fold wrote is written again and the others still hold the zeros of the first allocation - no
+        # zero-fill kernel (5 us) in front of the fold.  (Stream order protects the old contents' readers.)
+        nfold = int(self._lib.ttm_fold_size(self._pp))
+        prev = slot[4]() if slot[4] is not None else None
+        if prev is None and slot[5] is not None and slot[6] == (self._epoch, nfold):
+            fold = slot[5]
+        else:
+            fold = self._zeros(nfold)
+        slot[5], slot[6] = fold, (self._epoch, nfold)
+        st = self._stream()
+        rc = self._lib.ttm_fold_staged(self._pp, ctypes.c_void_p(slot[0].data_ptr()), self._ptr(coef), self._ptr(fold),
+                                       ctypes.c_void_p(slot[1].data_ptr()), st)
+        if rc != 0:
+            slot[3] = None
+            return None
+        coef._ttm_fold = fold
+        coef._ttm_tables = {}
+        pending = self._launch_default_tables(coef, h_unsorted=slot[2]) if self._eager_tables() else None
+        done = torch.cuda.Event()
+        done.record()
+        slot[3] = done
+        import weakref
+        slot[4] = weakref.ref(coef)
+        errs = slot[1][:2 * D]
+        flags = slot[2][:D] if pending is not None else None
+        coef._ttm_epoch = self._epoch
+        if getattr(self, 'deferred_checks', False):
+            if pending is not None:
+                tkey, entry = pending
+                coef._ttm_tables[tkey] = entry[:4] + (True,)
+            # (the ring slot is reused eight vectors on: validate() must have read it by then - it copies at once)
+            coef._ttm_pending = (fold, pending, errs, flags, done)
+            return coef
+        done.synchronize()
+        if not self._check_uform(fold, errs.numpy().copy()):
+            return self._fold(coef)                     # (U-form rejected: folded again without it, the plain path)
+        if pending is not None:
+            tkey, entry = pending
+            coef._ttm_tables[tkey] = entry[:4] + (int(flags.numpy().max()) == 0,)
+        return coef
 
     def _fold(self, coef):
         """Folded coefficients of a packed coefficient vector (device pre-pass, include/ttm.h "Folded coefficients"),
@@ -834,7 +905,7 @@ class transport_map():
         return (self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity' and self._cm.u_enabled and
                 getattr(self, '_cm', None) is not None and self._cm.u_h_cls > 0 and getattr(self, '_inverse_seen', False))
 
-    def _launch_default_tables(self, coef, resolution=1001, start_distance=10):
+    def _launch_default_tables(self, coef, resolution=1001, start_distance=10, h_unsorted=None):
         """Build + index the inverse tables of all components for the default table geometry (TM:4047-4058), no host visit:
         returns (cache key, (tables, tmin, tmax, bucket index, unsorted flags on the device))."""
         torch = _torch()
@@ -849,7 +920,8 @@ class transport_map():
         _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), 0, ncomp,
                                                             self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
                                                             self._ptr(tmin_d), self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
-                                                            ctypes.c_void_p(uns_d.data_ptr()), st))
+                                                            ctypes.c_void_p(uns_d.data_ptr()),
+                                                            None if h_unsorted is None else ctypes.c_void_p(h_unsorted.data_ptr()), st))
         return (0, ncomp, resolution, start_distance, nb), (out_d, tmin_d, tmax_d, bkt_d, uns_d)
 
     def _inv_nb(self):
@@ -1128,7 +1200,7 @@ class transport_map():
                 _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                                     self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
                                                                     self._ptr(tmin_d), self._ptr(tmax_d),
-                                                                    ctypes.c_void_p(bkt_d.data_ptr()), ctypes.c_void_p(uns_d.data_ptr()), st))
+                                                                    ctypes.c_void_p(bkt_d.data_ptr()), ctypes.c_void_p(uns_d.data_ptr()), None, st))
             else:
                 _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                               self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
