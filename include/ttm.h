@@ -422,14 +422,22 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
  * (TM:4047-4058 rebuilds the table in every inverse_map).  Same bits as the two calls.                      */
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                                   const double* pts, int32_t T, int32_t nb, double* out, double* tmin, double* tmax,
-                                  int32_t* bkt, int32_t* unsorted, int32_t* h_unsorted, void* stream);
-/* (h_unsorted: page-locked host memory, nullable - the sortedness flags also land there, readable behind an event on `stream`) */
+                                  int32_t* bkt, int32_t* unsorted, int32_t* h_unsorted, double* img, void* stream);
+/* (h_unsorted: page-locked host memory, nullable - the sortedness flags also land there, readable behind an event on `stream`)
+ * img (device, 16-byte aligned, nullable): (k1-k0) x ttm_inverse_table_image_doubles(p, k0, k1, T, nb) doubles that receive
+ * the RESIDENT-TABLE IMAGE of every component - search parameters, the window of the table the lookup kernel of banded maps
+ * keeps in LDS, its 16-bit bucket index (csrc/ttm_band_image.h) - laid out once here so that ttm_inverse_table copies them
+ * into LDS by DMA instead of assembling them per workgroup.  A pure function of the table: passing it changes no result.
+ * ttm_inverse_table_image_doubles returns 0 when the map / table geometry has no such kernel (img must then be NULL).       */
+int64_t ttm_inverse_table_image_doubles(const ttm_program* p, int32_t k0, int32_t k1, int32_t T, int32_t nb);
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                       const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,
                       const double* h_y_affine,
                       const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
-                      int32_t truncate, void* stream);
+                      int32_t truncate, const double* img, int64_t img_doubles, void* stream);
+/* (img: what ttm_inverse_table_build_index wrote for these tables and this [k0, k1), or NULL; img_doubles: doubles per
+ * component it was laid out with - an image of another layout than this launch plans for is ignored, not misread) */
 
 /* ---- K5: bisection inverse (both monotonicity modes) -----------------------------
  * TM:3798-3985 vectorized_root_search_bisection, exact bracket / window-shift / midpoint

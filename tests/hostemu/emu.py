@@ -188,7 +188,7 @@ class EmuMap:
         bkt = np.stack([np.searchsorted(tab_x[i], edges[i], side='left') for i in range(k1 - k0)]).astype(np.int32)
         bkt[:, 0], bkt[:, -1] = 0, T
         lib().ttm_inverse_table(self.pp, ptr(coef), ptr(self.fold), k0, k1, ptr(Zs), N, ptr(X), N, N, ptr(tab_x), ptr(tab_y),
-                                T, T, None, ptr(tmin), ptr(tmax), ptr(bkt), nb, int(truncate), None)
+                                T, T, None, ptr(tmin), ptr(tmax), ptr(bkt), nb, int(truncate), None, 0, None)
         return X.T.copy()
 
     def inverse_bisect(self, coef, k0, k1, Z, Xinit, cap=None):

@@ -738,17 +738,20 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
 
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
                                   int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
-                                  int32_t* h_unsorted, void* stream) {
+                                  int32_t* h_unsorted, double* img, void* stream) {
+    if (img) return TTM_E_ARG;                                 // (ttm_inverse_table_image_doubles is 0 here: no images on the host)
     int rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
     if (!rc) rc = ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
     if (!rc && h_unsorted) memcpy(h_unsorted, unsorted, sizeof(int32_t) * (size_t)(k1 - k0));
     return rc;
 }
 
+int64_t ttm_inverse_table_image_doubles(const ttm_program*, int32_t, int32_t, int32_t, int32_t) { return 0; }
+
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
                       int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
-                      int32_t truncate, void*) {
+                      int32_t truncate, const double*, int64_t, void*) {
     const Prog g = make_prog(p);
     if (u_on(p) && p->u_h_cls >= 1 && p->u_p_lag <= 2 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
         (nb + 1) % 4 == 0 && !getenv("TTM_EMU_NO_HOT")) {

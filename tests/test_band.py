@@ -345,3 +345,98 @@ def test_staged_fold_with_recycled_buffers_equals_the_copying_path(ttm_opt):
             assert (torch.equal(a, b) if hasattr(a, 'clone') else a == b)
         del ref
         ttm_opt('fold_fused', -1)
+
+
+def _ring_map(D, n=5003, seed=3):
+    """A C5-shaped banded map of D components with moderate random coefficients (tables monotone), device map + oracle."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    from oracle.ttm_oracle import OracleMap
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, D)) * (1.0 + 0.3 * rng.random(D)) + 0.2 * rng.standard_normal((n, 1))
+    mon, non = _synthetic_separable(D, 2, 3, 1, 2)
+    kw = dict(monotonicity='separable monotonicity')
+    tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
+    om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
+    for k in range(D):
+        cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
+        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
+        tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
+    return tm, om, X, rng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('D', [10, 26, 27])
+def test_ring_inverse_equals_the_block_inverse_and_the_oracle(D, ttm_opt):
+    """k_band_inverse_ring (resident-table images copied into a ring of LDS slots by DMA, csrc/ttm_band_image.h) against
+    k_band_inverse (tables assembled per workgroup and block) and the oracle: every component resident (no refill), rings of
+    24 slots refilled 8 at a time and of 12 / 16 slots refilled 4 at a time, an odd number of components, chunks of one and
+    of several tiles, targets beyond the resident window and beyond the tables."""
+    tm, om, X, rng = _ring_map(D)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    N = len(X)
+    Zin = rng.standard_normal((N, D))
+    Zin[:40] *= 3.5
+    Zin[41] = 60.0; Zin[42] = -60.0
+    Xo = om.inverse_map(Zin)
+    ttm_opt('u_loader', 1); ttm_opt('band_inv', 1)
+
+    def run(ring, cus, block):
+        ttm_opt('band_ring', ring); ttm_opt('band_cus', cus); ttm_opt('rt_block', block)
+        tm._pack_memo = None                                # (a fresh coefficient vector: tables and images under these options)
+        Xi = tm.inverse_map(Zin)
+        tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N)
+        return Xi, lib.ttm_last_kernel().decode()
+
+    X_block, name = run(0, -1, -1)
+    assert name == 'k_band_inverse' and relerr(X_block, Xo) < 1e-11
+    X_ring, name = run(1, -1, -1)
+    assert name == 'k_band_inverse_ring'
+    assert relerr(X_ring, Xo) < 1e-11
+    # one tile per chunk: both kernels carry the running sums in registers through all columns - the same bits
+    assert np.array_equal(X_ring, X_block)
+    for cus, block in ((-1, 12), (-1, 16), (1, -1), (1, 12), (2, 16)):
+        Xi, name = run(1, cus, block)
+        expect_ring = D > 4
+        assert name == ('k_band_inverse_ring' if expect_ring else 'k_band_inverse'), (cus, block, name)
+        # the ring kernel's result does not depend on how rows are cut into chunks and tiles or on the ring's size
+        assert np.array_equal(Xi, X_ring), (cus, block)
+        Xb, name = run(0, cus, block)
+        assert name == 'k_band_inverse' and relerr(Xb, X_ring) < 1e-14, (cus, block)
+
+
+@pytest.mark.gpu
+def test_table_images_fused_and_separate_launches_and_layout_mismatch(ttm_opt):
+    """The resident-table images written by the fused table kernel equal those of the two-launch path bit for bit; an image
+    laid out for another window than the lookup plans for is ignored (k_band_inverse runs), not misread."""
+    import torch
+    D = 26
+    tm, om, X, rng = _ring_map(D, n=3001)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    ttm_opt('u_loader', 1); ttm_opt('band_inv', 1)
+    Zin = rng.standard_normal((len(X), D))
+    Xo = om.inverse_map(Zin)
+    imgs = {}
+    for fused in (1, 0):
+        ttm_opt('table_fused', fused)
+        tm._pack_memo = None
+        coef = tm._pack_coeffs()
+        tm._inverse_table(coef, 0, D, None, None, 0)
+        entry = next(iter(coef._ttm_tables.values()))
+        assert entry[5] is not None and entry[5].numel() == D * int(lib.ttm_inverse_table_image_doubles(tm._pp, 0, D, 1001, tm._inv_nb()))
+        imgs[fused] = [t.clone() for t in entry[:4]] + [entry[5].clone()]
+    torch.cuda.synchronize()
+    for a, b in zip(imgs[1], imgs[0]):
+        assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b)
+    # tables and images built for the default window; the lookup then plans another one
+    ttm_opt('table_fused', 1)
+    tm._pack_memo = None
+    Xi = tm.inverse_map(Zin)
+    assert relerr(Xi, Xo) < 1e-11
+    ttm_opt('rt_window', 300)
+    Xw = tm.inverse_map(Zin)                                # (same coefficient vector: its cached tables and images)
+    tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N)
+    assert lib.ttm_last_kernel().decode() == 'k_band_inverse'
+    assert relerr(Xw, Xo) < 1e-11

@@ -54,14 +54,14 @@ def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails(ttm_opt):
     Zdev = tm.forward_device(tm._Xs, tm._N)
     assert _last_kernel(tm) == 'k_band_forward'
     tm.inverse_device(Zdev, tm._N)
-    assert _last_kernel(tm) == 'k_band_inverse'
+    assert _last_kernel(tm) == 'k_band_inverse_ring'
     Z = tm.map(X)
     Zo = om.map(X[idx])
     record_parity('c5_full/map(k_band_forward)_vs_oracle', relerr(Z[idx], Zo), 1e-11)
     assert relerr(Z[idx], Zo) < 1e-11
     Xi = tm.inverse_map(Z)
     Xio = om.inverse_map(Z[idx])
-    record_parity('c5_full/table_inverse(k_band_inverse)_of_pushed_samples_vs_oracle', relerr(Xi[idx], Xio), 1e-11)
+    record_parity('c5_full/table_inverse(k_band_inverse_ring)_of_pushed_samples_vs_oracle', relerr(Xi[idx], Xio), 1e-11)
     assert relerr(Xi[idx], Xio) < 1e-11
     # reference samples (not pushed forward ones): standard normal z, including |z| > 4
     Zr = np.random.default_rng(1).standard_normal((N, tm.D))
@@ -69,7 +69,7 @@ def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails(ttm_opt):
     jdx = np.concatenate((np.arange(50), subset_with_tails(Zr, 10000)))
     Xr = tm.inverse_map(Zr)
     Xro = om.inverse_map(Zr[jdx])
-    record_parity('c5_full/table_inverse(k_band_inverse)_of_reference_samples_vs_oracle', relerr(Xr[jdx], Xro), 1e-11)
+    record_parity('c5_full/table_inverse(k_band_inverse_ring)_of_reference_samples_vs_oracle', relerr(Xr[jdx], Xro), 1e-11)
     assert relerr(Xr[jdx], Xro) < 1e-11
     ttm_opt('rt_window', 0)                                                   # whole tables resident: the same bits as the planned window
     assert np.array_equal(tm.inverse_map(Zr), Xr)

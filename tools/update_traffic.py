@@ -17,7 +17,7 @@ for name, v in j.items():
     base = name.split('<')[0].replace('ttm_band::', '')
     if 'FETCH_SIZE' not in v or 'WRITE_SIZE' not in v:
         continue
-    if base in ('k_forward_hl', 'k_inverse_rt', 'k_import', 'k_import_flat', 'k_band_forward', 'k_band_inverse', 'k_band_density'):
+    if base in ('k_forward_hl', 'k_inverse_rt', 'k_import', 'k_import_flat', 'k_band_forward', 'k_band_inverse', 'k_band_inverse_ring', 'k_band_density'):
         if base == 'k_forward_hl' and '<true' in name:
             continue
         entry['raw'][name] = {'FETCH_SIZE': v['FETCH_SIZE'], 'WRITE_SIZE': v['WRITE_SIZE'], 'avg_ns': v.get('avg_ns')}

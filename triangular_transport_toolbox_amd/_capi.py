@@ -70,9 +70,10 @@ _SIGNATURES = {
     'ttm_basis': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'ttm_inverse_table_build': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     'ttm_inverse_table_index': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'ttm_inverse_table_build_index': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_inverse_table_build_index': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_inverse_table_image_doubles': (c_i64, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_i32, c_i32]),
     'ttm_inverse_table': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
-                                         c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+                                         c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'ttm_inverse_bisect': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                           c_i64, c_vp, c_vp, c_vp]),
     'ttm_inverse_newton': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,

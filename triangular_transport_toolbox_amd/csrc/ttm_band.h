@@ -36,8 +36,13 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
             int64_t ldz, double* logdet, const double* sigma, double* sumsq, int cus, size_t lds_per_cu, int block, void* stream, const char** kernel_name);
 
 // table inverse (resident windowed tables, as k_inverse_rt) in push form
+// img: the resident-table images of the components (image_plan; written by k_table_build_index) or nullptr
 int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx,
             int64_t N, const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt,
-            int nb, int cus, size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name);
+            int nb, const double* img, int img_doubles, int cus, size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name);
+
+// does the table inverse of [k0, k1) take resident-table images (csrc/ttm_band_image.h) for this table geometry?  The window
+// [w0, w0 + W) of every table and the doubles per image (the table-building kernel writes them, `inverse` reads them)
+bool image_plan(const ttm_program* p, int k0, int k1, int T, int nb, size_t lds_per_cu, int window, int block, int* w0, int* W, int* tab_slot);
 
 }  // namespace ttm_band

@@ -23,6 +23,7 @@
 
 #include "ttm_band.h"
 #include "ttm_band_etab.h"
+#include "ttm_band_image.h"
 
 namespace ttm_band {
 
@@ -1105,14 +1106,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few(const double* __restrict__
 // LDS (doubles): [tables: B x tab_slot | {E_i, y_i}: 2 x Weven]
 // table slot: [wl, wh, bucket scale, bucket bias, int32 {entries per bucket at most, 0}, int32 {degenerate, 0} | xs: W
 //              entries + 4 sentinels (+inf), rounded up to even | bucket index: nb + 1 uint16]
-#define BAND_RT_HDR 6
-#define BAND_RT_KMAX 24                                /* components per block, at most */
-
-__device__ __forceinline__ void band_bucket_params(double lo, double hi, int nb, double& scale, double& bias) {
-    scale = (double)nb / (hi - lo);                                           // (k_table_index: the same IEEE division)
-    if (!(scale > 0.0 && scale < 1.0e300)) scale = 0.0;
-    bias = -lo * scale;
-}
+#define BAND_RT_KMAX 24                                /* components per block, at most (BAND_RT_HDR, band_bucket_params: ttm_band_image.h) */
 
 // exp(-x^2/4) by the series (block boundaries, outliers): Cody-Waite reduction + degree-12 Taylor, <= 2 ulp
 __device__ __forceinline__ double band_expq_series(double x) {
@@ -1165,15 +1159,60 @@ struct BandInvCtx {
     unsigned int c1_32;
 };
 
-template <int CLS, int LAG>
+// The ring of resident tables (k_band_inverse_ring): step s of a workgroup's flat sequence (tile by tile, column by column)
+// finds the image of its component in slot s mod R.  EVERY step copies ONE image by DMA - each wave one 1 KB piece, without a
+// condition, so that the compiler's count of the loads in flight stays exact and the wait for the next column of z covers
+// nothing else: the image of step s - G + R goes into the slot step s - G used.  The workgroup meets at a barrier every G
+// steps, so that slot has been free since the last meeting; a piece requested before the last meeting has landed by the next
+// one (counted wait: every step since put at least three vector-memory operations behind it), the barrier makes that true
+// of every wave's piece, and the image is used at step s - G + R >= s + 2 G (R >= 3 G).  Past the last column the copies are
+// harmless repeats.
+struct BandRing {
+    const char* src;               // this lane's 16 bytes inside the image of component k0
+    unsigned int dst;              // where the wave's piece starts inside a slot (bytes)
+    unsigned int tabs_lds;         // LDS address of slot 0
+    unsigned int stride;           // bytes per image / slot
+    int R, ncomp;
+    int pos;                       // slot of the next step
+    int tpos, tcomp;               // slot the next step refills, component whose image goes there
+    int gcnt;                      // steps since the last meeting
+};
+
+// One LDS-DMA instruction (16 bytes per lane: the wave's 1 KB lands at lds_wave_base, an LDS byte address, lane after lane),
+// written in assembly so that the COMPILER DOES NOT KNOW IT: with a global_load_lds it knows to be in flight hipcc waits for
+// vmcnt(0) at the next use of any ordinary load (the column prefetch would be drained every step).  Unknown to it, its
+// counted waits are merely one stricter per copy among the younger operations: place the copy behind the step's wait for z,
+// and that wait retires the PREVIOUS step's copy (a whole step old) and nothing else.
+__device__ __forceinline__ void band_dma16(const void* g, unsigned int lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "m0");
+}
+__device__ __forceinline__ unsigned int band_lds_addr(const void* p) {
+    return (unsigned int)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// the images of the steps [0, n) into the slots [0, n) (in front of the first column: 16 bytes per lane and round)
+__device__ __forceinline__ void band_ring_fill(const double* img, int ncomp, double* tabs, int tab_slot, int n) {
+    const int U = tab_slot >> 1;                                              // 16-byte units per image
+    const int total = n * U;
+    for (int u0 = 0; u0 < total; u0 += BAND_CT) {
+        const int u = u0 + (int)threadIdx.x;
+        if (u < total) {
+            const int t = u / U, o = u - t * U;
+            band_dma16(img + (size_t)(t % ncomp) * tab_slot + 2 * o,
+                       __builtin_amdgcn_readfirstlane(band_lds_addr(tabs) + (unsigned int)(u0 + ((int)threadIdx.x & ~63)) * 16u));
+        }
+    }
+}
+
+template <int CLS, int LAG, bool RING = false, int G = 0>
 __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool full, int kb, int ke, const char* zcol, char* xcol, unsigned int tbase,
                                                   const unsigned int (&roff)[BAND_NS / 2], double (&pend)[BAND_NS][LAG],
-                                                  const D2 (&zfirst)[BAND_NS / 2], bool have_first) {
+                                                  const D2 (&zfirst)[BAND_NS / 2], bool have_first, BandRing* rg = nullptr) {
     constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
     constexpr int NS = BAND_NS, NP = NS / 2, HALF = 2 * BAND_CT;
     cdbl_p rec = cx.P + (int64_t)(kb + LAG) * PS;
     cdbl_p kt = cx.kt;
-    const double* slot = cx.tabs;
+    const double* slot = RING ? cx.tabs + (size_t)rg->pos * cx.tab_slot : cx.tabs;
     const double ystep = cx.ystep;
     const int nb1 = cx.nb - 1;
     D2 za[NP], zb[NP];
@@ -1231,6 +1270,12 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
             traw[e] = z - pend[e][0];
             tg[e] = fmin(fmax(traw[e], wl), wh);
             outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
+        }
+        if (RING && G > 0) {
+            // the step's piece of an image (BandRing), behind the wait for this step's z (the ballot needs every row's target)
+            band_dma16(rg->src + (size_t)rg->tcomp * rg->stride, rg->tabs_lds + (unsigned int)rg->tpos * rg->stride + rg->dst);
+            if (++rg->tpos == rg->R) rg->tpos = 0;
+            if (++rg->tcomp == rg->ncomp) rg->tcomp = 0;
         }
         // the four rows in phases, so that their dependent LDS reads travel together: bucket -> the bucket's entries ->
         // the interval.  np.searchsorted(xs, target) (left) = entries in lower buckets + entries of the target's own
@@ -1327,6 +1372,19 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
             }
         }
         rec += PS; slot += cx.tab_slot; zcol += cx.ldzb; xcol += cx.ldxb;
+        if (RING) {
+            if (++rg->pos == rg->R) { rg->pos = 0; slot = cx.tabs; }
+            if (G > 0 && ++rg->gcnt == G) {
+                rg->gcnt = 0;
+                // this wave's pieces from before the last meeting have landed: every step since put two column loads and a piece behind them
+                if (G == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                __syncthreads();
+            }
+        }
+#ifdef BAND_XI_BARRIERS                                      /* (timing experiment: what a workgroup barrier every so many columns costs) */
+        if ((j - kb) % BAND_XI_BARRIERS == BAND_XI_BARRIERS - 1) __syncthreads();
+#endif
     };
     int j = kb;
     for (; j + 1 < ke; j += 2) {
@@ -1400,6 +1458,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
         __syncthreads();                                      // every wave is done with the previous block's tables
         // the tables of the block: every load of the block in flight at once (element i of every table by thread i; the
         // bucket indices sixteen bytes at a time), the search parameters next to them
+#ifdef BAND_XI_NOSWITCH                                      /* (timing experiment: later blocks search the first block's tables) */
+        if (kb == k0)
+#endif
         {
             constexpr int KMAX = KM;                          // components per block, at most (the host plans for it)
             double lo = 0.0, hi = 0.0;
@@ -1443,6 +1504,9 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
         }
         __syncthreads();
         // entries per bucket, at most; the value range [wl, wh] whose search stays inside the window (k_inverse_rt)
+#ifdef BAND_XI_NOSWITCH
+        if (kb == k0)
+#endif
         for (int c = tid >> 6; c < nk; c += CT >> 6) {
             const unsigned short* bs = (const unsigned short*)(tabs + (size_t)c * tab_slot + BAND_RT_HDR + Weven);
             int per = 0;
@@ -1505,6 +1569,102 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
             char* xcol = (char*)X + (int64_t)colb * ldxb;
             band_inverse_tile<CLS, LAG>(cx, full, kb, ke, zcol, xcol, tbase, roff, pend, zfirst, tile == 0);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_band_inverse with the tables of a RING of components resident (BandRing, ttm_band_image.h): the images come ready-made
+// from the kernel that built the tables and are copied into LDS by DMA - all R slots in front of the first column (one round
+// trip: the first column of z is requested before them), then G at a time behind a barrier every G columns, two groups
+// ahead of their use.  A tile walks ALL its columns in one go: the running sums never leave the registers, so the result of a
+// row does not depend on the chunking (k_band_inverse re-reads LAG columns at a block boundary when a chunk has several tiles
+// and takes their exp(-x^2/4) from the series there).  The step itself is band_inverse_tile, shared with k_band_inverse.
+template <int CLS, int LAG, int G>
+__global__ __launch_bounds__(BAND_CT) void k_band_inverse_ring(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                               const double* __restrict__ Z, int64_t ldz, double* X, int64_t ldx, int64_t N,
+                                                               const double* __restrict__ tab_x, int T, double y0, double ystep, double ylast,
+                                                               const double* __restrict__ tmin, const double* __restrict__ tmax,
+                                                               const double* __restrict__ img, int nb, int tab_slot, int R,
+                                                               int64_t rows_per_wg, int w0, int W) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), PS = rec_stride(CLS, LAG);
+    constexpr int NS = BAND_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT;
+    extern __shared__ __align__(16) double g_lds[];
+    const int tid = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * rows_per_wg;
+    if (c0 >= N) return;
+    const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
+    const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
+    const int ncomp = k1 - k0;
+    const int Weven = (W + 4 + 1) & ~1;
+    double* tabs = g_lds;
+    double* etab = tabs + (size_t)R * tab_slot;
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const int64_t ldzb = ldz * 8, ldxb = ldx * 8;
+    const double y0m = y0 - ystep;
+    BandInvCtx cx;
+    cx.P = P; cx.kt = (cdbl_p)g_band_taylor; cx.tabs = tabs;
+    cx.etab1 = band_lds(etab) - 16 * w0 - 16;
+    cx.tab_x = tab_x; cx.tmin = tmin; cx.tmax = tmax;
+    cx.T = T; cx.nb = nb; cx.tab_slot = tab_slot; cx.w0 = w0; cx.Weven = Weven; cx.k0 = k0;
+    cx.y0 = y0; cx.ystep = ystep; cx.y0m = y0m; cx.ldzb = ldzb; cx.ldxb = ldxb; cx.c1_32 = (unsigned int)c1;
+    BandRing rg;
+    {
+        const int U = tab_slot >> 1, nw = (U + 63) >> 6;      // 16-byte units per image, waves that cover one
+        const int piece = (tid >> 6) % nw;                    // (the other waves repeat a piece: the same bytes to the same place)
+        const int start = 64 * piece < U - 64 ? 64 * piece : U - 64;
+        rg.src = (const char*)img + (size_t)(start + (tid & 63)) * 16;
+        rg.dst = __builtin_amdgcn_readfirstlane((unsigned int)start * 16u);
+        rg.tabs_lds = band_lds_addr(tabs);
+        rg.stride = (unsigned int)tab_slot * 8u;
+        rg.R = R; rg.ncomp = ncomp; rg.pos = 0; rg.gcnt = 0;
+        rg.tpos = G > 0 ? R - G : 0;
+        rg.tcomp = G > 0 ? (R - G) % ncomp : 0;
+    }
+    // the first column of z of the first tile, then the images of the first R steps: one memory round trip
+    D2 zfirst[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        unsigned int n = (unsigned int)c0 + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
+        n = n < last_pair ? n : last_pair;
+        zfirst[q] = band_load2((const char*)Z + (size_t)(n * 8u));
+    }
+    band_ring_fill(img, ncomp, tabs, tab_slot, R);
+    for (int i = tid; i < W; i += CT) {
+        etab[2 * i] = band_expq_series(w0 + i == T - 1 ? ylast : (double)(w0 + i) * ystep + y0);
+        etab[2 * i + 1] = fma((double)(w0 + i + 1), ystep, y0m);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int tile = 0; tile < ntile; ++tile) {
+        const unsigned int tbase = (unsigned int)c0 + (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+        const bool full = c0 + (int64_t)(tile + 1) * ROWS <= c1;
+        unsigned int roff[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned int n = tbase + (unsigned int)(q * HALF);
+            n = n < last_pair ? n : last_pair;
+            roff[q] = n * 8u;
+        }
+        // running sums at the first column from the LAG columns in front of it (conditioning columns, or nothing)
+        double pend[NS][LAG];
+#pragma unroll
+        for (int e = 0; e < NS; ++e)
+#pragma unroll
+            for (int l = 0; l < LAG; ++l) pend[e][l] = 0.0;
+        for (int i = 0; i < LAG; ++i) {
+            const int cc = kcol0 - LAG + i;
+            cdbl_p rec = P + (int64_t)(k0 + i) * PS;
+            const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                D2 xv = {0.0, 0.0};
+                if (cc >= 0) xv = *(const D2*)(col + roff[q]);
+                band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[1], xv.x, cc >= 0 ? band_expq_series(xv.x) : 1.0, pend[2 * q]);
+                band_push<DB, DA, LAG>(rec + TTM_P_HDR, rec[1], xv.y, cc >= 0 ? band_expq_series(xv.y) : 1.0, pend[2 * q + 1]);
+            }
+        }
+        band_inverse_tile<CLS, LAG, true, G>(cx, full, k0, k1, (const char*)Z, (char*)X + (int64_t)kcol0 * ldxb, tbase, roff, pend, zfirst, tile == 0, &rg);
     }
 }
 
@@ -1983,9 +2143,23 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     return 0;
 }
 
+static double window_fraction() {
+    static const double wfrac = [] { const char* e = getenv("TTM_BAND_WFRAC"); return e ? atof(e) : 0.52; }();
+    return wfrac;
+}
+
+// resident-table images (ttm_band_image.h) of the components [k0, k1) for this table geometry: the plan, or false
+bool image_plan(const ttm_program* p, int k0, int k1, int T, int nb, size_t lds_per_cu, int window, int block, int* w0, int* W, int* tab_slot) {
+    if (!usable(p, k0, k1) || p->u_p_lag != 2 || k1 - k0 <= TTM_P_FEW_D) return false;
+    BandRingPlan pl;
+    if (!band_ring_plan(T, nb, k1 - k0, lds_per_cu, window, block, window_fraction(), &pl)) return false;
+    *w0 = pl.w0; *W = pl.W; *tab_slot = pl.tab_slot;
+    return true;
+}
+
 int inverse(const ttm_program* p, const double* U, int k0, int k1, const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
-            const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int nb, int cus,
-            size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name) {
+            const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int nb, const double* img,
+            int img_doubles, int cus, size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name) {
     if (!usable(p, k0, k1) || !y_affine || T < 64 || T > 4096 || nb + 1 != 1024 || N >= ((int64_t)1 << 28)) return 1;      // (bucket rows copied 16 bytes at a time, 256 units per row)
     if ((uintptr_t)bkt % 16 != 0) return 1;
     const double ymax = fabs(y_affine[0]) > fabs(y_affine[2]) ? fabs(y_affine[0]) : fabs(y_affine[2]);
@@ -2025,7 +2199,26 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
     }
     if (p->u_p_lag != 2) return 1;
     static const int stagger = [] { const char* e = getenv("TTM_BAND_STAGGER"); return e ? atoi(e) : 1; }();
-    static const double wfrac = [] { const char* e = getenv("TTM_BAND_WFRAC"); return e ? atof(e) : 0.52; }();
+    const double wfrac = window_fraction();
+    // resident-table images at hand (ttm_inverse_table_build_index wrote them): the ring kernel
+    BandRingPlan pl;
+    if (img && (uintptr_t)img % 16 == 0 && band_ring_plan(T, nb, ncomp, lds_per_cu, window, block, wfrac, &pl) &&
+        pl.tab_slot == img_doubles) {                         // (laid out for another plan - options changed in between: not this kernel)
+        typedef void (*rkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, double*, int64_t, int64_t, const double*, int, double,
+                                double, double, const double*, const double*, const double*, int, int, int, int64_t, int, int);
+        const int cls = p->u_h_cls;
+#define BAND_RING_K(G) (cls == 1 ? k_band_inverse_ring<1, 2, G> : cls == 2 ? k_band_inverse_ring<2, 2, G> : k_band_inverse_ring<3, 2, G>)
+        rkern_t rk = pl.G == 8 ? BAND_RING_K(8) : pl.G == 4 ? BAND_RING_K(4) : BAND_RING_K(0);
+#undef BAND_RING_K
+        const int64_t rows = chunk_rows(N, cus);
+        const int64_t grid = (N + rows - 1) / rows;
+        allow_lds((const void*)rk, pl.lds);
+        hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(BAND_CT), pl.lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                           (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Zsoa, ldz, Xsoa, ldx, N, tab_x, T, y_affine[0], y_affine[1], y_affine[2], tmin,
+                           tmax, img, nb, pl.tab_slot, pl.R, rows, pl.w0, pl.W);
+        if (kernel_name) *kernel_name = "k_band_inverse_ring";
+        return 0;
+    }
     int W = T, w0 = 0, Weven = 0, tab_slot = 0, Bc = 0, nblk = 0;
     size_t lds = 0;
     auto plan = [&]() {

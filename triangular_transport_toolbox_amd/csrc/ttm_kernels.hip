@@ -30,6 +30,7 @@
 #include "ttm_rng.h"
 #include "ttm_uform.h"
 #include "ttm_band.h"
+#include "ttm_band_image.h"
 #include "ttm_int.h"
 
 using namespace ttm;
@@ -1695,6 +1696,21 @@ __global__ __launch_bounds__(256) void k_table_index(const double* __restrict__ 
     }
 }
 
+// resident-table image (csrc/ttm_band_image.h) of one table per workgroup from its row, range and bucket index in memory
+// (the fused kernel below writes it from what it holds in LDS; this one serves the two-launch path)
+__global__ __launch_bounds__(256) void k_table_image(const double* __restrict__ tab_x, int T, int nb, const double* __restrict__ tmin,
+                                                     const double* __restrict__ tmax, const int* __restrict__ bkt, double* __restrict__ img,
+                                                     int w0, int W, int slot) {
+    __shared__ double xs[2048];
+    __shared__ int bks[1024];
+    __shared__ int red;
+    const double* row = tab_x + (int64_t)blockIdx.x * T;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) xs[i] = row[i];
+    for (int q = threadIdx.x; q <= nb; q += blockDim.x) bks[q] = bkt[(int64_t)blockIdx.x * (nb + 1) + q];
+    __syncthreads();
+    band_image_write(xs, bks, &red, T, nb, tmin[blockIdx.x], tmax[blockIdx.x], w0, W, (W + 4 + 1) & ~1, slot, img + (int64_t)blockIdx.x * slot);
+}
+
 // k_table_build + k_table_index as ONE launch, one workgroup per component (blockIdx.x = component k0 + x): the table's T
 // points by the same evaluator as k_table_build (the same bits), kept in LDS for the index phase of k_table_index behind a
 // barrier - a new coefficient vector's inverse tables cost one launch instead of two (6.8 + 6.9 us and the gap).
@@ -1702,9 +1718,11 @@ __global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, co
                                                            const double* __restrict__ fold, const double* __restrict__ pts, int T,
                                                            int nb, double* __restrict__ out, double* __restrict__ tmin,
                                                            double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted,
-                                                           int* unsorted_host) {
+                                                           int* unsorted_host, double* __restrict__ img, int img_w0, int img_W,
+                                                           int img_slot) {
     __shared__ double xs[2048];
     __shared__ int bq[2048];
+    __shared__ int bks[1024];
     __shared__ int bad;
     double* slots;
     CacheStore<double> cst;
@@ -1751,6 +1769,12 @@ __global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, co
             }
         }
         bkt[(int64_t)blockIdx.x * (nb + 1) + q] = a;
+        if (img) bks[q] = a;                                              // (nb + 1 = 1024: the host checked)
+    }
+    // the resident-table image of the component for the banded-map lookup kernel (csrc/ttm_band_image.h)
+    if (img) {
+        __syncthreads();
+        band_image_write(xs, bks, &bad, T, nb, lo, hi, img_w0, img_W, (img_W + 4 + 1) & ~1, img_slot, img + (int64_t)blockIdx.x * img_slot);
     }
 }
 
@@ -2356,6 +2380,7 @@ static const DeviceInfo& device_info() {
     X(band_fwd, -1)      /* 0: banded maps through k_forward_hl instead of the push-form kernel (csrc/ttm_band.hip)   */ \
     X(band_inv, -1)      /* 0: banded maps through k_inverse_rt instead of the push-form kernel                      */ \
     X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */ \
+    X(band_ring, -1)     /* 0: banded table inverse through k_band_inverse (tables assembled per block) although images are at hand */ \
     X(int_dense, -1)     /* 0: integrated maps with dense B sets through the generic kernels instead of csrc/ttm_int.hip */ \
     X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
     X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
@@ -2908,36 +2933,57 @@ int ttm_inverse_table_index(const double* tab_x, int32_t ncomp, int32_t T, int32
     return check_launch("k_table_index");
 }
 
+int64_t ttm_inverse_table_image_doubles(const ttm_program* p, int32_t k0, int32_t k1, int32_t T, int32_t nb) {
+    if (validate(p, k0, k1) || T < 2 || T > 2048 || nb + 1 != 1024 || !u_on(p) || tuning().band_inv == 0) return 0;
+    int w0, W, slot;
+    const Tuning& tn = tuning();
+    if (!ttm_band::image_plan(p, k0, k1, (int)T, (int)nb, device_info().lds_per_cu, tn.rt_window, tn.rt_block, &w0, &W, &slot)) return 0;
+    return slot;
+}
+
 int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* pts,
                                   int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
-                                  int32_t* h_unsorted, void* stream) {
+                                  int32_t* h_unsorted, double* img, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
     if (!coef || !fold || !pts || !out || !tmin || !tmax || !bkt || !unsorted || T < 2 || T > 2048 || nb < 1 || nb > 4096)
         return set_err(TTM_E_ARG, "ttm_inverse_table_build_index: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
+    int iw0 = 0, iW = 0, islot = 0;
+    if (img) {
+        const Tuning& tn = tuning();
+        if ((uintptr_t)img % 16 != 0 || ttm_inverse_table_image_doubles(p, k0, k1, T, nb) == 0 ||
+            !ttm_band::image_plan(p, k0, k1, (int)T, (int)nb, device_info().lds_per_cu, tn.rt_window, tn.rt_block, &iw0, &iW, &islot))
+            return set_err(TTM_E_ARG, "ttm_inverse_table_build_index: no resident-table images for this map and table geometry "
+                                      "(ttm_inverse_table_image_doubles returns 0)%s");
+    }
     if (tuning().table_fused == 0) {
         rc = ttm_inverse_table_build(p, coef, fold, k0, k1, pts, T, out, stream);
         if (!rc) rc = ttm_inverse_table_index(out, k1 - k0, T, nb, tmin, tmax, bkt, unsorted, stream);
         if (!rc && h_unsorted && hipMemcpyAsync(h_unsorted, unsorted, sizeof(int32_t) * (size_t)(k1 - k0), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
             return set_err(TTM_E_HIP, "ttm_inverse_table_build_index: copy of the flags failed%s");
+        if (!rc && img) {
+            hipLaunchKernelGGL(k_table_image, dim3(k1 - k0), dim3(256), 0, (hipStream_t)stream, out, (int)T, (int)nb, tmin, tmax, (const int*)bkt, img,
+                               iw0, iW, islot);
+            rc = check_launch("k_table_image");
+        }
         return rc;
     }
     const int ns = map_slots(p, k0, k1);
-    const size_t stat = 2048 * 8 + 2048 * 4 + 64;               // (the kernel's static arrays)
+    const size_t stat = 2048 * 8 + 2048 * 4 + 1024 * 4 + 64;    // (the kernel's static arrays)
     int bd = 0;
     for (int b = 256; b >= 64; b >>= 1)
         if (lds_bytes(ns, b, 0) + stat <= (size_t)kLdsBudget) { bd = b; break; }
     if (!bd) return set_err(TTM_E_LIMIT, "ttm_inverse_table_build_index: %s%lld scratch slots do not fit the LDS budget", "", ns);
     hipLaunchKernelGGL(k_table_build_index, dim3(k1 - k0), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, coef,
-                       fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted, (int*)h_unsorted);
+                       fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted, (int*)h_unsorted, img, iw0, iW, islot);
     return check_launch("k_table_build_index");
 }
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,
                       int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
-                      int32_t truncate, void* stream) {
+                      int32_t truncate, const double* img, int64_t img_doubles, void* stream) {
     int rc = validate(p, k0, k1);
     if (rc) return rc;
     if (!coef || !fold || !Zsoa || !Xsoa || !tab_x || !tab_y || !tmin || !tmax || !bkt || N < 1 || ldx < N || ldz < N || T < 2 ||
@@ -2955,7 +3001,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         if (tn.band_inv != 0 && truncate && ttm_band::usable(p, k0, k1)) {
             const char* name = nullptr;
             if (ttm_band::inverse(p, fold + fold_base_size(p), k0, k1, Zsoa, ldz, Xsoa, ldx, N, tab_x, (int)T, h_y_affine, tmin, tmax, bkt, (int)nb,
-                                  tn.band_cus > 0 ? tn.band_cus : di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
+                                  tn.band_ring != 0 ? img : nullptr, (int)img_doubles, tn.band_cus > 0 ? tn.band_cus : di.cus, di.lds_per_cu, tn.rt_window, tn.rt_block, stream, &name) == 0)
                 return check_launch(name);
         }
       // k_inverse_rt sweeps the hot records themselves: not for lag-3 maps (include/ttm.h), and with fewer than four

@@ -809,7 +809,7 @@ class transport_map():
         if getattr(self, 'deferred_checks', False):
             if pending is not None:
                 tkey, entry = pending
-                coef._ttm_tables[tkey] = entry[:4] + (True,)
+                coef._ttm_tables[tkey] = entry[:4] + (True, entry[5])
             # (the ring slot is reused eight vectors on: validate() must have read it by then - it copies at once)
             coef._ttm_pending = (fold, pending, errs, flags, done)
             return coef
@@ -818,7 +818,7 @@ class transport_map():
             return self._fold(coef)                     # (U-form rejected: folded again without it, the plain path)
         if pending is not None:
             tkey, entry = pending
-            coef._ttm_tables[tkey] = entry[:4] + (int(flags.numpy().max()) == 0,)
+            coef._ttm_tables[tkey] = entry[:4] + (int(flags.numpy().max()) == 0, entry[5])
         return coef
 
     def _fold(self, coef):
@@ -846,7 +846,7 @@ class transport_map():
                 errs.copy_(fold[off:off + 2 * self._cm.D], non_blocking=True)
             if pending is not None:
                 tkey, entry = pending
-                coef._ttm_tables[tkey] = entry[:4] + (True,)
+                coef._ttm_tables[tkey] = entry[:4] + (True, entry[5])
                 flags = torch.empty(entry[4].numel(), dtype=torch.int32, pin_memory=True)
                 flags.copy_(entry[4], non_blocking=True)
             done = torch.cuda.Event()
@@ -862,7 +862,7 @@ class transport_map():
             pending = self._launch_default_tables(coef) if self._eager_tables() else None
         if pending is not None:
             tkey, entry = pending
-            coef._ttm_tables[tkey] = entry[:4] + (int(entry[4].cpu().max().item()) == 0,)
+            coef._ttm_tables[tkey] = entry[:4] + (int(entry[4].cpu().max().item()) == 0, entry[5])
         coef._ttm_epoch = self._epoch
         return coef
 
@@ -887,7 +887,7 @@ class transport_map():
         if pending is not None:
             tkey, entry = pending
             if int(flags.numpy().max()) != 0:
-                coef._ttm_tables[tkey] = entry[:4] + (False,)
+                coef._ttm_tables[tkey] = entry[:4] + (False, entry[5])
                 ok = False
         if coef._ttm_epoch == self._epoch and errs is not None and not self._check_uform(fold, errs.numpy()):
             saved, self.deferred_checks = self.deferred_checks, False
@@ -917,12 +917,20 @@ class transport_map():
         tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
         bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
         uns_d = self._empty(ncomp, dtype=torch.int32)
+        img_d = self._table_images(0, ncomp, resolution, nb)
         _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), 0, ncomp,
                                                             self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
                                                             self._ptr(tmin_d), self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
                                                             ctypes.c_void_p(uns_d.data_ptr()),
-                                                            None if h_unsorted is None else ctypes.c_void_p(h_unsorted.data_ptr()), st))
-        return (0, ncomp, resolution, start_distance, nb), (out_d, tmin_d, tmax_d, bkt_d, uns_d)
+                                                            None if h_unsorted is None else ctypes.c_void_p(h_unsorted.data_ptr()),
+                                                            self._ptr(img_d), st))
+        return (0, ncomp, resolution, start_distance, nb), (out_d, tmin_d, tmax_d, bkt_d, uns_d, img_d)
+
+    def _table_images(self, k0, k1, resolution, nb):
+        """Room for the resident-table images of the components [k0, k1) (include/ttm.h: ttm_inverse_table_build_index writes them,
+        the lookup kernel of banded maps copies them into LDS by DMA), or None when this map / table geometry has no such kernel."""
+        per = int(self._lib.ttm_inverse_table_image_doubles(self._pp, k0, k1, resolution, nb))      # (asked every time: a function of the launch options too)
+        return self._empty((k1 - k0) * per) if per > 0 else None
 
     def _inv_nb(self):
         """Buckets of the table index (~ table points; nb + 1 int32 per row = whole 16-byte units); TTM_INV_NB is read once."""
@@ -1195,27 +1203,31 @@ class transport_map():
             tmin_d, tmax_d = self._empty(ncomp), self._empty(ncomp)
             bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
             uns_d = self._empty(ncomp, dtype=torch.int32)
+            img_d = None
             if resolution <= 2048:
-                # table + its index (range, sortedness, bucket index) in one launch
+                # table + its index (range, sortedness, bucket index, resident-table images) in one launch
+                img_d = self._table_images(k0, k1, resolution, nb)
                 _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                                     self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
                                                                     self._ptr(tmin_d), self._ptr(tmax_d),
-                                                                    ctypes.c_void_p(bkt_d.data_ptr()), ctypes.c_void_p(uns_d.data_ptr()), None, st))
+                                                                    ctypes.c_void_p(bkt_d.data_ptr()), ctypes.c_void_p(uns_d.data_ptr()), None,
+                                                                    self._ptr(img_d), st))
             else:
                 _capi.check(self._lib.ttm_inverse_table_build(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                               self._ptr(self._pts_d), resolution, self._ptr(out_d), st))
                 _capi.check(self._lib.ttm_inverse_table_index(self._ptr(out_d), ncomp, resolution, nb, self._ptr(tmin_d),
                                                               self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
                                                               ctypes.c_void_p(uns_d.data_ptr()), st))
-            cache[tkey] = (out_d, tmin_d, tmax_d, bkt_d, int(uns_d.cpu().max().item()) == 0)    # (one copy of D flags, no reduction launch)
-        out_d, tmin_d, tmax_d, bkt_d, is_sorted = cache[tkey]
+            cache[tkey] = (out_d, tmin_d, tmax_d, bkt_d, int(uns_d.cpu().max().item()) == 0, img_d)    # (one copy of D flags, no reduction launch)
+        out_d, tmin_d, tmax_d, bkt_d, is_sorted, img_d = cache[tkey]
         if N == 0:
             return                                      # (tables only)
         if is_sorted:
             _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                     self._ptr(Zs, row0), Zs.shape[1], self._ptr(Xs, row0), Xs.shape[1], N, self._ptr(out_d),
                                                     self._ptr(self._pts_d), 0, resolution, self._pts_affine, self._ptr(tmin_d),
-                                                    self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
+                                                    self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, self._ptr(img_d),
+                                                    0 if img_d is None else img_d.numel() // ncomp, st))
             return
         # rare: some table is not non-decreasing -> reproduce interp1d's stable sort on the host and redo
         out = out_d.cpu().numpy()
@@ -1232,7 +1244,7 @@ class transport_map():
         _capi.check(self._lib.ttm_inverse_table(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), k0, k1,
                                                 self._ptr(Zs, row0), Zs.shape[1], self._ptr(Xs, row0), Xs.shape[1], N, self._ptr(tab_x_d),
                                                 self._ptr(tab_y_d), resolution, resolution, None, self._ptr(tmin_d),
-                                                self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, st))
+                                                self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, trunc, None, 0, st))
 
     def _inverse_bisect(self, coef, k0, k1, Zs, Xs, N):
         """TM:3798-3985.  Samples 1..N-1 run to convergence and record the largest
