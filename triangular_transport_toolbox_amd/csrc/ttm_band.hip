@@ -57,6 +57,32 @@ __host__ __device__ constexpr int rec_stride(int cls, int lag) { return (TTM_P_H
 #define BAND_PF 1                                    /* columns requested ahead of the one being evaluated */
 #endif
 
+// One LDS-DMA instruction (16 bytes per lane: the wave's 1 KB lands at lds_wave_base, an LDS byte address, lane after lane),
+// written in assembly so that the COMPILER DOES NOT KNOW IT: with a global_load_lds it knows to be in flight hipcc waits for
+// vmcnt(0) at the next use of any ordinary load (the column prefetch would be drained every step).  Unknown to it, its
+// counted waits are merely one stricter per copy among the younger operations: place the copy behind the step's wait for z,
+// and that wait retires the PREVIOUS step's copy (a whole step old) and nothing else.
+__device__ __forceinline__ void band_dma16(const void* g, unsigned int lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "m0");
+}
+__device__ __forceinline__ unsigned int band_lds_addr(const void* p) {
+    return (unsigned int)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// n doubles (even; both sides 16-byte aligned) from memory into LDS: every 16-byte unit requested at once by DMA, then waited
+// for - one memory round trip.  (A loop of load / store pairs through registers is compiled to load, wait, store per trip:
+// nine dependent round trips for the 140 KB of splines of C5.)  The caller's barrier publishes the bytes.
+template <bool WAIT = true>
+__device__ __forceinline__ void band_stage(double* lds_dst, const double* src, int n) {
+    const int units = n >> 1;
+    const unsigned int base = band_lds_addr(lds_dst);
+    for (int u0 = 0; u0 < units; u0 += BAND_CT) {
+        const int u = u0 + (int)threadIdx.x;
+        if (u < units) band_dma16(src + 2 * (size_t)u, __builtin_amdgcn_readfirstlane(base + (unsigned int)(u0 + ((int)threadIdx.x & ~63)) * 16u));
+    }
+    if (WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------
 // push records from the hot records (one workgroup of 64 threads per record)
 // ---------------------------------------------------------------------------
@@ -397,7 +423,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
     if (c0 >= N) return;
     const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
     const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
-    for (int i = tid; i < TTM_BAND_ET_N; i += CT) *(D2*)(etab + 2 * i) = *(const D2*)(g_band_etab + 2 * i);
+    band_stage<false>(etab, g_band_etab, 2 * TTM_BAND_ET_N);      // (waited for with the first block's splines)
     cdbl_p P = (cdbl_p)(U_ + p_off);
     cdbl_p kt = (cdbl_p)g_band_taylor;
     const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
@@ -449,7 +475,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
                 cint_p rb = (cint_p)(P + (int64_t)(kb + LAG) * PS), re = (cint_p)(P + (int64_t)(ke - 1 + LAG) * PS);
                 tab0 = rb[11];
                 const int n = re[11] + TTM_U_TSTRIDE * re[10] - tab0;
-                for (int i = 2 * tid; i < n; i += 2 * CT) *(D2*)(tabs + i) = *(const D2*)(U_ + tab0 + i);
+                band_stage(tabs, U_ + tab0, n);
             }
             __syncthreads();
             const int colb = kcol0 + (kb - k0);
@@ -664,7 +690,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_logdet(const double* __restric
             }
             tab0 = tb < 0 ? 0 : tb;
             const int n = tb < 0 ? 0 : te - tb;
-            for (int i = 2 * tid; i < n; i += 2 * CT) *(D2*)(tabs + i) = *(const D2*)(U_ + tab0 + i);
+            band_stage(tabs, U_ + tab0, n);
         }
         __syncthreads();
         for (int tile = 0; tile < ntile; ++tile) {
@@ -803,7 +829,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
     if (c0 >= N) return;
     const int64_t c1 = c0 + rows_per_wg < N ? c0 + rows_per_wg : N;
     const int ntile = (int)((c1 - c0 + ROWS - 1) / ROWS);
-    for (int i = tid; i < TTM_BAND_ET_N; i += CT) *(D2*)(etab + 2 * i) = *(const D2*)(g_band_etab + 2 * i);
+    band_stage<false>(etab, g_band_etab, 2 * TTM_BAND_ET_N);      // (waited for with the first block's splines)
     cdbl_p P = (cdbl_p)(U_ + p_off);
     cdbl_p kt = (cdbl_p)g_band_taylor;
     const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);      // first row of the last readable pair
@@ -818,7 +844,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_forward(const double* __restri
             cint_p rb = (cint_p)(P + (int64_t)(kb + LAG) * PS), re = (cint_p)(P + (int64_t)(ke - 1 + LAG) * PS);
             tab0 = rb[11];
             const int n = re[11] + TTM_U_TSTRIDE * re[10] - tab0;           // doubles (even)
-            for (int i = 2 * tid; i < n; i += 2 * CT) *(D2*)(tabs + i) = *(const D2*)(U_ + tab0 + i);
+            band_stage(tabs, U_ + tab0, n);
         }
         __syncthreads();
         const int colb = kcol0 + (kb - k0);                   // column of component kb
@@ -1177,18 +1203,6 @@ struct BandRing {
     int tpos, tcomp;               // slot the next step refills, component whose image goes there
     int gcnt;                      // steps since the last meeting
 };
-
-// One LDS-DMA instruction (16 bytes per lane: the wave's 1 KB lands at lds_wave_base, an LDS byte address, lane after lane),
-// written in assembly so that the COMPILER DOES NOT KNOW IT: with a global_load_lds it knows to be in flight hipcc waits for
-// vmcnt(0) at the next use of any ordinary load (the column prefetch would be drained every step).  Unknown to it, its
-// counted waits are merely one stricter per copy among the younger operations: place the copy behind the step's wait for z,
-// and that wait retires the PREVIOUS step's copy (a whole step old) and nothing else.
-__device__ __forceinline__ void band_dma16(const void* g, unsigned int lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "m0");
-}
-__device__ __forceinline__ unsigned int band_lds_addr(const void* p) {
-    return (unsigned int)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
-}
 
 // the images of the steps [0, n) into the slots [0, n) (in front of the first column: 16 bytes per lane and round)
 __device__ __forceinline__ void band_ring_fill(const double* img, int ncomp, double* tabs, int tab_slot, int n) {
