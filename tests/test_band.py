@@ -406,6 +406,16 @@ def test_ring_inverse_equals_the_block_inverse_and_the_oracle(D, ttm_opt):
         assert np.array_equal(Xi, X_ring), (cus, block)
         Xb, name = run(0, cus, block)
         assert name == 'k_band_inverse' and relerr(Xb, X_ring) < 1e-14, (cus, block)
+    # a sweep that starts inside the map (conditional inverse): the running sums start from the two columns in front
+    E = 3
+    Xc_o = om.inverse_map(Zin[:, E:], X_star=X[:, :E])
+    got = {}
+    for ring in (1, 0):
+        ttm_opt('band_ring', ring); ttm_opt('band_cus', -1); ttm_opt('rt_block', -1)
+        tm._pack_memo = None
+        got[ring] = tm.inverse_map(Zin[:, E:], X_star=X[:, :E])
+        assert relerr(got[ring], Xc_o) < 1e-11
+    assert np.array_equal(got[1], got[0])
 
 
 @pytest.mark.gpu
