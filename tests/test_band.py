@@ -349,19 +349,20 @@ def test_staged_fold_with_recycled_buffers_equals_the_copying_path(ttm_opt):
         ttm_opt('fold_fused', -1)
 
 
-def _ring_map(D, n=5003, seed=3):
-    """A C5-shaped banded map of D components with moderate random coefficients (tables monotone), device map + oracle."""
+def _ring_map(D, n=5003, seed=3, shape=(3, 1, 2), nm_scale=0.3):
+    """A banded map of D components (shape: Hermite-function order, plain order, iRBF terms - (3, 1, 2) is the C5 shape) with
+    moderate random coefficients (tables monotone), device map + oracle."""
     from triangular_transport_toolbox_amd.transport_map import transport_map
     from oracle.ttm_oracle import OracleMap
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((n, D)) * (1.0 + 0.3 * rng.random(D)) + 0.2 * rng.standard_normal((n, 1))
-    mon, non = _synthetic_separable(D, 2, 3, 1, 2)
+    mon, non = _synthetic_separable(D, 2, *shape)
     kw = dict(monotonicity='separable monotonicity')
     tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
     om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
     for k in range(D):
         cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
-        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        cn_ = nm_scale * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
         tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
     return tm, om, X, rng
@@ -452,3 +453,31 @@ def test_table_images_fused_and_separate_launches_and_layout_mismatch(ttm_opt):
     tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N)
     assert lib.ttm_last_kernel().decode() == 'k_band_inverse'
     assert relerr(Xw, Xo) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,cls', [((5, 3, 2), 2), ((7, 6, 2), 3)])
+def test_ring_inverse_of_the_higher_degree_classes(shape, cls, ttm_opt):
+    """The ring kernel's refill variants (8 and 4 columns at a time) for the degree classes (5,5) and (7,7): against the block
+    kernel bit for bit and the oracle."""
+    D = 26
+    tm, om, X, rng = _ring_map(D, n=4099, shape=shape, nm_scale=0.04)        # (tame offsets: 26 inversions in a row feed on each other)
+    assert tm._cm.u_h_cls == cls and tm._cm.u_p_lag == 2
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    Zin = rng.standard_normal((len(X), D))
+    Zin[:30] *= 3.0
+    Xo = om.inverse_map(Zin)
+    ttm_opt('u_loader', 1); ttm_opt('band_inv', 1)
+    res = {}
+    for ring, block in ((0, -1), (1, -1), (1, 12), (1, 16)):
+        ttm_opt('band_ring', ring); ttm_opt('rt_block', block)
+        tm._pack_memo = None
+        res[(ring, block)] = tm.inverse_map(Zin)
+        tm.inverse_device(tm._cols(D, tm._N, zero=True), tm._N)
+        assert lib.ttm_last_kernel().decode() == ('k_band_inverse_ring' if ring else 'k_band_inverse')
+        # (the oracle sums the offsets in another order, which the degree-5 / degree-7 groups amplify along 26 inversions in a row whose
+        # results reach |x| = 12: 2e-11 for BOTH kernels at class (5,5); test_band_kernels_… holds the 5-component maps to 1e-11)
+        assert relerr(res[(ring, block)], Xo) < 1e-10, (ring, block)
+    for key in ((1, -1), (1, 12), (1, 16)):
+        assert np.array_equal(res[key], res[(0, -1)]), key
