@@ -21,16 +21,20 @@ lib.ttm_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int32]
 
 PATHS = [dict(), dict(u_loader=1), dict(u_loader=1, band_fwd=0, band_inv=0), dict(u_loader=1, band_fwd=0, band_inv=0, rt_band=0),
          dict(u_loader=1, band_fwd=0, band_inv=0, hl_ns=2, rt_ns=2), dict(u_loader=1, u_no_hot=1), dict(u_loader=0, band_fwd=0, u_ns=4),
-         dict(no_uform=1), dict(no_plan=1, no_uform=1), dict(u_loader=1, rt_off=1, band_inv=0), dict(u_loader=1, band_fwd=1, band_inv=1, band_cus=3, rt_block=2)]
+         dict(no_uform=1), dict(no_plan=1, no_uform=1), dict(u_loader=1, rt_off=1, band_inv=0), dict(u_loader=1, band_fwd=1, band_inv=1, band_cus=3, rt_block=2),
+         # (round 4: the table inverse with resident-table images - all resident, rings of 12 / 16 slots, several tiles - and without)
+         dict(u_loader=1, band_ring=0), dict(u_loader=1, rt_block=12), dict(u_loader=1, rt_block=16, band_cus=1), dict(u_loader=1, rt_window=400)]
 
 
-def random_spec(rng):
+def random_spec(rng, long_map=False):
     D = int(rng.integers(1, 9))
     skip = int(rng.choice([0, 0, 0, 1, 2]))
     band = int(rng.choice([1, 2, 2, 2, 3, 4]))
+    if long_map:                                     # (seeds >= 100000: maps long enough for the ring of resident tables to be refilled)
+        D, skip, band = int(rng.integers(13, 34)), 0, int(rng.choice([1, 2, 2, 2]))
     family = 'hermite function'
     hf_max, plain_max = int(rng.choice([2, 3, 5])), int(rng.choice([0, 1, 3]))
-    if rng.random() < 0.4:
+    if rng.random() < 0.4 and not long_map:
         family = str(rng.choice(['legendre', 'chebyshev', 'power series', "probabilist's hermite", 'hermite']))
         hf_max, plain_max = 0, int(rng.choice([1, 2, 3]))
     mon, non = [], []
@@ -49,7 +53,7 @@ def random_spec(rng):
                     nm.append([j] * o + ['HF'])
         non.append(nm)
         m = ['LET %d' % kc] + ['iRBF %d' % kc] * int(rng.integers(0, 3)) + ['RET %d' % kc]
-        if rng.random() < 0.25:
+        if rng.random() < 0.25 and not long_map:
             m = [[kc]] + m
         mon.append(m)
     return D, skip, mon, non, family
@@ -57,7 +61,7 @@ def random_spec(rng):
 
 def one(seed):
     rng = np.random.default_rng(9000 + seed)
-    D, skip, mon, non, family = random_spec(rng)
+    D, skip, mon, non, family = random_spec(rng, long_map=seed >= 100000)
     d = D + skip
     n = int(rng.choice([257, 2049, 5003]))
     X = rng.standard_normal((n, d)) @ (np.tril(rng.standard_normal((d, d)) * 0.3) + np.eye(d)).T
@@ -66,7 +70,7 @@ def one(seed):
     om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
     for k in range(D):
         cm_ = 0.2 + 0.5 * rng.random(len(tm.coeffs_mon[k]))
-        cn_ = 0.3 * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
+        cn_ = (0.06 if seed >= 100000 else 0.3) * rng.standard_normal(len(tm.coeffs_nonmon[k])) / (1 + np.arange(len(tm.coeffs_nonmon[k])))
         tm.coeffs_mon[k], om.coeffs_mon[k] = cm_.copy(), cm_.copy()
         tm.coeffs_nonmon[k], om.coeffs_nonmon[k] = cn_.copy(), cn_.copy()
     Zo = om.map(X)
