@@ -53,6 +53,12 @@ __host__ __device__ constexpr int rec_stride(int cls, int lag) { return (TTM_P_H
 #ifndef BAND_INV_NT
 #define BAND_INV_NT 0
 #endif
+#ifndef BAND_FWD_NTL
+#define BAND_FWD_NTL 0                               /* non-temporal loads of the forward map's columns */
+#endif
+#ifndef BAND_INV_NTL
+#define BAND_INV_NTL 0
+#endif
 #ifndef BAND_PF
 #define BAND_PF 1                                    /* columns requested ahead of the one being evaluated */
 #endif
@@ -158,13 +164,12 @@ __device__ __forceinline__ void band_store2(char* p, double a, double b) {
     if (NT) __builtin_nontemporal_store(v, (v2*)p);
     else *(v2*)p = v;
 }
+template <bool NT = false>
 __device__ __forceinline__ D2 band_load2(const char* p) {
     typedef double v2 __attribute__((ext_vector_type(2)));
-#ifdef BAND_NT_LOAD
-    const v2 v = __builtin_nontemporal_load((const v2*)p);
-#else
-    const v2 v = *(const v2*)p;
-#endif
+    v2 v;
+    if (NT) v = __builtin_nontemporal_load((const v2*)p);
+    else v = *(const v2*)p;
     const D2 r = {v.x, v.y};
     return r;
 }
@@ -276,14 +281,14 @@ __device__ __forceinline__ void band_forward_tile(cdbl_p P, cdbl_p kt, const dou
     for (int i = 0; i < PF; ++i) {
         const char* xc0 = xcol + (int64_t)(kb + i < ke ? i : 0) * ldxb;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) xr[i][q] = band_load2(xc0 + roff[q]);
+        for (int q = 0; q < NP; ++q) xr[i][q] = band_load2<BAND_FWD_NTL != 0>(xc0 + roff[q]);
     }
     cdbl_p rec = P + (int64_t)(kb + LAG) * PS;
     auto step = [&](int j, const D2 (&xc)[NP], D2 (&xn)[NP]) {
         {
             const char* xnext = j + PF < ke ? xcol + PF * ldxb : xcol;        // (past the block: a harmless re-read)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) xn[q] = band_load2(xnext + roff[q]);
+            for (int q = 0; q < NP; ++q) xn[q] = band_load2<BAND_FWD_NTL != 0>(xnext + roff[q]);
         }
         __builtin_amdgcn_sched_barrier(0);                    // (the scheduler would sink the loads to the end of the step)
         // ---- uniform data of the step ------------------------------------------------------------------------
@@ -1235,7 +1240,7 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
         for (int q = 0; q < NP; ++q) za[q] = zfirst[q];
     } else {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) za[q] = band_load2(zcol + roff[q]);
+        for (int q = 0; q < NP; ++q) za[q] = band_load2<BAND_INV_NTL != 0>(zcol + roff[q]);
     }
     // interp1d slope form (TM:4062-4065) in the located interval and exp(-x^2/4) = E[i-1] exp(w), w = -delta (y_lo + x) / 4
     auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
@@ -1258,7 +1263,7 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
         {
             const char* znext = j + 1 < ke ? zcol + cx.ldzb : zcol;           // (past the block: a harmless re-read)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) zn[q] = band_load2(znext + roff[q]);
+            for (int q = 0; q < NP; ++q) zn[q] = band_load2<BAND_INV_NTL != 0>(znext + roff[q]);
         }
         // the record of the step, requested NOW (left to itself the compiler loads the group coefficients where the pushes
         // use them - at the end of the step's dependent chain, a scalar-cache round trip on the critical path)
@@ -1466,7 +1471,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse(const double* __restri
             for (int q = 0; q < NP; ++q) {
                 unsigned int n = (unsigned int)c0 + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
                 n = n < last_pair ? n : last_pair;
-                zfirst[q] = band_load2(zc0 + (size_t)(n * 8u));
+                zfirst[q] = band_load2<BAND_INV_NTL != 0>(zc0 + (size_t)(n * 8u));
             }
         }
         __syncthreads();                                      // every wave is done with the previous block's tables
@@ -1641,7 +1646,7 @@ __global__ __launch_bounds__(BAND_CT) void k_band_inverse_ring(const double* __r
     for (int q = 0; q < NP; ++q) {
         unsigned int n = (unsigned int)c0 + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
         n = n < last_pair ? n : last_pair;
-        zfirst[q] = band_load2((const char*)Z + (size_t)(n * 8u));
+        zfirst[q] = band_load2<BAND_INV_NTL != 0>((const char*)Z + (size_t)(n * 8u));
     }
     band_ring_fill(img, ncomp, tabs, tab_slot, R);
     for (int i = tid; i < W; i += CT) {
