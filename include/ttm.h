@@ -430,6 +430,13 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
  * into LDS by DMA instead of assembling them per workgroup.  A pure function of the table: passing it changes no result.
  * ttm_inverse_table_image_doubles returns 0 when the map / table geometry has no such kernel (img must then be NULL).       */
 int64_t ttm_inverse_table_image_doubles(const ttm_program* p, int32_t k0, int32_t k1, int32_t T, int32_t nb);
+/* ttm_setup_staged: ttm_fold_staged and ttm_inverse_table_build_index of ALL components (k0 = 0, k1 = D) as ONE launch whose two
+ * kinds of workgroups run side by side (the tables need only the folded coefficients: the table workgroups fold for themselves into
+ * fold2, a scratch of ttm_fold_size doubles, zero-filled once per layout like fold, that nobody else reads).  Every output as the
+ * two calls write it, bit for bit.  TTM_E_UNSUPPORTED: not for this map (the caller makes the two calls instead).                  */
+int ttm_setup_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* fold2, double* h_err,
+                     const double* pts, int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
+                     int32_t* h_unsorted, double* img, void* stream);
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1,
                       const double* Zsoa, int64_t ldz, double* Xsoa, int64_t ldx, int64_t N,
                       const double* tab_x, const double* tab_y, int64_t ldy, int32_t T,

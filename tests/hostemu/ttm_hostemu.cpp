@@ -748,6 +748,15 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
 
 int64_t ttm_inverse_table_image_doubles(const ttm_program*, int32_t, int32_t, int32_t, int32_t) { return 0; }
 
+int ttm_setup_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* fold2, double* h_err, const double* pts,
+                     int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted, int32_t* h_unsorted,
+                     double* img, void* stream) {
+    if (!fold2 || fold2 == fold) return TTM_E_ARG;
+    int rc = ttm_fold_staged(p, h_coef, coef, fold, h_err, stream);
+    if (!rc) rc = ttm_inverse_table_build_index(p, coef, fold, 0, p->D, pts, T, nb, out, tmin, tmax, bkt, unsorted, h_unsorted, img, stream);
+    return rc;
+}
+
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Z,
                       int64_t ldz, double* X, int64_t ldx, int64_t N, const double* tab_x, const double* tab_y, int64_t ldy,
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,

@@ -333,7 +333,7 @@ def test_staged_fold_with_recycled_buffers_equals_the_copying_path(ttm_opt):
             tm.coeffs_mon[k] = base_mon[k] * (1.0 + 0.01 * (i + 1))
         tm._pack_memo = None
         coef = tm._pack_coeffs()
-        assert tm._lib.ttm_last_kernel().decode() == 'k_table_build_index'
+        assert tm._lib.ttm_last_kernel().decode() == 'k_setup'                       # (fold + U section + tables: one launch)
         torch.cuda.synchronize()
         got = (coef.clone(), coef._ttm_fold.clone(), [t.clone() if hasattr(t, 'clone') else t for t in list(coef._ttm_tables.values())[0]])
         del coef
@@ -481,3 +481,54 @@ def test_ring_inverse_of_the_higher_degree_classes(shape, cls, ttm_opt):
         assert relerr(res[(ring, block)], Xo) < 1e-10, (ring, block)
     for key in ((1, -1), (1, 12), (1, 16)):
         assert np.array_equal(res[key], res[(0, -1)]), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['c5_shape', 'class_77', 'few_c3', 'few_entf'])
+def test_one_launch_setup_equals_the_two_launches(case, ttm_opt):
+    """ttm_setup_staged (k_setup: the uform workgroups and the table workgroups of a new coefficient vector side by side, the table
+    workgroups folding privately into a scratch copy) against ttm_fold_staged + ttm_inverse_table_build_index: folded coefficients
+    with their U section, tables, ranges, bucket indices, flags, resident-table images - bit for bit, over several vectors in a row
+    (the scratch copy is reused)."""
+    import torch
+    tm, om, X, rng = _build(case)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    tm._inverse_seen = True                                   # (the default tables ride along with the fold from now on)
+    tm.deferred_checks = True
+
+    def setup(vec):
+        for k in range(tm.D):
+            tm.coeffs_mon[k] = vec[0][k].copy()
+            tm.coeffs_nonmon[k] = vec[1][k].copy()
+        tm._pack_memo = None
+        coef = tm._pack_coeffs()
+        name = lib.ttm_last_kernel().decode()
+        assert tm.validate(coef)
+        torch.cuda.synchronize()
+        entry = next(iter(coef._ttm_tables.values()))
+        return coef._ttm_fold.clone(), [None if (t is None or isinstance(t, bool)) else t.clone() for t in entry], name
+    vecs = []
+    for i in range(3):
+        vecs.append(([0.2 + 0.5 * rng.random(len(c)) for c in tm.coeffs_mon],
+                     [0.3 * rng.standard_normal(len(c)) / (1 + np.arange(len(c))) for c in tm.coeffs_nonmon]))
+    one = [setup(v) for v in vecs]
+    assert all(name == 'k_setup' for _, _, name in one), [n for _, _, n in one]
+    ttm_opt('setup_fused', 0)
+    two = [setup(v) for v in vecs]
+    assert all(name == 'k_table_build_index' for _, _, name in two), [n for _, _, n in two]
+    for (fa, ta, _), (fb, tb, _) in zip(one, two):
+        assert fa.view(torch.int64).equal(fb.view(torch.int64))
+        for a, b in zip(ta, tb):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b)
+    # and the maps the vectors define
+    Zin = rng.standard_normal((len(X), tm.D))
+    E = CASES[case]['d'] - CASES[case]['D']
+    ttm_opt('setup_fused', -1)
+    tm._pack_memo = None
+    Xi = tm.inverse_map(Zin, X_star=X[:, :E] if E else None)
+    for k in range(tm.D):
+        om.coeffs_mon[k], om.coeffs_nonmon[k] = tm.coeffs_mon[k].copy(), tm.coeffs_nonmon[k].copy()
+    assert relerr(Xi, om.inverse_map(Zin, X_star=X[:, :E] if E else None)) < 1e-10

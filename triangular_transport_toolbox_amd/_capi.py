@@ -72,6 +72,7 @@ _SIGNATURES = {
     'ttm_inverse_table_index': (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ttm_inverse_table_build_index': (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ttm_inverse_table_image_doubles': (c_i64, [ctypes.POINTER(ttm_program), c_i32, c_i32, c_i32, c_i32]),
+    'ttm_setup_staged': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'ttm_inverse_table': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                          c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp]),
     'ttm_inverse_bisect': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,

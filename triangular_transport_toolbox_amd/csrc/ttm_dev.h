@@ -105,16 +105,17 @@ extern __shared__ __align__(16) double g_smem[];
 // LDS image: [erf table | column cache (8 x NS x blockDim) | per-thread slots ...]
 // stage_erf = false: the launch evaluates no special term (the erf table is neither loaded nor read; its LDS stays reserved so
 // that the image layout - and lds_bytes() on the host - is the same)
+// bd: the threads that evaluate (the first bd of the workgroup; the layout is that of a workgroup of bd threads)
 template <class R>
-__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots, bool stage_erf = true) {
+__device__ __forceinline__ Prog make_prog_lds_n(const DevProg& P, CacheStore<R>& cache, double*& slots, int bd, bool stage_erf = true) {
     double* et = g_smem;
     if (stage_erf) {
         for (int i = threadIdx.x; i < TTM_ERF_TABLE_LEN; i += blockDim.x) et[i] = g_erf_table[i];
         __syncthreads();
     }
     cache.base = et + TTM_ERF_TABLE_LEN + threadIdx.x;
-    cache.stride = blockDim.x;
-    slots = et + TTM_ERF_TABLE_LEN + (size_t)TTM_CACHE_SLOTS * lanes_of<R>::value * blockDim.x;
+    cache.stride = bd;
+    slots = et + TTM_ERF_TABLE_LEN + (size_t)TTM_CACHE_SLOTS * lanes_of<R>::value * bd;
     Prog g;
     g.qx = (cdbl_p)P.qx;
     g.qw = (cdbl_p)P.qw;
@@ -125,6 +126,11 @@ __device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& c
     g.rect = P.rect;
     g.delta = P.delta;
     return g;
+}
+
+template <class R>
+__device__ __forceinline__ Prog make_prog_lds(const DevProg& P, CacheStore<R>& cache, double*& slots, bool stage_erf = true) {
+    return make_prog_lds_n(P, cache, slots, (int)blockDim.x, stage_erf);
 }
 
 // component k of the program; coefficient / folded arrays are given relative to component kbase

@@ -454,12 +454,13 @@ struct UTabs {               // by-value kernel argument
 // costs no copy in the stream (an H2D copy between two kernels sits between two engine switches: 3.7 us + 10.8 us of gap in
 // front of it, tools/trace_uncached.sh).  err_host != nullptr: the component's two fit errors also go to page-locked host
 // memory by system-scope stores (the host reads them behind an event instead of behind a D2H copy).
-__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ coef_src, double* coef,
-                                                double* __restrict__ fold, double* __restrict__ U, int64_t err_off, int64_t h_off,
-                                                int h_cls, int h_ng, int64_t p_off, int p_lag, int p_stride, double* err_host) {
+// what one workgroup does for component k of a new coefficient vector (k_uform; the uform half of k_setup)
+__device__ __forceinline__ void uform_body(const DevProg& P, const UTabs& T, int k, const double* __restrict__ coef_src, double* coef,
+                                           double* __restrict__ fold, double* __restrict__ U, int64_t err_off, int64_t h_off, int h_cls,
+                                           int h_ng, int64_t p_off, int p_lag, int p_stride, double* err_host) {
     __shared__ double ybuf[TTM_U_NI_MAX * TTM_CHEB_N];
     __shared__ double red[2][16];
-    const int k = blockIdx.x, tid = threadIdx.x, bd = blockDim.x;
+    const int tid = threadIdx.x, bd = blockDim.x;
     const int D1 = P.D + 1;
     const int* uc = T.ucomp + k * TTM_UC_LEN;
     const int* fd = P.fdesc + k * TTM_FDESC_LEN;
@@ -513,6 +514,12 @@ __global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double
             __hip_atomic_store(err_host + 2 * k + 1, ed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_uform(DevProg P, UTabs T, const double* __restrict__ coef_src, double* coef,
+                                                double* __restrict__ fold, double* __restrict__ U, int64_t err_off, int64_t h_off,
+                                                int h_cls, int h_ng, int64_t p_off, int p_lag, int p_stride, double* err_host) {
+    uform_body(P, T, (int)blockIdx.x, coef_src, coef, fold, U, err_off, h_off, h_cls, h_ng, p_off, p_lag, p_stride, err_host);
 }
 
 // NS rows of one thread inside the current tile (32-bit row numbers: the column base stays a scalar pointer and
@@ -1714,52 +1721,54 @@ __global__ __launch_bounds__(256) void k_table_image(const double* __restrict__ 
 // k_table_build + k_table_index as ONE launch, one workgroup per component (blockIdx.x = component k0 + x): the table's T
 // points by the same evaluator as k_table_build (the same bits), kept in LDS for the index phase of k_table_index behind a
 // barrier - a new coefficient vector's inverse tables cost one launch instead of two (6.8 + 6.9 us and the gap).
-__global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, const double* __restrict__ coef,
-                                                           const double* __restrict__ fold, const double* __restrict__ pts, int T,
-                                                           int nb, double* __restrict__ out, double* __restrict__ tmin,
-                                                           double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted,
-                                                           int* unsorted_host, double* __restrict__ img, int img_w0, int img_W,
-                                                           int img_slot) {
+// what one workgroup does for the inverse table of component k (row krel of the outputs): the first ebd threads evaluate (the
+// evaluator's LDS image is that of a workgroup of ebd threads), every thread of the workgroup takes part in the index phases
+__device__ __forceinline__ void table_body(const DevProg& P, int k, int krel, int ebd, const double* __restrict__ coef,
+                                           const double* __restrict__ fold, const double* __restrict__ pts, int T, int nb,
+                                           double* __restrict__ out, double* __restrict__ tmin, double* __restrict__ tmax,
+                                           int* __restrict__ bkt, int* __restrict__ unsorted, int* unsorted_host, double* __restrict__ img,
+                                           int img_w0, int img_W, int img_slot) {
     __shared__ double xs[2048];
     __shared__ int bq[2048];
     __shared__ int bks[1024];
     __shared__ int bad;
     double* slots;
     CacheStore<double> cst;
-    Prog g = make_prog_lds(P, cst, slots);
+    Prog g = make_prog_lds_n(P, cst, slots, ebd);
     g.mono = TTM_MONO_SEPARABLE;
-    LdsSlots w{slots + threadIdx.x, (int)blockDim.x};
-    const int k = k0 + blockIdx.x;
+    const int tid = threadIdx.x, bd = blockDim.x;
+    LdsSlots w{slots + tid, ebd};
     const Comp c = comp_at(P, k, 0, coef, fold);
-    if (threadIdx.x == 0) bad = 0;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) {
-        const double t = pts[i];
-        double v, dv;
-        if (c.n_mnt == 0 && c.n_xgrp == 0) {
-            const UniformW uw{c.fold + c.off_wb};
-            g_eval<false>(c, g, t, uw, v, dv);
-        } else {
-            XFake x{c.kc, t};
-            mon_weights<double>(c, g, x, w);
-            g_eval<false>(c, g, t, w, v, dv);
+    if (tid == 0) bad = 0;
+    if (tid < ebd)
+        for (int i = tid; i < T; i += ebd) {
+            const double t = pts[i];
+            double v, dv;
+            if (c.n_mnt == 0 && c.n_xgrp == 0) {
+                const UniformW uw{c.fold + c.off_wb};
+                g_eval<false>(c, g, t, uw, v, dv);
+            } else {
+                XFake x{c.kc, t};
+                mon_weights<double>(c, g, x, w);
+                g_eval<false>(c, g, t, w, v, dv);
+            }
+            out[(int64_t)krel * T + i] = v;
+            xs[i] = v;
         }
-        out[(int64_t)blockIdx.x * T + i] = v;
-        xs[i] = v;
-    }
     __syncthreads();
     int mybad = 0;
-    for (int i = threadIdx.x + 1; i < T; i += blockDim.x) mybad |= !(xs[i - 1] <= xs[i]);   // also flags NaN
+    for (int i = tid + 1; i < T; i += bd) mybad |= !(xs[i - 1] <= xs[i]);   // also flags NaN
     if (mybad) atomicOr(&bad, 1);
     const double lo = xs[0], hi = xs[T - 1];
     double scale, bias;
     table_bucket_params(lo, hi, nb, scale, bias);
-    for (int i = threadIdx.x; i < T; i += blockDim.x) bq[i] = table_bucket(xs[i], scale, bias, nb);
+    for (int i = tid; i < T; i += bd) bq[i] = table_bucket(xs[i], scale, bias, nb);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        tmin[blockIdx.x] = lo; tmax[blockIdx.x] = hi; unsorted[blockIdx.x] = bad;
-        if (unsorted_host) __hip_atomic_store(unsorted_host + blockIdx.x, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+        tmin[krel] = lo; tmax[krel] = hi; unsorted[krel] = bad;
+        if (unsorted_host) __hip_atomic_store(unsorted_host + krel, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    for (int q = threadIdx.x; q <= nb; q += blockDim.x) {
+    for (int q = tid; q <= nb; q += bd) {
         int a = 0, b = T;
         if (q == nb) a = T;
         else if (q > 0) {
@@ -1768,14 +1777,61 @@ __global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, co
                 if (bq[mid] < q) a = mid + 1; else b = mid;
             }
         }
-        bkt[(int64_t)blockIdx.x * (nb + 1) + q] = a;
+        bkt[(int64_t)krel * (nb + 1) + q] = a;
         if (img) bks[q] = a;                                              // (nb + 1 = 1024: the host checked)
     }
     // the resident-table image of the component for the banded-map lookup kernel (csrc/ttm_band_image.h)
     if (img) {
         __syncthreads();
-        band_image_write(xs, bks, &bad, T, nb, lo, hi, img_w0, img_W, (img_W + 4 + 1) & ~1, img_slot, img + (int64_t)blockIdx.x * img_slot);
+        band_image_write(xs, bks, &bad, T, nb, lo, hi, img_w0, img_W, (img_W + 4 + 1) & ~1, img_slot, img + (int64_t)krel * img_slot);
     }
+}
+
+// k_table_build + k_table_index as ONE launch, one workgroup per component (blockIdx.x = component k0 + x): the table's T
+// points by the same evaluator as k_table_build (the same bits), kept in LDS for the index phase of k_table_index behind a
+// barrier - a new coefficient vector's inverse tables cost one launch instead of two (6.8 + 6.9 us and the gap).
+__global__ __launch_bounds__(256) void k_table_build_index(DevProg P, int k0, const double* __restrict__ coef,
+                                                           const double* __restrict__ fold, const double* __restrict__ pts, int T,
+                                                           int nb, double* __restrict__ out, double* __restrict__ tmin,
+                                                           double* __restrict__ tmax, int* __restrict__ bkt, int* __restrict__ unsorted,
+                                                           int* unsorted_host, double* __restrict__ img, int img_w0, int img_W,
+                                                           int img_slot) {
+    table_body(P, k0 + (int)blockIdx.x, (int)blockIdx.x, (int)blockDim.x, coef, fold, pts, T, nb, out, tmin, tmax, bkt, unsorted, unsorted_host,
+               img, img_w0, img_W, img_slot);
+}
+
+// A NEW COEFFICIENT VECTOR IN ONE LAUNCH: workgroups [0, D) do what k_uform does (fold, U section, records), workgroups [D, 2 D)
+// build the inverse table of component x - D as k_table_build_index does.  The tables need only the FOLDED coefficients, which
+// the table workgroup folds for itself into a scratch copy (fold2: the same layout, the same bits; nobody else touches its slice),
+// so the two halves share no data and run side by side: the launch takes as long as the slower half (20 us at C5) instead of
+// the sum (20 + 16 us and a gap).  The evaluator reads coefficients and folded sums through the scalar cache, which knows
+// nothing of the vector stores that just wrote them: invalidated between the two.
+__global__ __launch_bounds__(1024) void k_setup(DevProg P, UTabs T, const double* __restrict__ coef_src, double* coef,
+                                                double* __restrict__ fold, double* __restrict__ fold2, double* __restrict__ U,
+                                                int64_t err_off, int64_t h_off, int h_cls, int h_ng, int64_t p_off, int p_lag, int p_stride,
+                                                double* err_host, const double* __restrict__ pts, int Tn, int nb, double* __restrict__ out,
+                                                double* __restrict__ tmin, double* __restrict__ tmax, int* __restrict__ bkt,
+                                                int* __restrict__ unsorted, int* unsorted_host, double* __restrict__ img, int img_w0,
+                                                int img_W, int img_slot) {
+    if ((int)blockIdx.x < P.D) {
+        uform_body(P, T, (int)blockIdx.x, coef_src, coef, fold, U, err_off, h_off, h_cls, h_ng, p_off, p_lag, p_stride, err_host);
+        return;
+    }
+    const int k = (int)blockIdx.x - P.D, tid = threadIdx.x, bd = blockDim.x;
+    const int D1 = P.D + 1;
+    const int* off = P.off;
+    if (coef_src) {
+        // (the uform workgroup of the component copies the same values to the same place)
+        for (int i = off[2 * D1 + k] + tid; i < off[2 * D1 + k + 1]; i += bd) coef[i] = coef_src[i];
+        __syncthreads();
+    }
+    fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k], coef + off[2 * D1 + k], fold2 + off[3 * D1 + k], tid, bd);
+    __syncthreads();
+    fold_st8(P.fdesc + k * TTM_FDESC_LEN, P.fints, fold2 + off[3 * D1 + k], tid, bd);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    table_body(P, k, k, 256, coef, fold2, pts, Tn, nb, out, tmin, tmax, bkt, unsorted, unsorted_host, img, img_w0, img_W, img_slot);
 }
 
 // One sample per thread, no workgroup-level staging: the 1001-point tables of all components stay in
@@ -2385,7 +2441,8 @@ static const DeviceInfo& device_info() {
     X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
     X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
     X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
-    X(table_fused, -1)   /* 0: inverse tables as two launches (k_table_build, k_table_index) instead of one               */
+    X(table_fused, -1)   /* 0: inverse tables as two launches (k_table_build, k_table_index) instead of one               */ \
+    X(setup_fused, -1)   /* 0: ttm_setup_staged declines (the caller then launches ttm_fold_staged and the table kernel)           */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2978,6 +3035,46 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
     hipLaunchKernelGGL(k_table_build_index, dim3(k1 - k0), dim3(bd), lds_bytes(ns, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k0, coef,
                        fold, pts, (int)T, (int)nb, out, tmin, tmax, (int*)bkt, (int*)unsorted, (int*)h_unsorted, img, iw0, iW, islot);
     return check_launch("k_table_build_index");
+}
+
+int ttm_setup_staged(const ttm_program* p, const double* h_coef, double* coef, double* fold, double* fold2, double* h_err,
+                     const double* pts, int32_t T, int32_t nb, double* out, double* tmin, double* tmax, int32_t* bkt, int32_t* unsorted,
+                     int32_t* h_unsorted, double* img, void* stream) {
+    int rc = validate(p, 0, p ? p->D : 0);
+    if (rc) return rc;
+    if (!h_coef || !coef || !fold || !fold2 || fold2 == fold || !pts || !out || !tmin || !tmax || !bkt || !unsorted || T < 2 || T > 2048 ||
+        nb < 1 || nb > 4096)
+        return set_err(TTM_E_ARG, "ttm_setup_staged: bad arguments%s");
+    const Tuning& tn = tuning();
+    if (!(p->u_enabled && p->ucomp && p->ugrp && p->umono && p->ugeo) || tn.fold_fused == 0 || tn.table_fused == 0 || tn.setup_fused == 0 ||
+        p->monotonicity != TTM_MONO_SEPARABLE)
+        return set_err(TTM_E_UNSUPPORTED, "ttm_setup_staged: not for this map or these options (ttm_fold_staged + ttm_inverse_table_build_index)%s");
+    for (int k = 0; k < p->D; ++k)
+        if (p->h_ucomp && p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > TTM_U_NI_MAX)
+            return set_err(TTM_E_LIMIT, "ttm_fold: spline of component %s%lld exceeds TTM_U_NI_MAX columns", "", k);
+    int iw0 = 0, iW = 0, islot = 0;
+    if (img) {
+        if ((uintptr_t)img % 16 != 0 || ttm_inverse_table_image_doubles(p, 0, p->D, T, nb) == 0 ||
+            !ttm_band::image_plan(p, 0, p->D, (int)T, (int)nb, device_info().lds_per_cu, tn.rt_window, tn.rt_block, &iw0, &iW, &islot))
+            return set_err(TTM_E_ARG, "ttm_setup_staged: no resident-table images for this map and table geometry%s");
+    }
+    const int ns = map_slots(p, 0, p->D);
+    const size_t dyn = lds_bytes(ns, 256, 0);
+    const size_t stat = (size_t)TTM_U_NI_MAX * TTM_CHEB_N * 8 + 2 * 16 * 8 + 2048 * 8 + 2048 * 4 + 1024 * 4 + 64;     // (the kernel's static arrays)
+    if (dyn + stat > device_info().lds_per_cu / 2)
+        return set_err(TTM_E_UNSUPPORTED, "ttm_setup_staged: the evaluator's scratch does not fit next to the U-form arrays%s");
+    static thread_local size_t granted = 0;
+    if (dyn > granted) {
+        (void)hipFuncSetAttribute((const void*)k_setup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        granted = dyn;
+    }
+    const UTabs Tt{p->ucomp, p->ugrp, p->umono, p->ugeo};
+    const bool records = p->u_p_lag > 0 && p->u_h_cls > 0 && p->u_p_stride == ttm_band::record_stride(p->u_h_cls, p->u_p_lag);
+    hipLaunchKernelGGL(k_setup, dim3(2 * p->D), dim3(1024), dyn, (hipStream_t)stream, dev_prog(p), Tt, h_coef, coef, fold, fold2,
+                       fold + fold_base_size(p), (int64_t)p->u_err_off, (int64_t)p->u_h_off, (int)p->u_h_cls, (int)p->u_h_ng,
+                       (int64_t)p->u_p_off, records ? (int)p->u_p_lag : 0, (int)p->u_p_stride, h_err, pts, (int)T, (int)nb, out, tmin, tmax,
+                       (int*)bkt, (int*)unsorted, (int*)h_unsorted, img, iw0, iW, islot);
+    return check_launch("k_setup");
 }
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,

@@ -790,14 +790,28 @@ class transport_map():
             fold = self._zeros(nfold)
         slot[5], slot[6] = fold, (self._epoch, nfold)
         st = self._stream()
-        rc = self._lib.ttm_fold_staged(self._pp, ctypes.c_void_p(slot[0].data_ptr()), self._ptr(coef), self._ptr(fold),
-                                       ctypes.c_void_p(slot[1].data_ptr()), st)
+        pending = None
+        rc = -1
+        if self._eager_tables():
+            # fold + U section and the default inverse tables as ONE launch (include/ttm.h: ttm_setup_staged - the table workgroups
+            # fold for themselves into a scratch copy that belongs to this map: launches on one stream run one after the other)
+            scratch = getattr(self, '_fold2', None)
+            skey = (self._epoch, nfold, st.value if hasattr(st, 'value') else st)
+            if scratch is None or scratch[0] != skey:
+                scratch = self._fold2 = (skey, self._zeros(nfold))
+            coef._ttm_fold = fold
+            pending = self._launch_default_tables(coef, h_unsorted=slot[2], staged=(slot[0], slot[1], scratch[1]))
+            rc = 0 if pending is not None else -1
         if rc != 0:
-            slot[3] = None
-            return None
+            rc = self._lib.ttm_fold_staged(self._pp, ctypes.c_void_p(slot[0].data_ptr()), self._ptr(coef), self._ptr(fold),
+                                           ctypes.c_void_p(slot[1].data_ptr()), st)
+            if rc != 0:
+                slot[3] = None
+                return None
         coef._ttm_fold = fold
         coef._ttm_tables = {}
-        pending = self._launch_default_tables(coef, h_unsorted=slot[2]) if self._eager_tables() else None
+        if pending is None and self._eager_tables():
+            pending = self._launch_default_tables(coef, h_unsorted=slot[2])
         done = torch.cuda.Event()
         done.record()
         slot[3] = done
@@ -905,9 +919,11 @@ class transport_map():
         return (self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity' and self._cm.u_enabled and
                 getattr(self, '_cm', None) is not None and self._cm.u_h_cls > 0 and getattr(self, '_inverse_seen', False))
 
-    def _launch_default_tables(self, coef, resolution=1001, start_distance=10, h_unsorted=None):
+    def _launch_default_tables(self, coef, resolution=1001, start_distance=10, h_unsorted=None, staged=None):
         """Build + index the inverse tables of all components for the default table geometry (TM:4047-4058), no host visit:
-        returns (cache key, (tables, tmin, tmax, bucket index, unsorted flags on the device))."""
+        returns (cache key, (tables, tmin, tmax, bucket index, unsorted flags on the device)).  staged = (page-locked packed
+        vector, page-locked fit errors, fold scratch): the fold of the vector rides in the same launch (ttm_setup_staged);
+        None is returned when the library declines (nothing launched)."""
         torch = _torch()
         nb = self._inv_nb()
         self._ensure_pts(resolution, start_distance)
@@ -918,6 +934,16 @@ class transport_map():
         bkt_d = self._empty(ncomp, nb + 1, dtype=torch.int32)
         uns_d = self._empty(ncomp, dtype=torch.int32)
         img_d = self._table_images(0, ncomp, resolution, nb)
+        if staged is not None:
+            h_coef, h_err, fold2 = staged
+            rc = self._lib.ttm_setup_staged(self._pp, ctypes.c_void_p(h_coef.data_ptr()), self._ptr(coef), self._ptr(coef._ttm_fold),
+                                            self._ptr(fold2), ctypes.c_void_p(h_err.data_ptr()), self._ptr(self._pts_d), resolution, nb,
+                                            self._ptr(out_d), self._ptr(tmin_d), self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
+                                            ctypes.c_void_p(uns_d.data_ptr()),
+                                            None if h_unsorted is None else ctypes.c_void_p(h_unsorted.data_ptr()), self._ptr(img_d), st)
+            if rc != 0:
+                return None
+            return (0, ncomp, resolution, start_distance, nb), (out_d, tmin_d, tmax_d, bkt_d, uns_d, img_d)
         _capi.check(self._lib.ttm_inverse_table_build_index(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), 0, ncomp,
                                                             self._ptr(self._pts_d), resolution, nb, self._ptr(out_d),
                                                             self._ptr(tmin_d), self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()),
