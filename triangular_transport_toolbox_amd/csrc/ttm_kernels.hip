@@ -2479,9 +2479,13 @@ static int grid_for(int64_t N, int per_block) {
 // grid of the dense integrated kernels: these spend ~1e3 vector instructions per sample and component, so a launch is a few
 // dozen tile-times per CU - one workgroup per tile lets the dispatcher balance the CUs (a capped persistent grid ends on
 // the slowest CU's whole extra tile)
-static int int_grid_for(int64_t N, int per_block) {
+// (the forward map's tile is short - one evaluation per sample: six workgroups per CU walking the tiles take 6 % less than one
+// workgroup per tile at C2a, whose 7 814 workgroups each pay their launch and their first load; nothing at C5-int.  The root
+// searches keep one workgroup per tile.)
+static int int_grid_for(int64_t N, int per_block, int default_wgs = 0) {
     int64_t tiles = (N + per_block - 1) / per_block;
-    const int64_t cap = tuning().int_wgs > 0 ? (int64_t)device_info().cus * tuning().int_wgs : ((int64_t)1 << 20);
+    const int wgs = tuning().int_wgs > 0 ? tuning().int_wgs : default_wgs;
+    const int64_t cap = wgs > 0 ? (int64_t)device_info().cus * wgs : ((int64_t)1 << 20);
     if (tiles > cap) tiles = cap;
     if (tiles < 1) tiles = 1;
     return (int)tiles;
@@ -2769,7 +2773,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         const int ibd = pick_block(nsl, 0, 1);
         const char* name = nullptr;
         // a small ensemble is split over the components as well, until the launch has ~16 workgroups per CU to balance with
-        const int tiles = ibd ? int_grid_for(N, ibd) : 1;
+        const int tiles = ibd ? int_grid_for(N, ibd, 6) : 1;
         int nchunk = (int)(((int64_t)device_info().cus * 16 + tiles - 1) / tiles);
         if (tuning().int_chunks > 0) nchunk = tuning().int_chunks;
         if (nchunk > k1 - k0) nchunk = k1 - k0;
