@@ -22,7 +22,7 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fP
          '-DNDEBUG'] + shlex.split(os.environ.get('TTM_BUILD_FLAGS', ''))
 LINK = ['-ldl', '-pthread']                   # (RCCL is bound at run time, csrc/ttm_comm.cpp)
 # tuning builds: extra flags for ONE translation unit (only that object is recompiled), e.g. TTM_BAND_FLAGS=-DBAND_X=1
-EXTRA = {'ttm_band.hip': shlex.split(os.environ.get('TTM_BAND_FLAGS', ''))}
+EXTRA = {'ttm_band.hip': shlex.split(os.environ.get('TTM_BAND_FLAGS', '')), 'ttm_int.hip': shlex.split(os.environ.get('TTM_INT_FLAGS', ''))}
 
 
 def hipcc_path():

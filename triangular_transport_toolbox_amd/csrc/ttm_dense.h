@@ -219,13 +219,25 @@ TTM_HD void mon_eval(const Comp&, const Prog& p, const double& t, const DenseMon
 template <int PH, int PP, int RECT, bool DER, class XA, class Slots>
 TTM_HD void dense_sample_forward(const Comp& c, const Prog& p, double qw_sum, VarCache<XA, double>& x, Slots& w, bool want_value,
                                  double& S, double& dS) {
+#ifndef INT_X_NOW                                           /* (INT_X_*: timing experiments, results wrong by construction) */
     dense_weights<double>(c, p, x, w);
+#endif
     DenseMonoSet<PH, PP, RECT> s;
+#ifndef INT_X_NOMONO
     dense_monomials<PH, PP>(c, p, w, s.d);
+#else
+    for (int j = 0; j <= PH; ++j) s.d.h[j] = 0.01 * (j + 1);
+    for (int j = 0; j <= PP; ++j) s.d.a[j] = 0.02 * (j + 1);
+    s.d.probe = 0.0;
+#endif
     s.qw_sum = qw_sum;
     // (the nonmonotone part first: behind the node loop it would keep the component's table pointers alive across it)
     const double xk = x.get(c.kc);
+#ifndef INT_X_NONM
     const double nm = want_value ? nonmon_sum<double>(c, p, x) : 0.0;
+#else
+    const double nm = xk;
+#endif
     double m, dm;
     mon_eval<TTM_MONO_INTEGRATED, DER>(c, p, xk, s, m, dm);
     S = want_value ? nm + m : m;
