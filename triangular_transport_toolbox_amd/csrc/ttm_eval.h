@@ -472,6 +472,7 @@ TTM_HD void mon_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
     for (int b = 0; b <= c.nB; ++b) w.set(b, R(wb[b]));
     // cross terms with one polynomial / Hermite-function factor: per (B function, variable) a folded series - one
     // recurrence and the variable's cached exp(-x^2/4) instead of a walk through the term and factor records per term
+#ifndef INT_X_NOXGRP                                        /* (INT_X_*: timing experiments, results wrong by construction) */
     for (int g = 0; g < c.n_xgrp; ++g) {
         cint_p G = c.xgrp + 8 * g;
         const int var = TTM_UNI(G[0]);
@@ -493,12 +494,15 @@ TTM_HD void mon_weights(const Comp& c, const Prog& p, XA& x, Slots& w) {
         if (has_hf) wv = vfma(e, acch, wv);
         w.set(b, wv);
     }
+#endif
+#ifndef INT_X_NOMNT
     for (int j = 0; j < c.n_mnt; ++j) {
         cint_p T = c.mon_terms + 4 * TTM_UNI(c.mnt[j]);
         int b = TTM_UNI(T[2]);
         if (b < 0) b = c.nB;
         w.set(b, vfma(c.cmon[TTM_UNI(T[3])], eval_A<R>(T, c, p, x), w.get(b)));
     }
+#endif
 }
 
 struct UniformW {            // uniform weights straight from the folded array (SGPR operands)
