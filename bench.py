@@ -872,6 +872,15 @@ def main():
         torch.cuda.synchronize()
         extra['pullback_logdet_only_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
         extra['pullback_logdet_only_frac'] = 8.0 * N * (du + 1) / (extra['pullback_logdet_only_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # the same step replayed from a captured HIP graph (rank-local, informational - `value` is the stream-launched loop above): what
+        # the gaps between the launches of the Python loop cost
+        if args.workload == 'C5' and world == 1:
+            try:
+                g = graph_ms(torch, step, launches=10, reps=10)
+                if g is not None:
+                    extra['graph_replay_ms_per_step'] = g
+            except Exception as exc:                   # noqa: BLE001
+                extra['graph_replay_error'] = repr(exc)
     if world == 1 and not args.no_optimize:
         # secondary metric of BASELINE.json: optimize() wall-clock on the resident ensemble (from coeffs_init)
         saved = ([c.copy() for c in tm.coeffs_mon], [c.copy() for c in tm.coeffs_nonmon])
