@@ -42,6 +42,31 @@ def _last_kernel(tm):
     return tm._lib.ttm_last_kernel().decode()
 
 
+def test_c5_ring_inverse_with_several_tiles_per_workgroup(ttm_opt):
+    """C5 at N = 2 100 003 (an odd tail; 8 204 rows per workgroup = three tiles, the first two full): the ring of resident-table
+    images keeps turning across the tiles of a chunk.  Against k_band_inverse (which re-reads two columns at its block boundary when
+    a chunk has several tiles: last bits) and the oracle on a subset with tails."""
+    import torch
+    N = 2100003
+    tm, om, X = build('C5', 'c5_sep', N)
+    Z = tm.forward_device(tm._Xs, tm._N)
+    res = {}
+    for ring in (1, 0):
+        ttm_opt('band_ring', ring)
+        Xi = tm.inverse_device(Z, tm._N)
+        torch.cuda.synchronize()
+        res[ring] = Xi[:, :N].clone()
+        assert _last_kernel(tm) == ('k_band_inverse_ring' if ring else 'k_band_inverse')
+    assert (res[1] - res[0]).abs().max().item() < 1e-12
+    assert (res[1] - tm._Xs[:, :N]).abs().max().item() < 1e-3               # (round trip: the tables' interpolation error)
+    idx = subset_with_tails(X, 3000)
+    sel = torch.from_numpy(idx).to(Z.device)
+    Xo = (om.inverse_map(Z[:, :N].T[sel].cpu().numpy()) - om.X_mean) / om.X_std
+    err = relerr(res[1].T[sel].cpu().numpy(), Xo)
+    record_parity('c5_2.1e6/table_inverse(k_band_inverse_ring, three tiles per workgroup)_vs_oracle', err, 1e-11)
+    assert err < 1e-11
+
+
 def test_c5_full_size_against_the_oracle_on_1e4_samples_with_tails(ttm_opt):
     """C5 (d = 40, band 2, order 3, N = 1e6) through the kernels the benchmark times - asserted by name on the
     device-resident entry points - against the oracle: map 1e-11, table inverse 1e-11."""
