@@ -1396,8 +1396,8 @@ __device__ __forceinline__ void band_inverse_tile(const BandInvCtx& cx, bool ful
             if (G > 0 && ++rg->gcnt == G) {
                 rg->gcnt = 0;
                 // this wave's pieces from before the last meeting have landed: every step since put two column loads and a piece behind them
-                if (G == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                static_assert(G == 0 || G == 4, "the counted wait below is 3 G - 2");
+                asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 __syncthreads();
             }
         }
@@ -2227,7 +2227,7 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
                                 double, double, const double*, const double*, const double*, int, int, int, int64_t, int, int);
         const int cls = p->u_h_cls;
 #define BAND_RING_K(G) (cls == 1 ? k_band_inverse_ring<1, 2, G> : cls == 2 ? k_band_inverse_ring<2, 2, G> : k_band_inverse_ring<3, 2, G>)
-        rkern_t rk = pl.G == 8 ? BAND_RING_K(8) : pl.G == 4 ? BAND_RING_K(4) : BAND_RING_K(0);
+        rkern_t rk = pl.G == 4 ? BAND_RING_K(4) : BAND_RING_K(0);
 #undef BAND_RING_K
         const int64_t rows = chunk_rows(N, cus);
         const int64_t grid = (N + rows - 1) / rows;

@@ -54,7 +54,7 @@ static inline bool band_ring_plan(int T, int nb, int ncomp, size_t lds_per_cu, i
     if (pl->tab_slot % 2) return false;               // (16-byte units)
     if (ncomp <= B) { pl->R = ncomp; pl->G = 0; }
     else {
-        const int G = B >= 24 ? 8 : 4;
+        const int G = 4;                              // (refills of 8 measured 2 % slower at C5: OPTLOG round 4, item 22)
         const int R = B / G * G;
         if (R < 3 * G) return false;                  // (a refill is certified one group after it is issued and used two groups on)
         pl->R = R; pl->G = G;
