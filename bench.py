@@ -861,7 +861,7 @@ def main():
             tm.forward_device(Xs, N, coef=coef, Z=Z, logdet=ld, sigma=sigma, sumsq=ss)   # fused S, log det, |S|^2
             b.record()
         torch.cuda.synchronize()
-        extra['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        extra['pullback_fused_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp])) - ev_overhead_ms      # (the event pair's own time: kernel_timing)
         # the log-determinant-only pass (no map values written: what evaluate_pullback_density needs, 8 N (d + 1) bytes)
         for _ in range(20):
             tm.density_device(Xs, N, coef=coef, logdet=ld, sigma=sigma)
@@ -870,7 +870,7 @@ def main():
             tm.density_device(Xs, N, coef=coef, logdet=ld, sigma=sigma)
             b.record()
         torch.cuda.synchronize()
-        extra['pullback_logdet_only_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp]))
+        extra['pullback_logdet_only_ms'] = float(np.mean([a.elapsed_time(b) for a, b in evp])) - ev_overhead_ms
         extra['pullback_logdet_only_frac'] = 8.0 * N * (du + 1) / (extra['pullback_logdet_only_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS
         # the same step replayed from a captured HIP graph (rank-local, informational - `value` is the stream-launched loop above): what
         # the gaps between the launches of the Python loop cost
