@@ -211,7 +211,10 @@ def test_c2a_full_size_integrated_forward_and_bisection_inverse():
     tm, om, X = build('C2a', 'c2a_int', N)
     idx = subset_with_tails(X, n_random=10000)
     Z = tm.map(X)
-    assert relerr(Z[idx], om.map(X[idx])) < 1e-10
+    tm.forward_device(tm._Xs, tm._N)
+    assert _last_kernel(tm) == 'k_int_forward'
+    record_parity('c2a_full/map(k_int_forward)_vs_oracle', relerr(Z[idx], om.map(X[idx])), 1e-11)
+    assert relerr(Z[idx], om.map(X[idx])) < 1e-11                           # (integrated maps 1e-11)
     Xi = tm.inverse_map(Z)                                                  # 1e6 bisection searches, reference midpoint sequence
     # S(S^-1(z)) = z to the root search's own threshold (|S - z| <= 1e-9 at the last midpoint), under the ORACLE's map
     sub = idx[::4]
@@ -256,3 +259,112 @@ def test_c4_filter_update_at_1e5_against_the_oracle():
     assert relerr(got, Xa) < 1e-5
     sub = subset_with_tails(ens, 10000)
     assert relerr(got[sub], Xa[sub]) < 1e-5
+
+
+def _integrated_full_size(cfgname, fixture, N, n_map, n_root, obj_components, tag):
+    """An integrated-rectifier configuration at the size bench.py runs it: the monomial-form kernels of csrc/ttm_int.hip
+    (TM:2516-2547 map, TM:3798-3985 bisection, TM:3300-3635 objective / jacobian) asserted BY NAME on the device entry
+    points, against the oracle on rows that include the tails of every column.  Several tiles per workgroup and, for
+    small ensembles, component chunks on grid.y are what a 200-row fixture cannot reach."""
+    tm, om, X = build(cfgname, fixture, N)
+    assert all(int(f) & 4 for f in tm._cm.complex), 'polynomial B sets expected'
+    idx = subset_with_tails(X, n_random=n_map)
+    # forward map
+    Zs = tm.forward_device(tm._Xs, tm._N)
+    assert _last_kernel(tm) == 'k_int_forward'
+    Z = tm.map(X)
+    err = relerr(Z[idx], om.map(X[idx]))
+    record_parity('%s/map(k_int_forward)_vs_oracle' % tag, err, 1e-11)
+    assert err < 1e-11
+    perm = np.random.default_rng(11).permutation(N)[:50000]
+    assert np.array_equal(tm.map(X[perm]), Z[perm])                         # rows are independent: exact
+    # bisection, the reference's midpoint sequence: whole ensemble on the device, oracle on a subset
+    tm.inverse_device(Zs, tm._N, table=False)
+    assert _last_kernel(tm) == 'k_int_root<bisect>'
+    tm.alternate_root_finding = False
+    om.alternate_root_finding = False
+    Xi = tm.inverse_map(Z)
+    sub = subset_with_tails(X, n_random=n_root, n_tail=2, seed=5)
+    sub = sub[sub > 0]                                                      # (row 0: the loop-guard quirk depends on the batch)
+    res = np.abs(om.map(Xi[sub]) - Z[sub])
+    record_parity('%s/bisection(k_int_root)_residual_under_the_oracle_map' % tag, float(res.max()), 5e-9)
+    assert res.max() < 5e-9
+    Xo = om.inverse_map(np.vstack((Z[:1], Z[sub])))[1:]                      # (a row 0 of its own keeps the quirk off the subset)
+    dx = float(np.max(np.abs(Xi[sub] - Xo)))
+    record_parity('%s/bisection(k_int_root)_positions_vs_oracle' % tag, dx, 1e-6)
+    assert dx < 1e-6
+    assert np.max(np.abs(Xi[1:] - X[1:, tm.skip_dimensions:])) < 1e-6        # round trip of the whole ensemble
+    # Newton (extension): the same roots
+    tm.root_finder = 'newton'
+    Xn = tm.inverse_map(Z)
+    tm.inverse_device(Zs, tm._N, table=False)
+    assert _last_kernel(tm) == 'k_int_root<newton>'
+    tm.root_finder = 'reference'
+    resn = np.abs(om.map(Xn[sub]) - Z[sub])
+    record_parity('%s/newton(k_int_root)_residual_under_the_oracle_map' % tag, float(resn.max()), 2e-9)
+    assert resn.max() < 2e-9
+    assert np.max(np.abs(Xn[sub] - Xo)) < 1e-6
+    # objective and gradient over the WHOLE ensemble (north_star: 1e-10 relative)
+    rng = np.random.default_rng(2)
+    for k in obj_components:
+        div = len(tm.coeffs_nonmon[k])
+        c = np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k])) * (1.0 + 0.05 * rng.standard_normal(div + len(tm.coeffs_mon[k])))
+        J, G = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
+        tm._device_sums(k, c)
+        assert _last_kernel(tm) == 'k_int_objective'
+        Jo, Go = om.objective_function(c, k, div), om.objective_function_jacobian(c, k, div)
+        record_parity('%s/objective(k_int_objective)[k=%d]_vs_oracle' % (tag, k), abs(J - Jo) / (1 + abs(Jo)), 1e-10)
+        record_parity('%s/gradient(k_int_objective)[k=%d]_vs_oracle' % (tag, k), relerr(G, Go), 1e-10)
+        assert abs(J - Jo) < 1e-10 * (1 + abs(Jo))
+        assert relerr(G, Go) < 1e-10
+
+
+def test_c5int_full_size_kernels_of_the_default_monotonicity():
+    """C5-int (d = 40, band 2, order 3, Q = 25) at N = 2e5, the size bench.py times it at: order class (3,0), band-2 weights
+    through the term tables, component chunks on grid.y, workgroups walking several tiles, the two-launch sample-0 replay."""
+    _integrated_full_size('C5int', 'c5_int', 200000, 6000, 1500, (0, 1, 17, 39), 'c5int_2e5')
+
+
+def test_c3int_full_size_kernels_of_the_default_monotonicity():
+    """C3-int (d = 4, band 1, order 4, Q = 25) at N = 5e5."""
+    _integrated_full_size('C3int', 'c3_int', 500000, 10000, 4000, (0, 1, 2, 3), 'c3int_5e5')
+
+
+def test_c4_block_map_backward_step_at_1e5_against_the_oracle():
+    """The 6-column block map of the Ensemble Transport Smoother (example_07.py:368-465; BASELINE configs[3]) at N = 1e5:
+    ONE backward step reset -> optimize -> map -> inverse_map(X_star) through the class, against the oracle's step on the
+    same ensembles (SciPy L-BFGS-B on the host)."""
+    from triangular_transport_toolbox_amd import entf, specs
+    from oracle.ttm_oracle import OracleMap
+    N = 100000
+    rng = np.random.default_rng(0)
+    ana = rng.standard_normal((N, 3)) * [8.0, 9.0, 8.0] + [0.0, 0.0, 25.0]
+    ana = entf.rk4(ana, 0.05, 20)                                           # onto the attractor
+    fc_next = entf.rk4(ana, 0.05, 2)
+    Xnext = fc_next + 0.1 * rng.standard_normal((N, 3))
+    inp = np.column_stack((fc_next, ana))
+    tm = entf.make_smoother_map(N, maxorder=3, lmbda=0.05)
+    tm.reset(inp.copy())
+    tm.optimize()
+    Zp = tm.map(inp)
+    got = tm.inverse_map(X_star=Xnext.copy(), Z=Zp)
+    tm.forward_device(tm._Xs, tm._N)
+    fk = _last_kernel(tm)
+    mon, non = specs.ents_smoother_spec(3)
+    om = OracleMap(X=inp.copy(), monotone=mon, nonmonotone=non, polynomial_type="probabilist's hermite",
+                   monotonicity='separable monotonicity', regularization='l2', regularization_lambda=0.05)
+    om.optimize()
+    Zo = om.map(inp)
+    want = om.inverse_map(X_star=Xnext.copy(), Z=Zo)
+    sub = subset_with_tails(inp, 10000)
+    record_parity('c4_block_1e5/map(%s)_vs_oracle_after_own_optimize' % fk, relerr(Zp[sub], Zo[sub]), 1e-5)
+    record_parity('c4_block_1e5/conditional_inverse_vs_oracle', relerr(got, want), 1e-5)
+    assert relerr(Zp, Zo) < 1e-5
+    assert relerr(got, want) < 1e-5
+    # the same coefficients on both sides: the kernels alone (map 1e-11, conditional table inverse 1e-11)
+    om.coeffs_mon, om.coeffs_nonmon = [c.copy() for c in tm.coeffs_mon], [c.copy() for c in tm.coeffs_nonmon]
+    e1 = relerr(Zp[sub], om.map(inp[sub]))
+    e2 = relerr(got[sub], om.inverse_map(X_star=Xnext[sub].copy(), Z=Zp[sub]))
+    record_parity('c4_block_1e5/map(%s)_vs_oracle_same_coefficients' % fk, e1, 1e-11)
+    record_parity('c4_block_1e5/conditional_inverse_vs_oracle_same_coefficients', e2, 1e-11)
+    assert e1 < 1e-11 and e2 < 1e-11

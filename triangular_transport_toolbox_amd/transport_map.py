@@ -1319,14 +1319,7 @@ class transport_map():
             # host-driven optimiser: coefficients as kernel arguments, result written to pinned host memory,
             # one stream synchronisation per evaluation (no H2D / D2H copies, two launches)
             torch = _torch()
-            if getattr(self, '_obj_out', None) is None:
-                pin = self._dev.type == 'cuda'
-                self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
-                self._obj_cnt = self._zeros(16, dtype=torch.int32)
-            _capi.check(self._lib.ttm_objective_host(self._pp, int(k), ctypes.c_void_p(coef_k.ctypes.data), self._ptr(self._Xs),
-                                                     self._Xs.shape[1], self._N, self._ptr(work),
-                                                     ctypes.c_void_p(self._obj_cnt.data_ptr()),
-                                                     ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+            self._objective_launch(k, coef_k, work)
             if self._dev.type == 'cuda':
                 torch.cuda.current_stream().synchronize()
             return self._obj_out[:nout].numpy().copy()
@@ -1336,6 +1329,22 @@ class transport_map():
                                             self._N, self._ptr(work), self._ptr(out), self._stream()))
         self._allreduce(out)
         return out.cpu().numpy()
+
+    def _objective_launch(self, k, coef_k, work=None):
+        """The launches of one objective + gradient evaluation of component k (ttm_objective_host: sums into pinned host
+        memory), no synchronisation - what `_device_sums` waits for, and what bench.py times."""
+        torch = _torch()
+        if work is None:
+            nout = 1 + int(self._cm.n_mon[k]) + (0 if self.monotonicity.lower() == 'separable monotonicity' else int(self._cm.n_nm[k]))
+            work = self._workspace(self._lib.ttm_reduce_work_size(nout))
+        if getattr(self, '_obj_out', None) is None:
+            pin = self._dev.type == 'cuda'
+            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
+            self._obj_cnt = self._zeros(16, dtype=torch.int32)
+        _capi.check(self._lib.ttm_objective_host(self._pp, int(k), ctypes.c_void_p(coef_k.ctypes.data), self._ptr(self._Xs),
+                                                 self._Xs.shape[1], self._N, self._ptr(work),
+                                                 ctypes.c_void_p(self._obj_cnt.data_ptr()),
+                                                 ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
 
     def _regularization_terms(self, k, div, cn, cm):
         """TM:3382-3431 and TM:3575-3633."""
@@ -1527,11 +1536,7 @@ class transport_map():
         cache = getattr(self, '_sep_cache', None)
         if cache is not None and cache[0] == int(k) and self._dist() is None:
             m = len(c)
-            work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
-            _capi.check(self._lib.ttm_objective_sep_cached(self._ptr(cache[1]), cache[1].shape[1], self._N, m,
-                                                           ctypes.c_void_p(c.ctypes.data), float(self.delta), self._ptr(work),
-                                                           ctypes.c_void_p(self._obj_cnt.data_ptr()),
-                                                           ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+            self._sep_objective_launch(c)
             if self._dev.type == 'cuda':
                 _torch().cuda.current_stream().synchronize()
             sums = self._obj_out[:1 + m].numpy().copy()
@@ -1543,6 +1548,16 @@ class transport_map():
         objective = c @ Ax / 2 - sums[0] / N + np.inner(c, b)
         grad = Ax - sums[1:] / N + b
         return objective, grad
+
+    def _sep_objective_launch(self, c):
+        """The launch(es) of one reduced-objective evaluation on the cached derivative basis (ttm_objective_sep_cached),
+        no synchronisation."""
+        cache, m = self._sep_cache, len(c)
+        work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
+        _capi.check(self._lib.ttm_objective_sep_cached(self._ptr(cache[1]), cache[1].shape[1], self._N, m,
+                                                       ctypes.c_void_p(c.ctypes.data), float(self.delta), self._ptr(work),
+                                                       ctypes.c_void_p(self._obj_cnt.data_ptr()),
+                                                       ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
 
     def _respecify(self, monotone, nonmonotone):
         """New term lists on the resident ensemble (TM:432-438: function_constructor_alternative + precalculate)."""
