@@ -94,7 +94,7 @@ extern "C" {
  * Folded coefficients (recomputed from the coefficient vector when a kernel stages the program):
  *   [0] sum of constant nonmonotone coefficients | group arrays | wB[0..nB] = summed coefficients of the
  *   monotone terms that are functions of x_kc alone, per B function (slot nB: terms without x_kc). */
-#define TTM_HDR_LEN      28
+#define TTM_HDR_LEN      32
 #define TTM_HDR_KC        0   /* column of x_k in the sample matrix (k + skip_dimensions) */
 #define TTM_HDR_N_NM      1
 #define TTM_HDR_OFF_NM    2
@@ -123,6 +123,43 @@ extern "C" {
 #define TTM_HDR_OFF_WB   25   /* offset of wB inside the folded array                          */
 #define TTM_HDR_N_XGRP   26   /* cross groups: weights of B functions as folded series in ONE conditioning variable */
 #define TTM_HDR_OFF_XGRP 27   /* records of 8 int32: {var, P, fold offset, has_hf, b, 0, 0, 0}                      */
+#define TTM_HDR_OFF_XPROG 28  /* offset (within the block) of the component's X program; 0: it has none              */
+#define TTM_HDR_X_NROW   29   /* X program: row columns in front of the q columns (3 + U values + computed products)  */
+#define TTM_HDR_X_NSUM   30   /* X program: sums of an objective + gradient evaluation (<= TTM_X_SUM_MAX)              */
+/* ---- "X program" of an integrated-rectifier component (csrc/ttm_xprog.h; round 5) -------------------------------------
+ * Present (flag bit 4 of h_complex) when the functions of x_kc in the monotone list are polynomials / Hermite functions only
+ * (flag bit 2) and EVERY factor on another column, of every nonmonotone and monotone term, is a polynomial or a Hermite
+ * function of the map's family of an order within the component's order class, at most TTM_X_MAXF factors per term.
+ * The kernels then evaluate each distinct factor value ("U value": P_n(x_j) or a_n P_n(x_j) exp(-x_j^2/4)) ONCE per sample,
+ * each distinct product of them ("A value") once, and get the monomial form of g and the nonmonotone sum from matrices
+ * that are functions of the coefficients alone - part of the FOLD (computed by the fold recipe like every folded sum):
+ *     h_j = sum_a A_a HC[a][j],   a_j = sum_a A_a HP[a][j]   (g(t) = exp(-t^2/4) sum_j h_j t^j + sum_j a_j t^j),
+ *     Psi_nonmon c_nonmon = sum_a A'_a CN[a].
+ * A sample owns a ROW of doubles: [0] = 1, [1] = S_k, [2] = 1/2 S_k^2 - log(r + delta), [3 ..] the U values, then the
+ * computed products (X_NROW columns so far), then - objective kernel only - the q columns
+ *     qH_j = S x_k/2 mh_j - r'/(r + delta) E(x_k) x_k^j (j <= PH),   qP_j = S x_k/2 mp_j - r'/(r + delta) x_k^j (j <= PP)
+ * (mh, mp: the node moments of csrc/ttm_dense.h), so that EVERY sum of an evaluation is a product of two row entries summed
+ * over the samples: sum 0 = [0] [2] (J); 1 + a = A'_a [1] (gradient of the nonmonotone coefficients sharing product a);
+ * 1 + NA_NM + a NQ + j = A_a q_j - the gradient of monotone coefficient i is sum_j CB[b(i)][j] of the sums of its product,
+ * CB = the basis-conversion row of its B function (a_n folded in), applied once per evaluation by the finishing workgroup.
+ * Layout (int32): header of 8 {NVAR, NU, NPROD, NA_NM, NA_MON, offset of the fold's X section within the component's fold,
+ * offset of the U rows within the component's dpar slice, PH | PP << 8 (the component's own order class)}, then
+ *   vars  : NVAR x 4 {column, plain-polynomial U values on it, Hermite-function U values on it, 0}
+ *   prods : NPROD x 4 {c1, c2, c3, 0}: row columns of the factors (0 = the constant 1); product p lives in column 3 + NU + p
+ *   anm   : NA_NM row columns (padded to a multiple of 4): the distinct products of the nonmonotone terms
+ *   amon  : NA_MON row columns (padded): the distinct products A of the monotone terms
+ *   terms : N_NM + N_MON x 4 {index into anm / amon, B function b (nB: none; -1 for a nonmonotone term), 0, 0}
+ * dpar, at the U-row offset: (TTM_I_PMAX + 1) monomial coefficients per U value (a_n folded in), U values ordered by column,
+ * plain polynomials before Hermite functions, by order.  Fold X section: CN[NA_NM] | HC[NA_MON][TTM_I_PMAX + 1] |
+ * HP[NA_MON][TTM_I_PMAX + 1].                                                                                          */
+#define TTM_X_MAXF        3
+#define TTM_X_NU_MAX     40
+#define TTM_X_SUM_MAX   192
+#define TTM_XR_ONE        0
+#define TTM_XR_S          1
+#define TTM_XR_J          2
+#define TTM_XR_U          3
+#define TTM_XH_LEN        8
 #define TTM_ST_NPAR       5   /* dpar doubles per special term                                 */
 /* fast-path descriptor of a component (components whose terms are all univariate: no table walking,
  * every record is at a known offset so the scalar loads can be issued ahead of use) */
@@ -271,6 +308,7 @@ typedef struct ttm_program {
                                    bit 2 = integrated component whose functions of x_k are polynomials / Hermite functions
                                    only (any orders): the monomial-form kernels of csrc/ttm_int.hip apply,
                                    bit 3 = the component has special terms (LET / RET / RBF / iRBF) somewhere,
+                                   bit 4 = the component has an X program (TTM_HDR_OFF_XPROG), bits 16-23 = TTM_HDR_X_NROW, bits 24-25 = TTM_HDR_X_NSUM / 64 rounded up,
                                    bits 8-11 / 12-15 = largest Hermite-function / plain polynomial order among the
                                    functions of x_k (saturating at 15)                                          */
     /* device copy of the five prefix tables, 5 x (D+1) int32:
@@ -483,7 +521,7 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
                   int64_t ldx, int64_t N, double* work, double* out, void* stream);
 /* The same reduction for an optimiser that lives on the host (TM:3108-3114, 3252-3257 drive SciPy with one
  * objective / gradient evaluation per call, so the per-call latency is what optimize() costs):
- * h_coef_k is a HOST vector (<= 64 coefficients) that travels as kernel arguments - no host-to-device copy; the
+ * h_coef_k is a HOST vector (<= 128 coefficients) that travels as kernel arguments - no host-to-device copy; the
  * finishing sum runs in the workgroup that draws the last ticket of `counter` (device uint32[16], zero before the first
  * call; left zero) in the order of the three-launch path, so both give the same bits; `out` may be pinned host
  * memory (device-accessible), which also saves the device-to-host copy.  Two launches instead of three + two copies. */
@@ -558,7 +596,7 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
  *   0 = converged, 1 = iteration limit, 2 = no acceptable step (precision loss), 3 = NaN}.
  * ttm_optimize_integrated: component k of an integrated-rectifier map minimised without leaving the library:
  *   J(c) = sums[0] / Ntotal + penalty(c), grad = sums[1..m] / Ntotal + penalty'(c) with the sums of
- *   ttm_objective_host (TM:3300-3380, 3435-3573) over the local samples, m = n_nonmon + n_mon <= 64 coefficients
+ *   ttm_objective_host (TM:3300-3380, 3435-3573) over the local samples, m = n_nonmon + n_mon <= 128 coefficients
  *   [nonmonotone | monotone] in x (host, start / result); regularization 0 none, 1 l1: sum lambda_i |c_i|, 2 l2:
  *   sum lambda_i c_i^2 (TM:3382-3431, 3575-3633; lambda: host, m doubles, NULL for 0).  work / counter as
  *   ttm_objective_host; sums_host / sums_dev / comm / Ntotal as ttm_optimize_separable.                                */

@@ -22,7 +22,7 @@ SRC = os.path.join(HERE, 'ttm_hostemu.cpp')
 LIB = os.path.join(HERE, 'libttm_hostemu.so')
 CSRC = os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc')
 DEPS = [SRC, os.path.join(CSRC, 'ttm_eval.h'), os.path.join(CSRC, 'ttm_math.h'), os.path.join(CSRC, 'ttm_vec.h'),
-        os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(CSRC, 'ttm_dense.h'), os.path.join(CSRC, 'ttm_dense_table.h'), os.path.join(CSRC, 'ttm_uform.h'), os.path.join(CSRC, 'ttm_cheb_table.h'), os.path.join(CSRC, 'ttm_lbfgsb.h'), os.path.join(CSRC, 'ttm_bfgs.h'), os.path.join(CSRC, 'ttm_rng.h'), os.path.join(CSRC, 'ttm_optim.cpp'),
+        os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(CSRC, 'ttm_dense.h'), os.path.join(CSRC, 'ttm_xprog.h'), os.path.join(CSRC, 'ttm_dense_table.h'), os.path.join(CSRC, 'ttm_uform.h'), os.path.join(CSRC, 'ttm_cheb_table.h'), os.path.join(CSRC, 'ttm_lbfgsb.h'), os.path.join(CSRC, 'ttm_bfgs.h'), os.path.join(CSRC, 'ttm_rng.h'), os.path.join(CSRC, 'ttm_optim.cpp'),
         os.path.join(HERE, '..', '..', 'include', 'ttm.h')]
 
 _lib = None

@@ -17,6 +17,7 @@
 
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_eval.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_dense.h"
+#include "../../triangular_transport_toolbox_amd/csrc/ttm_xprog.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_uform.h"
 #include "../../triangular_transport_toolbox_amd/csrc/ttm_rng.h"
 
@@ -598,6 +599,30 @@ int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const d
     DenseClass dcls;
     const bool dense = int_dense(p, k, k + 1, dcls);
     const double qws = dense ? dense_qw_sum(g) : 0.0;
+    XProg xp;
+    if (dense && xprog_view(p->itab + p->h_comp_off[k], p->dpar + p->h_dpar_off[k], xp) &&
+        !(getenv("TTM_INT_XPROG") && atoi(getenv("TTM_INT_XPROG")) == 0)) {
+        // the X-program path of csrc/ttm_int.hip (k_int_objective): a row per sample, every sum a product of four row
+        // entries - the kernel gives a sum to a lane and walks the rows of a wave; here the same products in sample order
+        const double* fx = c.fold + xp.fold_x;                  // (comp_of folded the recipe, X section included)
+        std::vector<double> rowbuf(xp.nrow + 2 * (TTM_I_PMAX + 1)), T(xp.nsum, 0.0);
+        VecSlots row{rowbuf.data()};
+        std::vector<int> cols(2 * xp.nsum);
+#define TTM_CALL(PH, PP, RECT) for (int t = 0; t < xp.nsum; ++t) xobj_sum_columns((const int*)xp.anm, (const int*)xp.amon, xp.na_nm, xp.nrow, XQ<PH, PP>::NQ, t, cols[2 * t], cols[2 * t + 1])
+        TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+        for (int64_t n = 0; n < N; ++n) {
+            XSoA xa{X, ldx, n};
+#define TTM_CALL(PH, PP, RECT) xobj_sample_row<PH, PP, RECT>(xp, g, qws, fx, xa, row, true)
+            TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+            for (int t = 0; t < xp.nsum; ++t) T[t] = fma(row.get(cols[2 * t]), row.get(cols[2 * t + 1]), T[t]);
+        }
+#define TTM_CALL(PH, PP, RECT) for (int i = 0; i < nacc; ++i) { XResult<PH, PP> r; xobj_result_plan<PH, PP>(xp, g, i, r); out[i] = xobj_result_apply<PH, PP>(r, T); }
+        TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+        return 0;
+    }
     for (int64_t n = 0; n < N; ++n) {
         XSoA xa{X, ldx, n};
         double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});

@@ -127,13 +127,65 @@ def test_nan_and_infinite_samples_stay_nan(backend):
     assert relerr(Z[ok], Zo[ok]) < 1e-11
 
 
-def test_orders_beyond_the_dense_classes_take_the_generic_path(backend):
-    """Example 01's order-10 map: Hermite-function orders 1..10 > TTM_I_PMAX = 8 - the generic kernels run."""
+def test_example01_order10_map_takes_the_dense_kernels(backend):
+    """Example 01's order-10 map (example_01.py:121-170: Hermite-function orders 1..10, the reference's shipped configuration):
+    order class (10, 0) of the monomial-form kernels (round 4 stopped at order 8 and sent it to the generic interpreter);
+    map against the reference's values, objective and gradient through the X program against the generic kernels."""
     from tests.test_transport_map import make_tm as make_any
     npz, desc = load_case('ex01_order10')
     tm = make_any('ex01_order10', npz, desc)
     Z = tm.map(npz['X_head'])
     if backend == 'hip':
         tm.forward_device(tm._Xs, tm._N)
-        assert last_kernel(tm) in ('k_forward', 'k_forward_plan')
-    assert relerr(Z, npz['Z_head']) < 1e-11
+        assert last_kernel(tm) == 'k_int_forward'
+    check('dense/map[ex01_order10]', relerr(Z, npz['Z_head']), 1e-11, backend)
+    for k in range(tm.D):
+        div = len(tm.coeffs_nonmon[k])
+        c = np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k]))
+        tm._obj_cache = None
+        J, G = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
+        if backend == 'hip':
+            tm._device_sums(k, c)
+            assert last_kernel(tm) == 'k_int_objective'
+        with generic_path(tm, backend):
+            tm._obj_cache = None
+            Jg, Gg = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
+            if backend == 'hip':
+                tm._device_sums(k, c)
+                assert last_kernel(tm) == 'k_objective'
+        check('dense/objective_vs_generic[ex01_order10]', abs(J - Jg) / (1 + abs(Jg)), 1e-12, backend)
+        check('dense/gradient_vs_generic[ex01_order10]', relerr(G, Gg), 1e-11, backend)
+
+
+def test_x_program_and_fold_recipe_walk_agree(backend):
+    """The objective / gradient sums through the component's X program (csrc/ttm_xprog.h) against the kernel that walks the
+    fold recipe (option int_xprog = 0), every integrated fixture, every component."""
+    for name in DENSE:
+        npz, desc = load_case(name)
+        tm = make_tm(name, npz, desc)
+        for k in range(tm.D):
+            div = len(tm.coeffs_nonmon[k])
+            c = np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k])) * 0.97 + 0.005
+            tm._obj_cache = None
+            J, G = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
+            if backend == 'hip':
+                tm._device_sums(k, c)
+                assert last_kernel(tm) == 'k_int_objective'
+                tm._lib.ttm_set_option(b'int_xprog', 0)
+            else:
+                os.environ['TTM_INT_XPROG'] = '0'
+            try:
+                tm._obj_cache = None
+                Jw, Gw = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
+                if backend == 'hip':
+                    tm._device_sums(k, c)
+                    assert last_kernel(tm) == 'k_int_objective_walk'
+            finally:
+                if backend == 'hip':
+                    tm._lib.ttm_reset_options()
+                else:
+                    del os.environ['TTM_INT_XPROG']
+            with np.errstate(all='ignore'):
+                scale = 1.0 + np.abs(Gw)
+                check('xprog/objective_vs_walk[%s]' % name, abs(J - Jw) / (1 + abs(Jw)), 1e-12, backend)
+                check('xprog/gradient_vs_walk[%s]' % name, float(np.max(np.abs(G - Gw) / scale)), 1e-11, backend)

@@ -64,7 +64,7 @@ for w in sys.argv[2:]:
               'definition': 'flop_per_call = 64 lanes x (2 FMA + ADD + MUL + TRANS) fp64 wave-instructions summed over the launches '
                             'of ONE call (a reference-sequence inversion is two launches: samples 1..N-1, then sample 0)'}
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'fp64_counts.json'), 'w'), indent=1, sort_keys=True)
-json.dump(full, open(os.path.join(ROOT, 'profiles', 'r04_fp64_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
+json.dump(full, open(os.path.join(ROOT, 'profiles', 'r05_fp64_pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 for w, c in out.items():
     print(w, 'forward', c['forward_kernel'], 'inverse', c['inverse_kernel'], 'newton', c['newton_kernel'])
     for k, v in sorted(c['kernels'].items(), key=lambda kv: -kv[1]['flop_per_call'])[:8]:

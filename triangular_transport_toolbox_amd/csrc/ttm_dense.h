@@ -3,7 +3,7 @@
 // A component of an integrated-rectifier map (TM:2499-2547) is
 //     S_k(x) = Psi_nonmon(x_<k) c_nonmon + int_0^{x_k} ( r(g(t)) + delta ) dt,      g(t) = sum_b w_b(x_<k) B_b(t),
 // with the integral taken by Gauss-Legendre quadrature (TM:4238-4258: Q nodes, 25 in the examples).  For a polynomial map
-// the B_b are Hermite-function orders <= Ph and / or plain polynomial orders <= Pp of x_k (any set of orders - the
+// the B_b are Hermite-function orders <= Ph and / or plain polynomial orders <= Pp of x_k (any set of orders <= TTM_I_PMAX = 10 - the
 // "dense B set" of ttm_eval.h is the case 1..P -, no special terms), so
 //     g(t) = E(t) H(t) + A(t),        E(t) = exp(-t^2/4),   H, A polynomials of degree Ph, Pp.
 // Everything a sample spends on a component is spent in the Q nodes - in the bisection (TM:3842-3976) Q nodes for each
@@ -255,20 +255,16 @@ TTM_HD double dense_sample_root(const Comp& c, const Prog& p, double qw_sum, Var
     return NEWTON ? sample_newton<TTM_MONO_INTEGRATED>(c, p, off, zk, s, it) : sample_bisect<TTM_MONO_INTEGRATED>(c, p, off, zk, s, cap, it);
 }
 
-// objective + gradient contribution of one sample (TM:3343-3376, 3475-3569); scratch as sample_objective_int_dense:
-// w (nB+1; reused for the B values at x_k) | I (nB+1).  The integrals int r'(g) B_b dt are taken as MONOMIAL moments
-// sum_q cq E_q t_q^j (one multiplication for the power and one FMA per order and node) and converted to the basis once.
-template <int PH, int PP, int RECT, class XA, class Slots, class Acc>
-TTM_HD void dense_sample_objective(const Comp& c, const Prog& p, double qw_sum, VarCache<XA, double>& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
-    typedef VecD<TTM_I_NODES> V;
+// The node loop of the objective: sum_q W_q r(g_q) (-> mono) and the MONOMIAL moments of W_q r'(g_q) over the nodes,
+//     mh[j] = sum_q W_q r'(g_q) E(t_q) t_q^j  (j <= PH),      mp[j] = sum_q W_q r'(g_q) t_q^j  (j <= PP),
+// from which every integral int r'(g) B_b dt follows by the basis-conversion row of B_b (one multiplication for the power
+// and one addition per order and node); NODES nodes per pass.  The factor x_k/2 of the rule follows once, outside.
+template <int PH, int PP, int RECT, int NODES = TTM_I_NODES>
+TTM_HD void dense_moment_nodes(const Prog& p, const DenseMono<PH, PP>& d, double xk, double& mono, double* mh, double* mp) {
+    typedef VecD<NODES> V;
     const int rect = (RECT >= 0) ? RECT : p.rect;
-    dense_weights<double>(c, p, x, w);
-    DenseMono<PH, PP> d;
-    dense_monomials<PH, PP>(c, p, w, d);
-    const double xk = x.get(c.kc);
     const double half = xk * 0.5;
-    double mono = 0.0;
-    double mh[PH + 1], mp[PP + 1];
+    mono = 0.0;
 #pragma unroll
     for (int j = 0; j <= PH; ++j) mh[j] = 0.0;
 #pragma unroll
@@ -309,8 +305,25 @@ TTM_HD void dense_sample_objective(const Comp& c, const Prog& p, double qw_sum, 
         }
     };
     int q = 0;
-    for (; q + TTM_I_NODES <= p.Q; q += TTM_I_NODES) nodes(V(0.0), q);
+    for (; q + NODES <= p.Q; q += NODES) nodes(V(0.0), q);
     for (; q < p.Q; ++q) nodes(0.0, q);
+}
+
+// objective + gradient contribution of one sample (TM:3343-3376, 3475-3569); scratch as sample_objective_int_dense:
+// w (nB+1; reused for the B values at x_k) | I (nB+1).  The integrals int r'(g) B_b dt are taken as MONOMIAL moments
+// sum_q cq E_q t_q^j (dense_moment_nodes) and converted to the basis once.  (Components without an X program: the gradient
+// walks the fold recipe - csrc/ttm_xprog.h is the path of the others.)
+template <int PH, int PP, int RECT, class XA, class Slots, class Acc>
+TTM_HD void dense_sample_objective(const Comp& c, const Prog& p, double qw_sum, VarCache<XA, double>& x, Slots& w, Slots& Bv, Slots& I, Acc& acc) {
+    const int rect = (RECT >= 0) ? RECT : p.rect;
+    dense_weights<double>(c, p, x, w);
+    DenseMono<PH, PP> d;
+    dense_monomials<PH, PP>(c, p, w, d);
+    const double xk = x.get(c.kc);
+    const double half = xk * 0.5;
+    double mono;
+    double mh[PH + 1], mp[PP + 1];
+    dense_moment_nodes<PH, PP, RECT>(p, d, xk, mono, mh, mp);
     mono = half * fma(p.delta, qw_sum, mono) + (d.probe + xk * 0.0);
     // basis integrals from the moments (the Hermite-function ones carry their normalisation constants, as in
     // sample_objective_int_dense)
@@ -349,9 +362,9 @@ struct DenseClass { int ph, pp; };
 TTM_HD DenseClass dense_class_of(int max_ph, int max_pp) {
     DenseClass k{0, 0};
     if (max_ph > TTM_I_PMAX || max_pp > TTM_I_PMAX || (max_ph == 0 && max_pp == 0)) return k;
-    if (max_pp == 0) { k.ph = max_ph <= 3 ? 3 : (max_ph <= 5 ? 5 : 8); k.pp = 0; }
-    else if (max_ph == 0) { k.ph = 0; k.pp = 8; }
-    else { k.ph = 8; k.pp = 8; }
+    if (max_pp == 0) { k.ph = max_ph <= 3 ? 3 : (max_ph <= 5 ? 5 : (max_ph <= 8 ? 8 : 10)); k.pp = 0; }
+    else if (max_ph == 0) { k.ph = 0; k.pp = 10; }
+    else { k.ph = 10; k.pp = 10; }
     return k;
 }
 
@@ -373,13 +386,19 @@ inline bool dense_range_class(const int32_t* h_complex, int k0, int k1, DenseCla
 // run CALL(PH, PP, RECT) for the class and rectifier given at run time (host-side dispatch: kernel pick, test double)
 #define TTM_DENSE_DISPATCH_RECT(CALL, PH, PP, rect) \
     do { if ((rect) == TTM_RECT_EXPONENTIAL) { CALL(PH, PP, TTM_RECT_EXPONENTIAL); } else { CALL(PH, PP, -1); } } while (0)
+#ifdef TTM_INT_MINI      /* (tuning builds: two classes, exponential rectifier only - a sixth of the compile time) */
+#define TTM_DENSE_DISPATCH(CALL, cls, rect) \
+    do { if ((cls).ph == 3) { CALL(3, 0, TTM_RECT_EXPONENTIAL); } else { CALL(5, 0, TTM_RECT_EXPONENTIAL); } } while (0)
+#else
 #define TTM_DENSE_DISPATCH(CALL, cls, rect)                                           \
     do {                                                                               \
         if ((cls).pp == 0 && (cls).ph == 3) TTM_DENSE_DISPATCH_RECT(CALL, 3, 0, rect); \
         else if ((cls).pp == 0 && (cls).ph == 5) TTM_DENSE_DISPATCH_RECT(CALL, 5, 0, rect); \
-        else if ((cls).pp == 0) TTM_DENSE_DISPATCH_RECT(CALL, 8, 0, rect);             \
-        else if ((cls).ph == 0) TTM_DENSE_DISPATCH_RECT(CALL, 0, 8, rect);             \
-        else TTM_DENSE_DISPATCH_RECT(CALL, 8, 8, rect);                                \
+        else if ((cls).pp == 0 && (cls).ph == 8) TTM_DENSE_DISPATCH_RECT(CALL, 8, 0, rect); \
+        else if ((cls).pp == 0) TTM_DENSE_DISPATCH_RECT(CALL, 10, 0, rect);            \
+        else if ((cls).ph == 0) TTM_DENSE_DISPATCH_RECT(CALL, 0, 10, rect);            \
+        else TTM_DENSE_DISPATCH_RECT(CALL, 10, 10, rect);                              \
     } while (0)
+#endif
 
 }  // namespace ttm

@@ -173,7 +173,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 
 #define TTM_RED_BLOCKS 1024
-#define TTM_HOSTCOEF_MAX 64
+#define TTM_HOSTCOEF_MAX 128
 
 // "Which workgroup is the last one?" without a thousand atomics on one address (they serialise in the L2: ~75 ns each,
 // 77 us for the 977 workgroups of an N = 1e6 reduction): workgroups draw a ticket from one of 8 group counters
@@ -202,6 +202,86 @@ __device__ __forceinline__ bool last_workgroup(unsigned int* counter) {
     return is_last != 0;
 }
 
+// Two-stage finish of a reduction over MANY workgroups and sums (the X-program objective kernel: up to 1 016 workgroups x 192
+// sums - one workgroup adding 1 016 rows by itself spends 60-80 us in dependent round trips, measured).  Workgroup b has written
+// its nsum partial sums to row b of `partial` (coherent_store).  Stage A: the last workgroup of group g = b mod 8 to arrive
+// (ticket on counter[1 + g]) adds the rows of its group into row nb + g - the eight groups finish side by side, all but the
+// last one while other workgroups still compute.  Stage B: the last of those (ticket on counter[0]) adds the eight group rows
+// into `fin` (LDS, nsum doubles) and returns true.  Rows are added lane = sum index (coalesced), wave = every nw-th row, four
+// loads in flight per lane; fixed order: run-to-run deterministic.  `scr`: LDS scratch of nw x nsum doubles.
+// Visibility WITHOUT fences (a device-scope fence is an L2 write-back per wave: 1 000 workgroups x 4 waves of them cost this
+// kernel 45-55 us, measured): the rows travel as agent-scope atomic stores / loads - written through to / read from the level the
+// XCDs share -, every wave drains its stores (vmcnt(0)) before the workgroup draws its ticket.
+// partial must hold nb + 8 rows; counter: 16 uint32, zero before the first launch; left zero.
+__device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() {
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "drain_stores(): the raw s_waitcnt immediate below is the gfx9 encoding"
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // (compiler ordering)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0)
+}
+
+__device__ __forceinline__ void add_rows(const double* partial, int first, int step, int count, int nsum, double* scr,
+                                         double* dst_lds, double* dst_glob) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    constexpr int B = 16;                                   // loads in flight per lane (a round trip to the shared level is ~1.5 us)
+    for (int i0 = 0; i0 < nsum; i0 += 64) {
+        const int i = i0 + lane;
+        double a0 = 0.0, a1 = 0.0;
+        if (i < nsum) {
+            for (int r0 = wv; r0 < count; r0 += B * nw) {
+                double v[B];
+#pragma unroll
+                for (int j = 0; j < B; ++j) {
+                    const int r = r0 + j * nw;
+                    v[j] = r < count ? coherent_load(partial + (int64_t)(first + r * step) * nsum + i) : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < B; j += 2) { a0 += v[j]; a1 += v[j + 1]; }
+            }
+            scr[wv * nsum + i] = a0 + a1;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nsum; i += blockDim.x) {
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += scr[w * nsum + i];
+        if (dst_lds) dst_lds[i] = v;
+        if (dst_glob) coherent_store(dst_glob + i, v);
+    }
+    drain_stores();
+    __syncthreads();
+}
+
+// (every wave of the workgroup has drained its coherent_store's of row blockIdx.x before the call; flag: an int in LDS)
+// stage A: false = this workgroup is done; true = it has added the rows of its group, drawn its second ticket (verdict in
+// *flag) and goes on to finish_stage_b
+__device__ __forceinline__ bool finish_stage_a(double* partial, int nsum, unsigned int* counter, double* scr, int* flag) {
+    const unsigned int nb = gridDim.x, g = blockIdx.x & 7u;
+    const unsigned int in_group = (nb - g + 7u) / 8u;
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(counter + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_group - 1u ? 1 : 0;
+    __syncthreads();
+    if (!*flag) return false;
+    add_rows(partial, (int)g, 8, (int)in_group, nsum, scr, nullptr, partial + (int64_t)(nb + g) * nsum);
+    if (threadIdx.x == 0) {
+        const unsigned int ngroups = nb < 8u ? nb : 8u;
+        *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1 : 0;
+    }
+    return true;
+}
+// stage B (same flag): true = this is the last workgroup of the grid, `fin` (LDS) holds the nsum totals
+__device__ __forceinline__ bool finish_stage_b(double* partial, int nsum, unsigned int* counter, double* scr, double* fin, int* flag) {
+    const unsigned int nb = gridDim.x, ngroups = nb < 8u ? nb : 8u;
+    __syncthreads();
+    if (!*flag) return false;
+    if (threadIdx.x < 9) __hip_atomic_store(counter + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    add_rows(partial, (int)nb, 1, (int)ngroups, nsum, scr, fin, nullptr);
+    return true;
+}
+
 // Results of a finishing workgroup and the completion mark behind them (all threads of the workgroup call; fin: the n
 // results in LDS).  ONE wave stores the results, waits until every one of those stores has been acknowledged
 // (s_waitcnt vmcnt(0): the results span several cache lines, which travel through different L2 channels and would
@@ -228,4 +308,4 @@ __device__ __forceinline__ void publish(const double* fin, int n, double* out, d
         }
     }
 }
-#define TTM_FIN_MAX 72
+#define TTM_FIN_MAX 136         /* >= 1 + TTM_HOSTCOEF_MAX */

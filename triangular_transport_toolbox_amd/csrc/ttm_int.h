@@ -3,6 +3,7 @@
 // bookkeeping.  A launch geometry is handed in; the name of the kernel that ran comes back for ttm_last_kernel().
 #pragma once
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ttm.h"
@@ -29,5 +30,14 @@ int root(const ttm_program* p, const DevProg& P, int k0, int k1, const double* c
 int objective(const ttm_program* p, const DevProg& P, int k, const double* coef_k, const double* fold_k, const double* Xsoa,
               int64_t ldx, int64_t N, int nscr, int nacc, double* partial, unsigned int* counter, double* out, double* flag,
               double mark, int grid, int bd, size_t lds, void* stream, const char** kernel_name);
+
+// the same sums through the component's X program (csrc/ttm_xprog.h: every factor value once per sample, a sum per lane): one launch
+// per evaluation, coefficients from the host (h_coef_k: kernel argument) or from device memory (d_coef_k); finished by the
+// workgroup that draws the last ticket (out != nullptr) - grids of up to TTM_RED_BLOCKS workgroups
+bool has_xprog(const ttm_program* p, int k);
+size_t objective_x_lds(const ttm_program* p, int k, int bd);
+int objective_x(const ttm_program* p, const DevProg& P, int k, const double* h_coef_k, const double* d_coef_k, int ncoef, const double* Xsoa,
+                int64_t ldx, int64_t N, double* partial, unsigned int* counter, double* out, double* flag, double mark,
+                int grid, int bd, void* stream, const char** kernel_name);
 
 }  // namespace ttm_int

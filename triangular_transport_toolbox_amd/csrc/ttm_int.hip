@@ -18,6 +18,7 @@
 
 #include "ttm_dev.h"
 #include "ttm_dense.h"
+#include "ttm_xprog.h"
 #include "ttm_int.h"
 
 using namespace ttm;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void k_int_root(DevProg P, int k0, int k1, int
 
 // LDS: erf table | column cache | per-thread scratch columns (nscr) | one row of nacc running sums per wave
 template <int PH, int PP, int RECT>
-__global__ __launch_bounds__(256) void k_int_objective(DevProg P, int k, const double* __restrict__ coef_k,
+__global__ __launch_bounds__(256) void k_int_objective_walk(DevProg P, int k, const double* __restrict__ coef_k,
                                                        const double* __restrict__ fold_k, const double* __restrict__ X,
                                                        int64_t ldx, int64_t N, int nscr, int nacc, double* __restrict__ partial,
                                                        unsigned int* __restrict__ counter, double* __restrict__ out, double* flag,
@@ -153,6 +154,149 @@ __global__ __launch_bounds__(256) void k_int_objective(DevProg P, int k, const d
             }
             publish(fin, nacc, out, flag, mark);
         }
+    }
+}
+
+// ---- objective + gradient sums through the X program (csrc/ttm_xprog.h) ---------------------------------------------------
+// LDS: [coefficients (TTM_HOSTCOEF_MAX) | the component's fold (nfold) | per wave: rows of its 64 samples, COLUMN-major with a
+// column stride of XOBJ_CS = 65 doubles | per wave XOBJ_SUMS running totals].  Column-major: in the per-sample phase the
+// 64 lanes of a wave write one column at consecutive addresses; in the sum phase lane t reads column c(t) at the SAME sample
+// s - addresses c(t) 65 + s, different columns on different banks - and s is an immediate offset of the unrolled loop.
+// Per tile of blockDim samples: every lane writes the row of its sample (xobj_sample_row), then - inside each wave, no
+// workgroup barrier - lane t walks the wave's 64 rows with the two columns of sum t (a component with more than 64 sums
+// gives a lane up to three).  Two partial totals per sum keep the adds independent; fixed order, run-to-run deterministic.
+// The coefficients travel as a kernel argument (or come from device memory); the workgroup folds them itself (fold_coeffs:
+// the X section of the fold is what the per-sample phase reads): ONE launch per evaluation, finished - sums of the
+// workgroups, then the basis conversion of xobj_result - by the workgroup that draws the last ticket.
+#define XOBJ_SUMS TTM_X_SUM_MAX
+#define XOBJ_CS 65
+#define XOBJ_NCH ((TTM_X_SUM_MAX + 63) / 64)
+struct XCoef { double c[TTM_HOSTCOEF_MAX]; };
+
+struct WaveRow {             // the row of this lane's sample inside its wave's column-major block
+    double* base;
+    __device__ __forceinline__ double get(int c) const { return base[c * XOBJ_CS]; }
+    __device__ __forceinline__ void set(int c, double v) { base[c * XOBJ_CS] = v; }
+};
+struct SumsView {
+    const double* t;
+    __device__ __forceinline__ double operator[](int i) const { return t[i]; }
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // rows written by the lanes of this wave are read by other lanes of the SAME wave: LDS operations of a wave complete in
+    // order, what is needed is that the compiler keeps them in order and waits for the writes' return
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#ifndef XOBJ_OCC
+#define XOBJ_OCC 1
+#endif
+template <int PH, int PP, int RECT, int NCH>
+__global__ __launch_bounds__(256, XOBJ_OCC) void k_int_objective(DevProg P, int k, XCoef hc, const double* __restrict__ d_coef, int ncoef,
+                                                                 const double* __restrict__ X, int64_t ldx, int64_t N, int nfold, int ncols,
+                                                                 double* __restrict__ partial, unsigned int* __restrict__ counter,
+                                                                 double* __restrict__ out, double* flag, double mark) {
+    constexpr int NQ = XQ<PH, PP>::NQ;
+    const int bd = blockDim.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = bd >> 6;
+    double* lcoef = g_smem;
+    double* lfold = lcoef + TTM_HOSTCOEF_MAX;
+    double* rows = lfold + nfold;
+    double* wsum = rows + (size_t)nw * ncols * XOBJ_CS;
+    // the program first (chains of dependent scalar loads: they travel while the coefficients are folded)
+    const int* off = P.off;
+    const int D1 = P.D + 1;
+    cint_p cb = (cint_p)P.itab + off[k];
+    XProg xp;
+    xprog_view(cb, (cdbl_p)P.dpar + off[D1 + k], xp);
+    Prog g;
+    g.qx = (cdbl_p)P.qx; g.qw = (cdbl_p)P.qw; g.erf_tab = nullptr; g.Q = P.Q; g.family = P.family; g.mono = P.mono; g.rect = P.rect;
+    g.delta = P.delta;
+    const double qws = dense_qw_sum(g);
+    const int nsum = xp.nsum;
+    // the sums of this lane: t = lane + 64 c; the two columns as offsets (doubles) into the wave's block
+    double* wblock = rows + (size_t)wv * ncols * XOBJ_CS;
+    const int* ganm = P.itab + off[k] + (int)(xp.anm - cb);
+    const int* gamon = P.itab + off[k] + (int)(xp.amon - cb);
+    int o1[NCH], o2[NCH];
+    double acc[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int c1 = 0, c2 = 0;
+        if (lane + 64 * c < nsum) xobj_sum_columns(ganm, gamon, xp.na_nm, xp.nrow, NQ, lane + 64 * c, c1, c2);
+        o1[c] = c1 * XOBJ_CS; o2[c] = c2 * XOBJ_CS;
+        acc[c][0] = acc[c][1] = 0.0;
+    }
+    for (int i = tid; i < TTM_HOSTCOEF_MAX; i += bd) lcoef[i] = d_coef ? (i < ncoef ? d_coef[i] : 0.0) : hc.c[i];
+    __syncthreads();
+#ifndef XOBJ_X_NOFOLD                                        /* (XOBJ_X_*: timing builds, results wrong by construction) */
+    fold_coeffs(P.itab + off[k], P.ftab + off[4 * D1 + k], P.dpar + off[D1 + k], lcoef, lfold, tid, bd);
+#else
+    for (int i = tid; i < nfold; i += bd) lfold[i] = 0.01;
+#endif
+    __syncthreads();
+    WaveRow row{wblock + lane};
+    for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
+        const int64_t n = n0 + tid;
+        const bool active = n < N;
+        const XSoA xa{X, ldx, active ? n : N - 1};
+        // (the fold is constant over the tiles: without this the compiler keeps every entry the per-sample phase reads in a
+        // vector register across the whole loop)
+        const double* fx = lfold + xp.fold_x;
+        asm volatile("" : "+v"(fx));
+#ifndef XOBJ_X_NOROW
+        xobj_sample_row<PH, PP, RECT>(xp, g, qws, fx, xa, row, active);
+#else
+        for (int c = 0; c < ncols; ++c) row.set(c, xa(xp.kc) + fx[c & 7]);
+#endif
+        wave_lds_sync();
+#ifndef XOBJ_X_NOSUM
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (64 * c < nsum) {
+                const double* p1 = wblock + o1[c];
+                const double* p2 = wblock + o2[c];
+#pragma unroll
+                for (int s = 0; s < 64; ++s) acc[c][s & 1] = fma(p1[s], p2[s], acc[c][s & 1]);
+            }
+        }
+#else
+        acc[0][0] += wblock[o1[0]] + wblock[o2[0]];
+#endif
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) wsum[wv * XOBJ_SUMS + 64 * c + lane] = acc[c][0] + acc[c][1];
+    __syncthreads();
+    for (int i = tid; i < nsum; i += bd) {
+        double v = 0.0;
+        for (int wq = 0; wq < nw; ++wq) v += wsum[wq * XOBJ_SUMS + i];
+        coherent_store(partial + (int64_t)blockIdx.x * nsum + i, v);
+    }
+    drain_stores();
+#ifdef XOBJ_X_NOFIN
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(flag ? flag : out, mark, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+#endif
+    {
+        // (LDS: the rows are done with - group / final sums in `rows`, scratch of nw x nsum in the wave totals' place)
+        double* fin = rows;                                       // sums of all workgroups, then the results behind them
+        double* res = rows + XOBJ_SUMS;
+        __shared__ int stage_a;
+        if (!finish_stage_a(partial, nsum, counter, wsum, &stage_a)) return;
+        // what result `tid` is made of (program reads) travels while the last group rows arrive
+        XResult<PH, PP> plan;
+        if (tid <= ncoef) xobj_result_plan<PH, PP>(xp, g, tid, plan);
+        if (!finish_stage_b(partial, nsum, counter, wsum, fin, &stage_a)) return;
+        const SumsView T{fin};
+        if (tid <= ncoef) res[tid] = xobj_result_apply<PH, PP>(plan, T);
+        for (int i = tid + bd; i <= ncoef; i += bd) {             // (more results than threads: 128 coefficients, a workgroup of 128)
+            xobj_result_plan<PH, PP>(xp, g, i, plan);
+            res[i] = xobj_result_apply<PH, PP>(plan, T);
+        }
+        publish(res, 1 + ncoef, out, flag, mark);
     }
 }
 
@@ -219,8 +363,49 @@ int objective(const ttm_program* p, const DevProg& P, int k, const double* coef_
     DenseClass cls;
     if (!dense_range_class(p->h_complex, k, k + 1, cls)) return TTM_E_UNSUPPORTED;
 #define TTM_CALL(PH, PP, RECT)                                                                                             \
-    hipLaunchKernelGGL((k_int_objective<PH, PP, RECT>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k, coef_k, fold_k, Xsoa, \
+    hipLaunchKernelGGL((k_int_objective_walk<PH, PP, RECT>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k, coef_k, fold_k, Xsoa, \
                        ldx, N, nscr, nacc, partial, counter, out, flag, mark)
+    TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
+#undef TTM_CALL
+    *kernel_name = "k_int_objective_walk";
+    return TTM_OK;
+}
+
+bool has_xprog(const ttm_program* p, int k) { return usable(p, k, k + 1) && (p->h_complex[k] & 16) != 0; }
+
+// row columns of the objective kernel: the X program's own + the q columns of the component's order class
+static int objective_x_cols(const ttm_program* p, int k) {
+    DenseClass cls;
+    if (!dense_range_class(p->h_complex, k, k + 1, cls)) return 0;
+    return ((p->h_complex[k] >> 16) & 255) + (cls.ph > 0 ? cls.ph + 1 : 0) + cls.pp + 1;
+}
+
+size_t objective_x_lds(const ttm_program* p, int k, int bd) {
+    const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
+    size_t rows = (size_t)(bd / 64) * objective_x_cols(p, k) * XOBJ_CS;
+    if (rows < (size_t)2 * XOBJ_SUMS) rows = 2 * XOBJ_SUMS;       // (the finishing workgroup keeps sums and results there)
+    return ((size_t)TTM_HOSTCOEF_MAX + nfold + rows + (size_t)(bd / 64) * XOBJ_SUMS) * sizeof(double);
+}
+
+int objective_x(const ttm_program* p, const DevProg& P, int k, const double* h_coef_k, const double* d_coef_k, int ncoef, const double* Xsoa,
+                int64_t ldx, int64_t N, double* partial, unsigned int* counter, double* out, double* flag, double mark,
+                int grid, int bd, void* stream, const char** kernel_name) {
+    DenseClass cls;
+    if (!dense_range_class(p->h_complex, k, k + 1, cls) || !(p->h_complex[k] & 16)) return TTM_E_UNSUPPORTED;
+    if (ncoef < 1 || ncoef > TTM_HOSTCOEF_MAX || (!h_coef_k && !d_coef_k) || !counter || !out) return TTM_E_ARG;
+    XCoef hc;
+    for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = (h_coef_k && i < ncoef) ? h_coef_k[i] : 0.0;
+    const size_t lds = objective_x_lds(p, k, bd);
+    const int nfold = p->h_fold_off[k + 1] - p->h_fold_off[k];
+    const int ncols = objective_x_cols(p, k);
+    const int nch = (p->h_complex[k] >> 24) & 3;            // (sums of an evaluation / 64, rounded up)
+#define TTM_CALL(PH, PP, RECT)                                                                                                  \
+    do {                                                                                                                       \
+        if (nch <= 1) hipLaunchKernelGGL((k_int_objective<PH, PP, RECT, 1>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k, hc, \
+                                           d_coef_k, ncoef, Xsoa, ldx, N, nfold, ncols, partial, counter, out, flag, mark);    \
+        else hipLaunchKernelGGL((k_int_objective<PH, PP, RECT, XOBJ_NCH>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k, hc,   \
+                                d_coef_k, ncoef, Xsoa, ldx, N, nfold, ncols, partial, counter, out, flag, mark);               \
+    } while (0)
     TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
 #undef TTM_CALL
     *kernel_name = "k_int_objective";

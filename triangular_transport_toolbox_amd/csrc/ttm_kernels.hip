@@ -2438,6 +2438,7 @@ static const DeviceInfo& device_info() {
     X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */ \
     X(band_ring, -1)     /* 0: banded table inverse through k_band_inverse (tables assembled per block) although images are at hand */ \
     X(int_dense, -1)     /* 0: integrated maps with dense B sets through the generic kernels instead of csrc/ttm_int.hip */ \
+    X(int_xprog, -1)     /* 0: objective / gradient sums of integrated components without their X programs (csrc/ttm_xprog.h) */ \
     X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
     X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
     X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
@@ -3260,7 +3261,22 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
 
 // workspace: [folded coefficients of the component (<= 4096) | per-block partials]
 #define TTM_OBJ_FOLD_MAX 4096
-int64_t ttm_reduce_work_size(int32_t nout) { return (int64_t)TTM_OBJ_FOLD_MAX + (int64_t)TTM_RED_BLOCKS * (nout > 0 ? nout : 1); }
+// (rows of per-workgroup partial sums: nout doubles, or the TTM_X_SUM_MAX sums of an X-program evaluation, csrc/ttm_xprog.h)
+int64_t ttm_reduce_work_size(int32_t nout) { return (int64_t)TTM_OBJ_FOLD_MAX + (int64_t)TTM_RED_BLOCKS * (nout > TTM_X_SUM_MAX ? nout : TTM_X_SUM_MAX); }
+
+// objective + gradient sums of an integrated component through its X program (csrc/ttm_xprog.h, k_int_objective): ONE launch,
+// coefficients as kernel arguments (h_coef_k) or from device memory (d_coef_k).  TTM_E_UNSUPPORTED: the component has none.
+static int objective_xprog(const ttm_program* p, int k, const double* h_coef_k, const double* d_coef_k, int ncoef, const double* Xsoa,
+                           int64_t ldx, int64_t N, double* partial, unsigned int* counter, double* out, double* flag, double mark,
+                           void* stream, const char** name) {
+    if (tuning().int_dense == 0 || tuning().int_xprog == 0 || ncoef > TTM_HOSTCOEF_MAX || !counter || !ttm_int::has_xprog(p, k)) return TTM_E_UNSUPPORTED;
+    int bd = 256;
+    while (bd > 128 && ttm_int::objective_x_lds(p, k, bd) > (size_t)kLdsBudget) bd >>= 1;       // (>= 128: a result per thread at the finish)
+    if (ttm_int::objective_x_lds(p, k, bd) > (size_t)kLdsBudget) return TTM_E_UNSUPPORTED;
+    int nb = grid_for(N, bd);                        // (partial: TTM_RED_BLOCKS rows of <= TTM_X_SUM_MAX sums, ttm_reduce_work_size)
+    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;         // (eight more rows: the group sums of the two-stage finish)
+    return ttm_int::objective_x(p, dev_prog(p), k, h_coef_k, d_coef_k, ncoef, Xsoa, ldx, N, partial, counter, out, flag, mark, nb, bd, stream, name);
+}
 
 int ttm_objective(const ttm_program* p, int32_t k, const double* coef_k, const double* Xsoa, int64_t ldx, int64_t N,
                   double* work, double* out, void* stream) {
@@ -3315,7 +3331,7 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     const int n_nm = p->h_n_nm[k];
     const int ncoef = p->h_coef_off[k + 1] - p->h_coef_off[k];
     const int n_mon = ncoef - n_nm;
-    if (ncoef > TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "ttm_objective_host: component %s%lld has more than 64 coefficients", "", k);
+    if (ncoef > TTM_HOSTCOEF_MAX) return set_err(TTM_E_LIMIT, "ttm_objective_host: component %s%lld has more than 128 coefficients", "", k);
     const int nacc = sep ? 1 + n_mon : 1 + n_nm + n_mon;
     // scratch columns per thread: separable dB | integrated w, B values, integrals - a dense B set keeps its B values in the
     // weights' columns (they are dead by then): two sets instead of three
@@ -3330,6 +3346,11 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     double* fold_k = work;
     double* coef_dev = work + TTM_OBJ_FOLD_MAX - TTM_HOSTCOEF_MAX;
     double* partial = work + TTM_OBJ_FOLD_MAX;
+    if (!sep) {
+        const char* xname = nullptr;
+        if (objective_xprog(p, k, h_coef_k, nullptr, ncoef, Xsoa, ldx, N, partial, (unsigned int*)counter, out, flag, mark, stream, &xname) == TTM_OK)
+            return check_launch(xname);
+    }
     HostCoef hc;
     for (int i = 0; i < TTM_HOSTCOEF_MAX; ++i) hc.c[i] = i < ncoef ? h_coef_k[i] : 0.0;
     hipLaunchKernelGGL(k_fold_host, dim3(1), dim3(64), 0, (hipStream_t)stream, P, (int)k, hc, ncoef, coef_dev, fold_k);

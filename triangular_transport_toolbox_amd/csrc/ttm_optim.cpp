@@ -407,7 +407,7 @@ int ttm_bfgs_minimize(int32_t n, double* x, ttm_objective_cb fun, void* user, in
 int ttm_optimize_integrated(const ttm_program* p, int32_t k, int32_t m, const double* Xsoa, int64_t ldx, int64_t N, double Ntotal,
                             int32_t regularization, const double* lambda, double* x, double* work, uint32_t* counter,
                             double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result) {
-    if (!p || !Xsoa || !x || !work || !counter || !sums_host || m < 1 || m > 64 || N < 1 || !(Ntotal > 0.0) || regularization < 0 ||
+    if (!p || !Xsoa || !x || !work || !counter || !sums_host || m < 1 || m > 128 || N < 1 || !(Ntotal > 0.0) || regularization < 0 ||
         regularization > 2 || (regularization && !lambda))
         return TTM_E_ARG;
     if (comm && !sums_dev) return TTM_E_ARG;

@@ -38,10 +38,12 @@ import numpy as np
 KIND_POLY, KIND_HF, KIND_LET, KIND_RET, KIND_RBF, KIND_IRBF = 1, 2, 3, 4, 5, 6
 ST_KINDS = {'let': KIND_LET, 'ret': KIND_RET, 'rbf': KIND_RBF, 'irbf': KIND_IRBF}
 FAM_HERMITE_E, FAM_POWER, FAM_HERMITE, FAM_CHEBYSHEV, FAM_LAGUERRE, FAM_LEGENDRE = range(6)
-HDR_LEN = 28
+HDR_LEN = 32
 (HDR_KC, HDR_N_NM, HDR_OFF_NM, HDR_N_MON, HDR_OFF_MON, HDR_OFF_FAC, HDR_NB, HDR_OFF_B, HDR_NB_HF, HDR_NB_POLY,
  HDR_NB_ST, HDR_MAXP_HF, HDR_MAXP_POLY, HDR_FLAGS, HDR_N_DPAR, HDR_LEN_BLK, HDR_N_GRP, HDR_OFF_GRP, HDR_N_GEN,
- HDR_OFF_GEN, HDR_N_MNT, HDR_OFF_MNT, HDR_N_FOLD, HDR_OFF_FSLOT, HDR_OFF_FSRC, HDR_OFF_WB, HDR_N_XGRP, HDR_OFF_XGRP) = range(28)
+ HDR_OFF_GEN, HDR_N_MNT, HDR_OFF_MNT, HDR_N_FOLD, HDR_OFF_FSLOT, HDR_OFF_FSRC, HDR_OFF_WB, HDR_N_XGRP, HDR_OFF_XGRP,
+ HDR_OFF_XPROG, HDR_X_NROW, HDR_X_NSUM, HDR_X_RESERVED) = range(32)
+X_MAXF, X_NU_MAX, X_SUM_MAX, XR_ONE, XR_S, XR_J, XR_U = 3, 40, 192, 0, 1, 2, 3      # "X program" (include/ttm.h)
 ST_NPAR = 5   # centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)
 
 # polynomial_type -> (family id, numpy class, unified name)   (TM:274-304)
@@ -232,6 +234,127 @@ def _descriptor(term):
     return out
 
 
+I_PMAX = 10                   # TTM_I_PMAX (csrc/ttm_dense_table.h)
+
+
+def dense_class(max_ph, max_pp):
+    """Order class (PH, PP) of the monomial-form kernels for a component whose x_k-functions reach these orders
+    (csrc/ttm_dense.h: dense_class_of); None when there is none."""
+    if max_ph > I_PMAX or max_pp > I_PMAX or (max_ph == 0 and max_pp == 0):
+        return None
+    if max_pp == 0:
+        return (3 if max_ph <= 3 else (5 if max_ph <= 5 else (8 if max_ph <= 8 else 10)), 0)
+    if max_ph == 0:
+        return (0, 10)
+    return (10, 10)
+
+
+def _x_program(terms, facs, bfuns, n_nm, kc, polyclass, dp_const, dp_hf_value, fold_slots):
+    """X program of one component (include/ttm.h, csrc/ttm_xprog.h); None when the component cannot have one (a factor on
+    another column that is a special term, more than X_MAXF such factors in a term, a factor of higher order than the
+    component's order class, too many distinct values or sums).
+    terms: records [f0, nf, b, ci] (nonmonotone, then monotone, each in coefficient order); facs: [var, kind, order, p0];
+    bfuns: [kind, order, p0, 0].  dp_const(value) -> index of a constant in the component's dpar slice; fold_slots: the fold
+    recipe under construction - the X section (CN | HC | HP) is appended to it.
+    Returns dict(ints=[...], n_sum=...)."""
+    nB = len(bfuns)
+    max_ph = max([b[1] for b in bfuns if b[0] == KIND_HF], default=0)
+    max_pp = max([b[1] for b in bfuns if b[0] == KIND_POLY], default=0)
+    cls = dense_class(max_ph, max_pp)
+    if cls is None:
+        return None
+    PH, PP = cls
+    PM = max(PH, PP)
+    used = []
+    for f0, nf, _, _ in terms:
+        if nf > X_MAXF:
+            return None
+        for f in facs[f0:f0 + nf]:
+            if f[1] not in (KIND_POLY, KIND_HF) or f[0] == kc or f[2] > PM:
+                return None
+            key = (f[0], 0 if f[1] == KIND_POLY else 1, f[2])
+            if key not in used:
+                used.append(key)
+    if len(used) > X_NU_MAX:
+        return None
+    used.sort()                                            # by column, plain polynomials before Hermite functions, by order
+    cols = sorted(set(u[0] for u in used))
+    ucol = {u: XR_U + i for i, u in enumerate(used)}
+    # computed products (two or three factors), distinct
+    prods = []
+
+    def acol_of(f0, nf):
+        cs = sorted(ucol[(f[0], 0 if f[1] == KIND_POLY else 1, f[2])] for f in facs[f0:f0 + nf])
+        if len(cs) == 0:
+            return XR_ONE
+        if len(cs) == 1:
+            return cs[0]
+        key = tuple(cs)
+        if key not in prods:
+            prods.append(key)
+        return XR_U + len(used) + prods.index(key)
+    a_nm, a_mon, trec = [], [], []
+    for which, (f0, nf, b, ci) in enumerate(terms):
+        col = acol_of(f0, nf)
+        lst = a_nm if which < n_nm else a_mon
+        if col not in lst:
+            lst.append(col)
+        trec.append([lst.index(col), -1 if which < n_nm else (b if b >= 0 else nB), 0, 0])
+    NH = PH + 1 if PH > 0 else 0
+    NQ = NH + PP + 1
+    n_sum = 1 + len(a_nm) + len(a_mon) * NQ
+    if n_sum > X_SUM_MAX:
+        return None
+    # constants: Horner rows of the U values (a_n folded in), stride I_PMAX + 1
+    LD = I_PMAX + 1
+
+    def mono_row(order):
+        c = np.zeros(LD)
+        cc = polyclass.basis(order).convert(kind=np.polynomial.Polynomial).coef
+        c[:len(cc)] = cc
+        return c
+    urow_first = None
+    for (_, is_hf, order) in used:
+        row = mono_row(order) * (dp_hf_value(order) if is_hf else 1.0)
+        idx = [dp_const(float(v), force_new=True) for v in row]
+        urow_first = idx[0] if urow_first is None else urow_first
+        assert idx == list(range(idx[0], idx[0] + LD))
+    # fold X section: CN[a] | HC[a][0..LD) | HP[a][0..LD)
+    off_x = len(fold_slots)
+    fold_slots.extend([] for _ in range(len(a_nm) + 2 * LD * len(a_mon)))
+    for which, (f0, nf, b, ci) in enumerate(terms):
+        a = trec[which][0]
+        if which < n_nm:
+            fold_slots[off_x + a].append((ci, -1))
+            continue
+        gci = n_nm + ci
+        hc0 = off_x + len(a_nm) + a * LD
+        hp0 = off_x + len(a_nm) + LD * len(a_mon) + a * LD
+        if b < 0:
+            fold_slots[hp0].append((gci, -1))
+        elif bfuns[b][0] == KIND_HF:
+            row = mono_row(bfuns[b][1]) * dp_hf_value(bfuns[b][1])
+            for j in range(PH + 1):
+                if row[j] != 0.0:
+                    fold_slots[hc0 + j].append((gci, dp_const(float(row[j]))))
+        else:
+            row = mono_row(bfuns[b][1])
+            for j in range(PP + 1):
+                if row[j] != 0.0:
+                    fold_slots[hp0 + j].append((gci, dp_const(float(row[j]))))
+    ints = [len(cols), len(used), len(prods), len(a_nm), len(a_mon), off_x, urow_first if urow_first is not None else 0, PH | (PP << 8)]
+    for c in cols:
+        mine = [u for u in used if u[0] == c]
+        ints += [c, sum(1 for u in mine if u[1] == 0), sum(1 for u in mine if u[1] == 1), 0]
+    for key in prods:
+        ints += list(key) + [XR_ONE] * (4 - len(key))
+    ints += a_nm + [0] * ((-len(a_nm)) % 4)
+    ints += a_mon + [0] * ((-len(a_mon)) % 4)
+    for r in trec:
+        ints += r
+    return dict(ints=ints, n_sum=n_sum, n_u=len(used), n_prod=len(prods), n_var=len(cols))
+
+
 PLAN_WAYS = 4            # TTM_PLAN_WAYS
 PLAN_HF, PLAN_XHIT, PLAN_EHIT, PLAN_E = 1, 2, 4, 1 << 30
 FD_LEN, FD_KC_SLOT = 16, 13
@@ -407,6 +530,15 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
                 dp_local.append(('hf', hf_constant(polyclass, order)))
             return dp_index[key]
 
+        def dp_const(value, force_new=False):
+            key = ('const', value)
+            if force_new or key not in dp_index:
+                if not force_new:
+                    dp_index[key] = len(dp_local)
+                dp_local.append(('hf', value))
+                return len(dp_local) - 1
+            return dp_index[key]
+
         def dp_st(f):
             key = ('st', f[3], f[2], f[4])
             if key not in dp_index:
@@ -533,6 +665,12 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
                 fold_slots[rec] = trivial_src
                 for j_, which in enumerate((0, 2, 3, 4)):
                     fold_slots[rec + 1 + j_] = [(-1, p0 + which)]
+        # ---- X program (include/ttm.h): every factor value on another column once per sample, the monomial form of g and
+        # the nonmonotone sum from folded matrices (their recipe joins the fold recipe), every objective / gradient sum a
+        # product of two row entries
+        poly_b_x = (not separable and len(b_st) == 0 and len(b_hf) + len(b_poly) > 0)
+        xprog = _x_program(terms, facs, bfuns, len(nm_terms), kc, polyclass, dp_const,
+                           lambda order: hf_constant(polyclass, order), fold_slots) if poly_b_x else None
         fslots, fsrc = [], []
         for sl in fold_slots:
             fslots.append([len(fsrc), len(sl)])
@@ -574,7 +712,9 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         off_gen = off_grp + 4 * len(groups)
         off_mnt = off_gen + len(gen_idx)
         off_xgrp = off_mnt + len(mnt_idx)
-        blk_len = off_xgrp + 8 * len(xgroups)
+        xpad = (-(off_xgrp + 8 * len(xgroups))) % 4         # (records of four int32: 16-byte aligned within the block)
+        off_xprog = off_xgrp + 8 * len(xgroups) + xpad
+        blk_len = off_xprog + (len(xprog['ints']) if xprog else 0)
         off_fslot = 0                                       # fold recipes live in a separate table (ftab):
         off_fsrc = 2 * len(fslots)                          # they are read once at staging, not kept in LDS
         pad = (-blk_len) % 4                               # keep every block 16-byte aligned
@@ -596,8 +736,13 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         hdr[HDR_N_XGRP], hdr[HDR_OFF_XGRP] = len(xgroups), off_xgrp
         hdr[HDR_N_FOLD], hdr[HDR_OFF_FSLOT], hdr[HDR_OFF_FSRC] = len(fslots), off_fslot, off_fsrc
         hdr[HDR_OFF_WB] = off_wb
+        if xprog:
+            hdr[HDR_OFF_XPROG] = off_xprog
+            hdr[HDR_X_NROW] = XR_U + xprog['n_u'] + xprog['n_prod']            # row columns in front of the q columns
+            hdr[HDR_X_NSUM] = xprog['n_sum']
         block = (hdr + [v for t in terms for v in t] + [v for f in facs for v in f] + [v for b in bfuns for v in b] +
-                 [v for g in groups for v in g] + gen_idx + mnt_idx + [v for g in xgroups for v in g] + [0] * pad)
+                 [v for g in groups for v in g] + gen_idx + mnt_idx + [v for g in xgroups for v in g] + [0] * xpad +
+                 (xprog['ints'] if xprog else []) + [0] * pad)
         assert len(block) == blk_len
         fold_off.append(fold_off[-1] + fold_len)
         ftab.extend([v for sl in fslots for v in sl] + [v for e in fsrc for v in e])
@@ -621,7 +766,10 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
         # integrated kernels of csrc/ttm_int.hip are instantiated per order class)
         # (bit 3: the component has special terms somewhere - a kernel without any needs no erf table in LDS)
         has_st = any(f[0] == 'st' for t in list(nm_terms) + list(mon_terms) for f in t)
-        complex_all.append(int(complex_comp) | (2 if dense_b else 0) | (4 if poly_b else 0) | (8 if has_st else 0) |
+        # (bit 4: the component has an X program)
+        complex_all.append(int(complex_comp) | (2 if dense_b else 0) | (4 if poly_b else 0) | (8 if has_st else 0) | (16 if xprog else 0) |
+                           (((XR_U + xprog['n_u'] + xprog['n_prod']) << 16) if xprog else 0) |   # (bits 16-23: row columns in front of the q columns)
+                           ((((xprog['n_sum'] + 63) // 64) << 24) if xprog else 0) |             # (bits 24-25: sums of an evaluation / 64, rounded up)
                            (min(int(hdr[HDR_MAXP_HF]), 15) << 8) | (min(int(hdr[HDR_MAXP_POLY]), 15) << 12))
         nb1.append(len(bfuns) + 1)
         n_nm_all.append(len(nm_terms))

@@ -70,6 +70,8 @@ def _parallel_copy(dst, src, threads=8):
     list(_COPY_POOL.map(lambda r0: np.copyto(dst[r0:r0 + step], src[r0:r0 + step]), range(0, n, step)))
 
 
+HOSTCOEF_MAX = 128           # coefficients of a component that travel as kernel arguments (csrc/ttm_dev.h: TTM_HOSTCOEF_MAX)
+
 class transport_map():
 
     # the device the class allocates on; tests that inject the host test double
@@ -1315,7 +1317,7 @@ class transport_map():
                                               else int(self._cm.n_nm[k]))
         work = self._workspace(self._lib.ttm_reduce_work_size(nout))
         coef_k = np.ascontiguousarray(coef_k, dtype=float)
-        if self._dist() is None and len(coef_k) <= 64:
+        if self._dist() is None and len(coef_k) <= HOSTCOEF_MAX:
             # host-driven optimiser: coefficients as kernel arguments, result written to pinned host memory,
             # one stream synchronisation per evaluation (no H2D / D2H copies, two launches)
             torch = _torch()
@@ -1339,7 +1341,7 @@ class transport_map():
             work = self._workspace(self._lib.ttm_reduce_work_size(nout))
         if getattr(self, '_obj_out', None) is None:
             pin = self._dev.type == 'cuda'
-            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
+            self._obj_out = torch.zeros(256, dtype=torch.float64, pin_memory=pin)
             self._obj_cnt = self._zeros(16, dtype=torch.int32)
         _capi.check(self._lib.ttm_objective_host(self._pp, int(k), ctypes.c_void_p(coef_k.ctypes.data), self._ptr(self._Xs),
                                                  self._Xs.shape[1], self._N, self._ptr(work),
@@ -1523,7 +1525,7 @@ class transport_map():
                                         dpsi.shape[1], self._stream()))
         if getattr(self, '_obj_out', None) is None:
             pin = self._dev.type == 'cuda'
-            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=pin)
+            self._obj_out = torch.zeros(256, dtype=torch.float64, pin_memory=pin)
             self._obj_cnt = self._zeros(16, dtype=torch.int32)
         self._sep_cache = (int(k), dpsi)
 
@@ -1965,12 +1967,12 @@ class transport_map():
         n = len(K)
         sizes = [len(self.coeffs_nonmon[k]) + len(self.coeffs_mon[k]) for k in K]
         pens = [self._penalty_vector(k, m) for k, m in zip(K, sizes)]
-        if any(m < 1 or m > 64 for m in sizes) or any(p is None for p in pens):
+        if any(m < 1 or m > HOSTCOEF_MAX for m in sizes) or any(p is None for p in pens):
             return None
         wsz = int(self._lib.ttm_reduce_work_size(1 + max(sizes)))
         work = self._empty(n * wsz)
         counters = self._zeros(n * 16, dtype=torch.int32)
-        sums = torch.zeros(n * 128, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+        sums = torch.zeros(n * 256, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
         tasks = (_capi.ttm_int_task * n)()
         xs = []
         for i, (k, m, (kind, lam)) in enumerate(zip(K, sizes, pens)):
@@ -1982,7 +1984,7 @@ class transport_map():
             t.x = x.ctypes.data
             t.work = work.data_ptr() + 8 * i * wsz
             t.counter = counters.data_ptr() + 4 * 16 * i
-            t.sums_host = sums.data_ptr() + 8 * 128 * i
+            t.sums_host = sums.data_ptr() + 8 * 256 * i
         _capi.check(self._lib.ttm_optimize_integrated_batch(self._pp, tasks, n, self._ptr(self._Xs), self._Xs.shape[1], self._N,
                                                             float(self._Nglobal), int(min(self.optimizer_threads, n)),
                                                             self._stream(), 0))
@@ -1999,10 +2001,10 @@ class transport_map():
 
     def _optimize_integrated_native(self, k, x0, div):
         """TM:3252-3257 for one component without leaving the library (ttm_optimize_integrated: SciPy's BFGS restated
-        over ttm_objective_host); None when the native loop does not apply (more than 64 coefficients, a penalty it
+        over ttm_objective_host); None when the native loop does not apply (more than 128 coefficients, a penalty it
         does not know, ranks that share samples without an RCCL / test-double communicator)."""
         m = len(x0)
-        if not self.native_optimizer or m > 64:
+        if not self.native_optimizer or m > HOSTCOEF_MAX:
             return None
         pen = self._penalty_vector(k, m)
         if pen is None:
@@ -2015,7 +2017,7 @@ class transport_map():
                 return None
         torch = _torch()
         if getattr(self, '_obj_out', None) is None:
-            self._obj_out = torch.zeros(128, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            self._obj_out = torch.zeros(256, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
             self._obj_cnt = self._zeros(16, dtype=torch.int32)
         x = np.array(x0, dtype=float, copy=True)
         work = self._workspace(self._lib.ttm_reduce_work_size(1 + m))
