@@ -86,6 +86,14 @@ bool int_dense(const ttm_program* p, int ka, int kb, DenseClass& cls) {
     return dense_range_class(p->h_complex, ka, kb, cls);
 }
 
+// same dispatch rule as the library (csrc/ttm_int.hip: xprog_rows): the X-program kernels when every component of the range has one
+bool all_xprog(const ttm_program* p, int ka, int kb) {
+    if (getenv("TTM_INT_XPROG") && atoi(getenv("TTM_INT_XPROG")) == 0) return false;
+    for (int k = ka; k < kb; ++k)
+        if (!(p->h_complex[k] & 16)) return false;
+    return true;
+}
+
 // same dispatch rule as the library: planned-cache fast path when every component of the range is simple
 bool all_fast(const ttm_program* p, int ka, int kb) {
     if (getenv("TTM_NO_PLAN")) return false;
@@ -398,6 +406,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         std::vector<HostComp> hc(k1 - k0);
         for (int k = k0; k < k1; ++k) comp_of(p, k, coef + p->h_coef_off[k], hc[k - k0], fold + p->h_fold_off[k]);
         const double qws = dense_qw_sum(g);
+        const bool xall = all_xprog(p, k0, k1);
         for (int64_t n = 0; n < N; ++n) {
             XSoA xa{X, ldx, n};
             double cbuf[8]; VarCache<XSoA, double> x(xa, CacheStore<double>{cbuf, 1});
@@ -406,6 +415,18 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                 const Comp& c = hc[k - k0].c;
                 VecSlots w{scr.data()};
                 double S = 0.0, dS = 0.0;
+                if (xall) {
+                    XProg xp;
+                    xprog_view(p->itab + p->h_comp_off[k], p->dpar + p->h_dpar_off[k], xp);
+                    const double* fx = c.fold + xp.fold_x;
+#define TTM_CALL(PH, PP, RECT)                                                                                  \
+    do {                                                                                                        \
+        if (logdet) xprog_sample_forward<PH, PP, RECT, true>(xp, g, qws, fx, xa, w, Z || sumsq, S, dS);          \
+        else xprog_sample_forward<PH, PP, RECT, false>(xp, g, qws, fx, xa, w, true, S, dS);                      \
+    } while (0)
+                    TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+                } else {
 #define TTM_CALL(PH, PP, RECT)                                                                                  \
     do {                                                                                                        \
         if (logdet) dense_sample_forward<PH, PP, RECT, true>(c, g, qws, x, w, Z || sumsq, S, dS);               \
@@ -413,6 +434,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
     } while (0)
                 TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
 #undef TTM_CALL
+                }
                 if (logdet) ld += fast_log(sigma ? fast_div(dS, sigma[k - k0]) : dS);
                 if (Z) Z[(int64_t)(k - k0) * ldz + n] = S;
                 ss = fma(S, S, ss);
@@ -891,9 +913,21 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
         for (int k = k0; k < k1; ++k) {
             const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
-            const double off = nonmon_sum<double>(c, g, x);
             int it = 0;
             double r = 0.0;
+            if (dense && all_xprog(p, k0, k1) && getenv("TTM_INT_XPROG") && atoi(getenv("TTM_INT_XPROG")) == 2) {
+                XProg xp;
+                xprog_view(p->itab + p->h_comp_off[k], p->dpar + p->h_dpar_off[k], xp);
+                const double* fx = c.fold + xp.fold_x;
+#define TTM_CALL(PH, PP, RECT) r = xprog_sample_root<PH, PP, RECT, false>(xp, g, qws, fx, xa, w, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it)
+                TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+                X[(int64_t)c.kc * ldx + n] = r;
+                x.put(c.kc, r);
+                if (it > iters[k - k0]) iters[k - k0] = it;
+                continue;
+            }
+            const double off = nonmon_sum<double>(c, g, x);
             if (dense) {
 #define TTM_CALL(PH, PP, RECT) r = dense_sample_root<PH, PP, RECT, false>(c, g, qws, x, w, off, Z[(int64_t)(k - k0) * ldz + n], cap ? cap[k - k0] : -1, it)
                 TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
@@ -924,9 +958,21 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
         for (int k = k0; k < k1; ++k) {
             const Comp& c = hc[k - k0].c;
             VecSlots w{scr.data()};
-            const double off = nonmon_sum<double>(c, g, x);
             int it = 0;
             double r = 0.0;
+            if (dense && all_xprog(p, k0, k1) && getenv("TTM_INT_XPROG") && atoi(getenv("TTM_INT_XPROG")) == 2) {
+                XProg xp;
+                xprog_view(p->itab + p->h_comp_off[k], p->dpar + p->h_dpar_off[k], xp);
+                const double* fx = c.fold + xp.fold_x;
+#define TTM_CALL(PH, PP, RECT) r = xprog_sample_root<PH, PP, RECT, true>(xp, g, qws, fx, xa, w, Z[(int64_t)(k - k0) * ldz + n], -1, it)
+                TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);
+#undef TTM_CALL
+                X[(int64_t)c.kc * ldx + n] = r;
+                x.put(c.kc, r);
+                if (it > iters[k - k0]) iters[k - k0] = it;
+                continue;
+            }
+            const double off = nonmon_sum<double>(c, g, x);
             if (dense) {
 #define TTM_CALL(PH, PP, RECT) r = dense_sample_root<PH, PP, RECT, true>(c, g, qws, x, w, off, Z[(int64_t)(k - k0) * ldz + n], -1, it)
                 TTM_DENSE_DISPATCH(TTM_CALL, dcls, p->rectifier);

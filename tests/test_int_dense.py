@@ -157,35 +157,81 @@ def test_example01_order10_map_takes_the_dense_kernels(backend):
         check('dense/gradient_vs_generic[ex01_order10]', relerr(G, Gg), 1e-11, backend)
 
 
-def test_x_program_and_fold_recipe_walk_agree(backend):
-    """The objective / gradient sums through the component's X program (csrc/ttm_xprog.h) against the kernel that walks the
-    fold recipe (option int_xprog = 0), every integrated fixture, every component."""
-    for name in DENSE:
-        npz, desc = load_case(name)
-        tm = make_tm(name, npz, desc)
+class walk_path:
+    """int_xprog = 0 for the duration of the block: the kernels that walk the term tables per sample."""
+    def __init__(self, tm, backend):
+        self.tm, self.backend = tm, backend
+
+    def __enter__(self):
+        if self.backend == 'hip':
+            self.tm._lib.ttm_set_option(b'int_xprog', 0)
+        else:
+            os.environ['TTM_INT_XPROG'] = '0'
+
+    def __exit__(self, *exc):
+        if self.backend == 'hip':
+            self.tm._lib.ttm_reset_options()
+        else:
+            del os.environ['TTM_INT_XPROG']
+
+
+@pytest.mark.parametrize('name', DENSE + ['ex01_order10'])
+def test_x_program_and_term_table_walk_agree(backend, name):
+    """Everything that goes through the components' X programs (csrc/ttm_xprog.h: forward map, bisection and Newton root
+    searches, objective / gradient sums) against the kernels that walk the term tables per sample (option int_xprog = 0)."""
+    npz, desc = load_case(name)
+    if name == 'ex01_order10':
+        from tests.test_transport_map import make_tm as make_any
+        tm = make_any(name, npz, desc)
+        tm.alternate_root_finding = False
+        X = npz['X_head']
+    else:
+        tm = make_tm(name, npz, desc, alternate_root_finding=False)
+        X = case_X(name, npz)[:npz['Z'].shape[0]]
+    assert all(int(f) & 16 for f in tm._cm.complex), 'fixture should have X programs'
+    Zin = npz['inv_Z'] if 'inv_Z' in npz else np.random.default_rng(5).standard_normal((64, tm.D))
+
+    def everything(names):
+        out = {'Z': tm.map(X)}
+        if backend == 'hip':
+            Zs = tm.forward_device(tm._Xs, tm._N)
+            assert last_kernel(tm) == names[0]
+            tm.inverse_device(Zs, tm._N, table=False)
+            assert last_kernel(tm) == names[1]
+        out['Xi'] = tm.inverse_map(Zin)
+        tm.root_finder = 'newton'
+        out['Xn'] = tm.inverse_map(Zin)
+        tm.root_finder = 'reference'
+        out['J'], out['G'] = [], []
         for k in range(tm.D):
             div = len(tm.coeffs_nonmon[k])
             c = np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k])) * 0.97 + 0.005
             tm._obj_cache = None
-            J, G = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
-            if backend == 'hip':
+            out['J'].append(tm.objective_function(c, k, div))
+            out['G'].append(tm.objective_function_jacobian(c, k, div))
+            if backend == 'hip' and len(c) <= 128:
                 tm._device_sums(k, c)
-                assert last_kernel(tm) == 'k_int_objective'
-                tm._lib.ttm_set_option(b'int_xprog', 0)
-            else:
-                os.environ['TTM_INT_XPROG'] = '0'
-            try:
-                tm._obj_cache = None
-                Jw, Gw = tm.objective_function(c, k, div), tm.objective_function_jacobian(c, k, div)
-                if backend == 'hip':
-                    tm._device_sums(k, c)
-                    assert last_kernel(tm) == 'k_int_objective_walk'
-            finally:
-                if backend == 'hip':
-                    tm._lib.ttm_reset_options()
-                else:
-                    del os.environ['TTM_INT_XPROG']
-            with np.errstate(all='ignore'):
-                scale = 1.0 + np.abs(Gw)
-                check('xprog/objective_vs_walk[%s]' % name, abs(J - Jw) / (1 + abs(Jw)), 1e-12, backend)
-                check('xprog/gradient_vs_walk[%s]' % name, float(np.max(np.abs(G - Gw) / scale)), 1e-11, backend)
+                assert last_kernel(tm) == names[2]
+        return out
+    if backend == 'hip':
+        tm._lib.ttm_set_option(b'int_xprog', 2)          # (the root searches through the X programs as well: off by default)
+    else:
+        os.environ['TTM_INT_XPROG'] = '2'
+    try:
+        a = everything(('k_int_forward', 'k_int_root_x<bisect>', 'k_int_objective'))
+    finally:
+        if backend == 'hip':
+            tm._lib.ttm_reset_options()
+        else:
+            del os.environ['TTM_INT_XPROG']
+    with walk_path(tm, backend):
+        b = everything(('k_int_forward<walk>', 'k_int_root<bisect>', 'k_int_objective_walk'))
+    with np.errstate(all='ignore'):
+        check('xprog/map_vs_walk[%s]' % name, relerr(a['Z'], b['Z']), 1e-12, backend)
+        ok = np.all(np.isfinite(b['Xi']), axis=1) & np.all(np.isfinite(b['Xn']), axis=1)
+        assert np.array_equal(np.all(np.isfinite(a['Xi']), axis=1) & np.all(np.isfinite(a['Xn']), axis=1), ok)
+        check('xprog/bisection_vs_walk[%s]' % name, relerr(a['Xi'][ok], b['Xi'][ok]), 1e-7, backend)
+        check('xprog/newton_vs_walk[%s]' % name, relerr(a['Xn'][ok], b['Xn'][ok]), 1e-7, backend)
+        for k in range(tm.D):
+            check('xprog/objective_vs_walk[%s]' % name, abs(a['J'][k] - b['J'][k]) / (1 + abs(b['J'][k])), 1e-12, backend)
+            check('xprog/gradient_vs_walk[%s]' % name, float(np.max(np.abs(a['G'][k] - b['G'][k]) / (1.0 + np.abs(b['G'][k])))), 1e-11, backend)

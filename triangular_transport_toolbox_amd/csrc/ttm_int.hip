@@ -157,6 +157,86 @@ __global__ __launch_bounds__(256) void k_int_objective_walk(DevProg P, int k, co
     }
 }
 
+// ---- forward map and root searches through the X programs (csrc/ttm_xprog.h): every component of the launch has one ---------
+// k_int_forward / k_int_root with the term-table walks of a sample (weights of the B functions, their conversion to monomial
+// coefficients, nonmonotone groups: 620 of the 1 780 vector instructions of an evaluation at C2a, 0.5-0.7 scalar instructions
+// per vector instruction) replaced by the sample's row: factor values once, the monomial form of g and the nonmonotone sum
+// as products with the fold's X section (scalar loads from the fold buffer at addresses known from the component's header).
+// LDS: one row per thread, column-major over the workgroup (nrow x blockDim doubles); columns come from global memory
+// (a column is read by at most a few components: L2 hits; the kernels are FP64-bound).
+template <int PH, int PP, int RECT, bool WANT_LD>
+__global__ __launch_bounds__(256) void k_int_forward_x(DevProg P, int kfirst, int klast, int chunk, const double* __restrict__ fold,
+                                                       const double* __restrict__ X, int64_t ldx, int64_t N, double* __restrict__ Z,
+                                                       int64_t ldz, double* __restrict__ logdet, const double* __restrict__ sigma,
+                                                       double* __restrict__ sumsq) {
+    const int k0 = kfirst + (int)blockIdx.y * chunk;
+    const int k1 = (k0 + chunk < klast) ? k0 + chunk : klast;
+    const int bd = blockDim.x;
+    LdsSlots row{g_smem + threadIdx.x, bd};
+    Prog g;
+    g.qx = (cdbl_p)P.qx; g.qw = (cdbl_p)P.qw; g.erf_tab = nullptr; g.Q = P.Q; g.family = P.family; g.mono = P.mono; g.rect = P.rect;
+    g.delta = P.delta;
+    const bool want_val = (Z != nullptr) || (sumsq != nullptr);
+    const double qws = dense_qw_sum(g);
+    cint_p off = (cint_p)P.off;
+    const int D1 = P.D + 1;
+    for (int64_t n0 = (int64_t)blockIdx.x * bd; n0 < N; n0 += (int64_t)gridDim.x * bd) {
+        const int64_t n = n0 + threadIdx.x;
+        const bool active = n < N;
+        const XSoA xa{X, ldx, active ? n : N - 1};
+        double ld = 0.0, ss = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            XProg xp;
+            xprog_view((cint_p)P.itab + off[k], (cdbl_p)P.dpar + off[D1 + k], xp);
+            cdbl_p fx = (cdbl_p)fold + off[3 * D1 + k] + xp.fold_x;            // (fold: the folded coefficients of the WHOLE map)
+            double S, dS;
+            xprog_sample_forward<PH, PP, RECT, WANT_LD>(xp, g, qws, fx, xa, row, WANT_LD ? want_val : true, S, dS);
+            if (WANT_LD) ld += fast_log(sigma ? fast_div(dS, ((cdbl_p)sigma)[k - kfirst]) : dS);
+            if (Z && active) Z[(int64_t)(k - kfirst) * ldz + n] = S;
+            ss = fma(S, S, ss);
+        }
+        if (active) {
+            if (WANT_LD) logdet[n] = ld;
+            if (sumsq) sumsq[n] = ss;
+        }
+    }
+}
+
+template <int PH, int PP, int RECT, bool NEWTON>
+__global__ __launch_bounds__(256) void k_int_root_x(DevProg P, int k0, int k1, const double* __restrict__ fold, const double* __restrict__ Z,
+                                                    int64_t ldz, double* X, int64_t ldx, int64_t N, int* __restrict__ iters,
+                                                    const int* __restrict__ cap) {
+    LdsSlots row{g_smem + threadIdx.x, (int)blockDim.x};
+    Prog g;
+    g.qx = (cdbl_p)P.qx; g.qw = (cdbl_p)P.qw; g.erf_tab = nullptr; g.Q = P.Q; g.family = P.family; g.mono = P.mono; g.rect = P.rect;
+    g.delta = P.delta;
+    const double qws = dense_qw_sum(g);
+    cint_p off = (cint_p)P.off;
+    const int D1 = P.D + 1;
+    for (int64_t n0 = (int64_t)blockIdx.x * blockDim.x; n0 < N; n0 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = n0 + threadIdx.x;
+        const bool active = n < N;
+        // (columns of the components solved so far are read back from X: this lane wrote them itself)
+        const XSoA xa{X, ldx, active ? n : 0};
+        for (int k = k0; k < k1; ++k) {
+            XProg xp;
+            xprog_view((cint_p)P.itab + off[k], (cdbl_p)P.dpar + off[D1 + k], xp);
+            cdbl_p fx = (cdbl_p)fold + off[3 * D1 + k] + xp.fold_x;            // (fold: the folded coefficients of the WHOLE map)
+            int it = 0;
+            if (active) {
+                const int capk = cap ? cap[k - k0] : -1;
+                const double zk = Z[(int64_t)(k - k0) * ldz + n];
+                const double r = xprog_sample_root<PH, PP, RECT, NEWTON>(xp, g, qws, fx, xa, row, zk, capk, it);
+                X[(int64_t)xp.kc * ldx + n] = r;
+            }
+            // wave-level max, one atomic per wave (the sample-0 guard of the reference's loop needs the largest count)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) it = max(it, __shfl_down(it, o, 64));
+            if ((threadIdx.x & 63) == 0 && it > 0) atomicMax(&iters[k - k0], it);
+        }
+    }
+}
+
 // ---- objective + gradient sums through the X program (csrc/ttm_xprog.h) ---------------------------------------------------
 // LDS: [coefficients (TTM_HOSTCOEF_MAX) | the component's fold (nfold) | per wave: rows of its 64 samples, COLUMN-major with a
 // column stride of XOBJ_CS = 65 doubles | per wave XOBJ_SUMS running totals].  Column-major: in the per-sample phase the
@@ -311,6 +391,17 @@ static int needs_erf(const ttm_program* p, int k0, int k1) {
     return 0;
 }
 
+// row columns the X-program kernels need for the components [k0, k1): 0 when one of them has no X program
+static int xprog_rows(const ttm_program* p, int k0, int k1) {
+    int rows = 0;
+    for (int k = k0; k < k1; ++k) {
+        if (!(p->h_complex[k] & 16)) return 0;
+        const int r = (p->h_complex[k] >> 16) & 255;
+        rows = r > rows ? r : rows;
+    }
+    return rows;
+}
+
 bool usable(const ttm_program* p, int k0, int k1) {
     if (!p || p->monotonicity != TTM_MONO_INTEGRATED || p->family < 0 || p->family > 5) return false;
     DenseClass cls;
@@ -319,12 +410,27 @@ bool usable(const ttm_program* p, int k0, int k1) {
 
 int forward(const ttm_program* p, const DevProg& P, int k0, int k1, const double* coef, const double* fold, const double* Xsoa,
             int64_t ldx, int64_t N, double* Zsoa, int64_t ldz, double* logdet, const double* sigma, double* sumsq, int grid,
-            int chunk, int bd, size_t lds, void* stream, const char** kernel_name) {
+            int chunk, int bd, size_t lds, int use_x, void* stream, const char** kernel_name) {
     DenseClass cls;
     if (!dense_range_class(p->h_complex, k0, k1, cls)) return TTM_E_UNSUPPORTED;
     if (chunk < 1 || logdet || sumsq) chunk = k1 - k0;
     const int erf = needs_erf(p, k0, k1);
     const dim3 g3(grid, (k1 - k0 + chunk - 1) / chunk);
+    const int xrows = use_x ? xprog_rows(p, k0, k1) : 0;
+    if (xrows > 0 && (size_t)xrows * bd * sizeof(double) <= 64 * 1024) {
+        const size_t xlds = (size_t)xrows * bd * sizeof(double);
+#define TTM_CALL(PH, PP, RECT)                                                                                              \
+    do {                                                                                                                    \
+        if (logdet) hipLaunchKernelGGL((k_int_forward_x<PH, PP, RECT, true>), g3, dim3(bd), xlds, (hipStream_t)stream, P, k0, \
+                                       k1, chunk, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);                      \
+        else hipLaunchKernelGGL((k_int_forward_x<PH, PP, RECT, false>), g3, dim3(bd), xlds, (hipStream_t)stream, P, k0, k1,  \
+                                chunk, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq);                                 \
+    } while (0)
+        TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
+#undef TTM_CALL
+        *kernel_name = "k_int_forward";
+        return TTM_OK;
+    }
 #define TTM_CALL(PH, PP, RECT)                                                                                              \
     do {                                                                                                                    \
         if (logdet) hipLaunchKernelGGL((k_int_forward<PH, PP, RECT, true>), g3, dim3(bd), lds, (hipStream_t)stream, P, k0,  \
@@ -334,16 +440,31 @@ int forward(const ttm_program* p, const DevProg& P, int k0, int k1, const double
     } while (0)
     TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
 #undef TTM_CALL
-    *kernel_name = "k_int_forward";
+    *kernel_name = "k_int_forward<walk>";
     return TTM_OK;
 }
 
 int root(const ttm_program* p, const DevProg& P, int k0, int k1, const double* coef, const double* fold, const double* Zsoa,
          int64_t ldz, double* Xsoa, int64_t ldx, int64_t N, int32_t* iters, const int32_t* cap, int newton, int grid, int bd,
-         size_t lds, void* stream, const char** kernel_name) {
+         size_t lds, int use_x, void* stream, const char** kernel_name) {
     DenseClass cls;
     if (!dense_range_class(p->h_complex, k0, k1, cls)) return TTM_E_UNSUPPORTED;
     const int erf = needs_erf(p, k0, k1);
+    const int xrows = use_x ? xprog_rows(p, k0, k1) : 0;
+    if (xrows > 0 && (size_t)xrows * bd * sizeof(double) <= 64 * 1024) {
+        const size_t xlds = (size_t)xrows * bd * sizeof(double);
+#define TTM_CALL(PH, PP, RECT)                                                                                              \
+    do {                                                                                                                    \
+        if (newton) hipLaunchKernelGGL((k_int_root_x<PH, PP, RECT, true>), dim3(grid), dim3(bd), xlds, (hipStream_t)stream, P, k0, k1, \
+                                       fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);                        \
+        else hipLaunchKernelGGL((k_int_root_x<PH, PP, RECT, false>), dim3(grid), dim3(bd), xlds, (hipStream_t)stream, P, k0, k1,      \
+                                fold, Zsoa, ldz, Xsoa, ldx, N, (int*)iters, (const int*)cap);                               \
+    } while (0)
+        TTM_DENSE_DISPATCH(TTM_CALL, cls, p->rectifier);
+#undef TTM_CALL
+        *kernel_name = newton ? "k_int_root_x<newton>" : "k_int_root_x<bisect>";
+        return TTM_OK;
+    }
 #define TTM_CALL(PH, PP, RECT)                                                                                              \
     do {                                                                                                                    \
         if (newton) hipLaunchKernelGGL((k_int_root<PH, PP, RECT, true>), dim3(grid), dim3(bd), lds, (hipStream_t)stream, P, k0, k1, \

@@ -2438,7 +2438,8 @@ static const DeviceInfo& device_info() {
     X(band_cus, -1)      /* > 0: the band kernels plan their row chunks for this many CUs (tests: several tiles per chunk) */ \
     X(band_ring, -1)     /* 0: banded table inverse through k_band_inverse (tables assembled per block) although images are at hand */ \
     X(int_dense, -1)     /* 0: integrated maps with dense B sets through the generic kernels instead of csrc/ttm_int.hip */ \
-    X(int_xprog, -1)     /* 0: objective / gradient sums of integrated components without their X programs (csrc/ttm_xprog.h) */ \
+    X(int_xprog, -1)     /* 0: integrated components without their X programs (csrc/ttm_xprog.h: forward map, objective / gradient sums); \
+                            2: the root searches through them as well (measured: the weights are 1 % of a bisection - no gain, 5 % slower at C2a) */ \
     X(int_wgs, -1)       /* > 0: workgroups per CU of the dense integrated kernels (default: one workgroup per tile of samples) */ \
     X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
     X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
@@ -2781,7 +2782,7 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
         if (nchunk < 1) nchunk = 1;
         const int chunk = (k1 - k0 + nchunk - 1) / nchunk;
         if (ibd && ttm_int::forward(p, dev_prog(p), k0, k1, coef, fold, Xsoa, ldx, N, Zsoa, ldz, logdet, sigma, sumsq, tiles, chunk, ibd,
-                                    lds_bytes(nsl, ibd, 0, 1), stream, &name) == TTM_OK)
+                                    lds_bytes(nsl, ibd, 0, 1), tuning().int_xprog != 0, stream, &name) == TTM_OK)
             return check_launch(name);
     }
     if (sep && u_on(p) && all_fast(p, k0, k1) && N < ((int64_t)1 << 29)) {
@@ -3230,7 +3231,7 @@ int ttm_inverse_bisect(const ttm_program* p, const double* coef, const double* f
     if (tuning().int_dense != 0 && ttm_int::usable(p, k0, k1)) {
         const char* name = nullptr;
         if (ttm_int::root(p, dev_prog(p), k0, k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, cap, 0, int_grid_for(N, bd), bd, lds_bytes(ns, bd, 0),
-                          stream, &name) == TTM_OK)
+                          tuning().int_xprog == 2, stream, &name) == TTM_OK)
             return check_launch(name);
     }
     auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, false> : k_inverse_bisect<TTM_MONO_INTEGRATED, false>;
@@ -3250,7 +3251,7 @@ int ttm_inverse_newton(const ttm_program* p, const double* coef, const double* f
     if (tuning().int_dense != 0 && ttm_int::usable(p, k0, k1)) {
         const char* name = nullptr;
         if (ttm_int::root(p, dev_prog(p), k0, k1, coef, fold, Zsoa, ldz, Xsoa, ldx, N, iters, nullptr, 1, int_grid_for(N, bd), bd, lds_bytes(ns, bd, 0),
-                          stream, &name) == TTM_OK)
+                          tuning().int_xprog == 2, stream, &name) == TTM_OK)
             return check_launch(name);
     }
     auto kern = p->monotonicity == TTM_MONO_SEPARABLE ? k_inverse_bisect<TTM_MONO_SEPARABLE, true> : k_inverse_bisect<TTM_MONO_INTEGRATED, true>;

@@ -133,6 +133,39 @@ TTM_HD void xprog_mono(const XProg& xp, FP fx, const Row& row, DenseMono<PH, PP>
     d.probe = t * 0.0;
 }
 
+// S_k(x) and dS_k/dx_k of one sample (TM:2499-2547) through the X program: dense_sample_forward of ttm_dense.h with the term-table
+// walks (weights of the B functions, their conversion to monomials, nonmonotone groups) replaced by the row
+template <int PH, int PP, int RECT, bool DER, class FP, class XA, class Row>
+TTM_HD void xprog_sample_forward(const XProg& xp, const Prog& p, double qw_sum, FP fx, const XA& xa, Row& row, bool want_value,
+                                 double& S, double& dS) {
+    constexpr int PM = PH > PP ? PH : PP;
+    xprog_values<PM>(xp, xa, row);
+    DenseMonoSet<PH, PP, RECT> s;
+    double s_nm;
+    xprog_mono<PH, PP>(xp, fx, row, s.d, s_nm);
+    s.qw_sum = qw_sum;
+    const double xk = xa(xp.kc);
+    double m, dm;
+    Comp unused;                                            // (mon_eval of a DenseMonoSet reads nothing of the component)
+    mon_eval<TTM_MONO_INTEGRATED, DER>(unused, p, xk, s, m, dm);
+    S = want_value ? s_nm + m : m;
+    dS = dm;
+}
+
+// bisection (the reference's sequence, TM:3842-3976) or safeguarded Newton root search of one sample through the X program;
+// xa: the sample's columns with the roots of the earlier components already in place
+template <int PH, int PP, int RECT, bool NEWTON, class FP, class XA, class Row>
+TTM_HD double xprog_sample_root(const XProg& xp, const Prog& p, double qw_sum, FP fx, const XA& xa, Row& row, double zk, int cap, int& it) {
+    constexpr int PM = PH > PP ? PH : PP;
+    xprog_values<PM>(xp, xa, row);
+    DenseMonoSet<PH, PP, RECT> s;
+    double off;
+    xprog_mono<PH, PP>(xp, fx, row, s.d, off);
+    s.qw_sum = qw_sum;
+    Comp unused;
+    return NEWTON ? sample_newton<TTM_MONO_INTEGRATED>(unused, p, off, zk, s, it) : sample_bisect<TTM_MONO_INTEGRATED>(unused, p, off, zk, s, cap, it);
+}
+
 #ifndef XOBJ_NODES
 #define XOBJ_NODES 4          /* nodes per pass of the objective's node loop: 115-123 vector registers (four waves per SIMD); 5: 125-134 */
 #endif
