@@ -19,7 +19,8 @@ from triangular_transport_toolbox_amd import _capi, termtable
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'ttm_hostemu.cpp')
-LIB = os.path.join(HERE, 'libttm_hostemu.so')
+# (TTM_HOSTEMU_LIB: a build of the test double made elsewhere - the sanitizer builds of tools/sanitize_hostemu.sh - used as it is)
+LIB = os.environ.get('TTM_HOSTEMU_LIB') or os.path.join(HERE, 'libttm_hostemu.so')
 CSRC = os.path.join(HERE, '..', '..', 'triangular_transport_toolbox_amd', 'csrc')
 DEPS = [SRC, os.path.join(CSRC, 'ttm_eval.h'), os.path.join(CSRC, 'ttm_math.h'), os.path.join(CSRC, 'ttm_vec.h'),
         os.path.join(CSRC, 'ttm_erf_table.h'), os.path.join(CSRC, 'ttm_dense.h'), os.path.join(CSRC, 'ttm_xprog.h'), os.path.join(CSRC, 'ttm_dense_table.h'), os.path.join(CSRC, 'ttm_uform.h'), os.path.join(CSRC, 'ttm_cheb_table.h'), os.path.join(CSRC, 'ttm_lbfgsb.h'), os.path.join(CSRC, 'ttm_bfgs.h'), os.path.join(CSRC, 'ttm_rng.h'), os.path.join(CSRC, 'ttm_optim.cpp'),
@@ -40,6 +41,8 @@ def _allreduce_cb(buf, count, is_f64, op):
 
 
 def build():
+    if os.environ.get('TTM_HOSTEMU_LIB'):
+        return LIB
     if os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in DEPS):
         return LIB
     tmp = '%s.tmp.%d' % (LIB, os.getpid())

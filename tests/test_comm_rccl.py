@@ -69,6 +69,21 @@ if handle is not None:                        # (an RCCL that accepts two ranks 
     rc = lib.ttm_allreduce_f64(handle, ctypes.c_void_p(x.data_ptr()), 5, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     out['sum'] = [rc] + x.cpu().tolist()
+    # the Gram-matrix size (m^2 = 400 doubles, SURVEY section 8a' C1) and the int32 maximum the bisection caps / the radix
+    # select's bin counts go through (ttm_allreduce_i32)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.arange(400, dtype=torch.float64, device='cuda') * (rank + 1)
+    rc = lib.ttm_allreduce_f64(handle, ctypes.c_void_p(g.data_ptr()), 400, 0, st)
+    torch.cuda.synchronize()
+    out['gram'] = [rc, float((g - 3.0 * torch.arange(400, dtype=torch.float64, device='cuda')).abs().max().item())]
+    it = torch.tensor([7 + rank, 3 - rank, 100 * rank], dtype=torch.int32, device='cuda')
+    rc = lib.ttm_allreduce_i32(handle, ctypes.c_void_p(it.data_ptr()), 3, 1, st)
+    torch.cuda.synchronize()
+    out['imax'] = [rc] + it.cpu().tolist()
+    cnt = torch.full((256,), rank + 1, dtype=torch.int32, device='cuda')
+    rc = lib.ttm_allreduce_i32(handle, ctypes.c_void_p(cnt.data_ptr()), 256, 0, st)
+    torch.cuda.synchronize()
+    out['isum'] = [rc, int(cnt.min().item()), int(cnt.max().item())]
 # whatever happened, both ranks are still in step: a collective over the control plane completes
 t = torch.tensor([rank + 1.0])
 dist.all_reduce(t)
@@ -111,6 +126,13 @@ def _run_two_ranks(tmp_path, extra_env):
     return res
 
 
+def _check_extras(res):
+    for r in res:
+        assert r['gram'] == [0, 0.0], r                        # 400 doubles summed over the two ranks
+        assert r['imax'] == [0, 8, 3, 100], r                  # int32 maximum
+        assert r['isum'] == [0, 3, 3], r                       # int32 sum (the radix select's bin counts)
+
+
 def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
     res = _run_two_ranks(tmp_path, {})
     print('communicator created:', res[0]['handle'], '|', res[0]['warned'])
@@ -118,6 +140,7 @@ def test_two_ranks_on_one_gpu_agree_on_the_fallback(tmp_path):
     assert res[0]['after'] == res[1]['after'] == 3.0            # and are still in step afterwards
     if res[0]['handle']:
         assert res[0]['sum'] == res[1]['sum'] == [0] + [3.0] * 5
+        _check_extras(res)
     else:
         assert all('communicator not available' in ' '.join(r['warned']) for r in res)
 
@@ -131,4 +154,5 @@ def test_two_ranks_on_two_gpus_reduce_over_rccl(tmp_path):
     res = _run_two_ranks(tmp_path, {'TTM_TEST_ONE_GPU_PER_RANK': '1'})
     assert res[0]['handle'] and res[1]['handle'], res
     assert res[0]['sum'] == res[1]['sum'] == [0] + [3.0] * 5
+    _check_extras(res)
     assert res[0]['after'] == res[1]['after'] == 3.0

@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIB = os.environ.get('TTM_BUILD_LIB') or os.path.join(PKG, 'libttm.so')
 SOURCES = ['ttm_kernels.hip', 'ttm_band.hip', 'ttm_int.hip', 'ttm_optim.cpp', 'ttm_comm.cpp']
 # what the translation units include (the depfile of the last build supersedes this list)
-HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', 'ttm_uform.h', 'ttm_cheb_table.h', 'ttm_lbfgsb.h', 'ttm_bfgs.h', 'ttm_rng.h', 'ttm_band.h', 'ttm_band_etab.h', 'ttm_dev.h', 'ttm_dense.h', 'ttm_dense_table.h', 'ttm_int.h',
+HEADERS = ['ttm_eval.h', 'ttm_math.h', 'ttm_vec.h', 'ttm_erf_table.h', 'ttm_uform.h', 'ttm_cheb_table.h', 'ttm_lbfgsb.h', 'ttm_bfgs.h', 'ttm_rng.h', 'ttm_band.h', 'ttm_band_etab.h', 'ttm_dev.h', 'ttm_dense.h', 'ttm_dense_table.h', 'ttm_int.h', 'ttm_xprog.h', 'ttm_handover.h',
            os.path.join('..', '..', 'include', 'ttm.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-ffp-contract=off', '-fPIC', '-shared',
          '-DNDEBUG'] + shlex.split(os.environ.get('TTM_BUILD_FLAGS', ''))

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ttm.h"
+#include "ttm_handover.h"
 
 namespace {
 
@@ -134,52 +135,30 @@ int ttm_comm_create(const void* id128, int32_t rank, int32_t nranks, ttm_comm** 
     // ncclCommInitRank blocks until every rank has called it: one rank that failed earlier (or died) would leave the
     // others there for good.  It runs on a helper thread (same HIP device) and is given TTM_COMM_TIMEOUT_S seconds
     // (default 120); past that the call is reported as failed - the ranks then agree on "no communicator" (comm.py) -
-    // and the helper is left to finish or not on its own (a blocked ncclCommInitRank cannot be cancelled from outside).
-    // Hand-over between helper and waiter is ONE tri-state word: PENDING -> DONE (helper, result published) or
-    // PENDING -> ABANDONED (waiter, timed out).  Whoever loses the compare-exchange knows what the other did: a helper
-    // that finds ABANDONED owns the communicator it has just made and destroys it; a waiter whose CAS fails finds DONE
-    // and takes the result.  The reference count only decides who frees the Pending block.
-    enum : int { PENDING = 0, DONE = 1, ABANDONED = 2 };
-    struct Pending { std::atomic<int> state{PENDING}; std::atomic<int> owners{2}; ncclComm_t comm = nullptr; ncclResult_t rc = 0; };
-    Pending* pend = new Pending;                       // (shared with the helper: freed by whoever finishes last)
+    // and the helper is left to finish or not on its own (a blocked ncclCommInitRank cannot be cancelled from outside);
+    // a communicator it still makes is destroyed by the helper itself (csrc/ttm_handover.h: the hand-over protocol).
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { delete pend; return fail(TTM_E_HIP, "ttm_comm_create: hipGetDevice"); }
-    auto release = [](Pending* p) { if (p->owners.fetch_sub(1, std::memory_order_acq_rel) == 1) delete p; };
-    try {
-        std::thread([=] {
-            (void)hipSetDevice(dev);
-            ncclComm_t c2 = nullptr;
-            pend->rc = r->CommInitRank(&c2, nranks, id, rank);
-            pend->comm = c2;
-            int expect = PENDING;
-            if (!pend->state.compare_exchange_strong(expect, DONE, std::memory_order_acq_rel)) {
-                // ABANDONED: nobody will ever take this communicator
-                if (c2 && !pend->rc && r->CommDestroy) r->CommDestroy(c2);
-            }
-            release(pend);
-        }).detach();
-    } catch (...) {
-        delete pend;
-        return fail(TTM_E_HIP, "ttm_comm_create: no thread for ncclCommInitRank");
-    }
+    if (hipGetDevice(&dev) != hipSuccess) return fail(TTM_E_HIP, "ttm_comm_create: hipGetDevice");
+    struct Made { ncclComm_t comm = nullptr; ncclResult_t rc = 0; };
     double limit = 120.0;
     if (const char* e = getenv("TTM_COMM_TIMEOUT_S")) limit = atof(e) > 0.0 ? atof(e) : limit;
-    const auto t0 = std::chrono::steady_clock::now();
-    while (pend->state.load(std::memory_order_acquire) != DONE) {
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
-            int expect = PENDING;
-            if (pend->state.compare_exchange_strong(expect, ABANDONED, std::memory_order_acq_rel)) {
-                release(pend);
-                snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank did not return within %.0f s (a rank missing from the rendezvous?)", limit);
-                return TTM_E_HIP;
-            }
-            break;                                     // the helper finished in the same instant: state is DONE
-        }
-        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    Made made;
+    const int how = ttm_handover::run_with_timeout<Made>(
+        [=] {
+            (void)hipSetDevice(dev);
+            Made m;
+            m.rc = r->CommInitRank(&m.comm, nranks, id, rank);
+            return m;
+        },
+        [=](const Made& m) { if (m.comm && !m.rc && r->CommDestroy) r->CommDestroy(m.comm); },
+        limit, made);
+    if (how < 0) return fail(TTM_E_HIP, "ttm_comm_create: no thread for ncclCommInitRank");
+    if (how > 0) {
+        snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank did not return within %.0f s (a rank missing from the rendezvous?)", limit);
+        return TTM_E_HIP;
     }
-    const ncclResult_t rc = pend->rc;
-    ncclComm_t c = pend->comm;
-    release(pend);
+    const ncclResult_t rc = made.rc;
+    ncclComm_t c = made.comm;
     if (rc) return fail(TTM_E_HIP, "ncclCommInitRank", rc);
     *out = new ttm_comm{c, rank, nranks};
     return TTM_OK;
