@@ -204,12 +204,14 @@ extern "C" {
  *   ucomp : TTM_UC_LEN int32 per component
  *   ugrp  : TTM_UG_LEN int32 per group; a component's nonmonotone groups first, then (TTM_UCF_OWN) one group for
  *           the polynomial / Hermite-function terms of its monotone list
- *   U section (doubles, at fold + u_base): per component, at DBL_OFF: {c0, -t_lo/h, 1/h, 2/h} and 16 doubles per
- *           group {B[0..7] monomial coefficients of the exp(-x^2/4) part, A[0..7] of the plain part}; at TAB_OFF the
+ *   U section (doubles, at fold + u_base): per component, at DBL_OFF: {c0, -t_lo/h, 1/h, 2/h} and TTM_U_GSTRIDE doubles per
+ *           group {B[0..11] monomial coefficients of the exp(-x^2/4) part, A[0..11] of the plain part}; at TAB_OFF the
  *           spline of the summed special terms: NI columns of TTM_U_TSTRIDE doubles (12 coefficients in the local
  *           coordinate s in [-1,1] of the interval + padding), column 0 / NI-1 = the linear tails; then 2 doubles per
  *           component {fit error of the value, of the derivative} at u_err_off.                                   */
-#define TTM_U_PMAX        7   /* largest polynomial order a group may have                      */
+#define TTM_U_PMAX       10   /* largest polynomial order a group may have (round 5: 7 -> 10, example_03.py:103)          */
+#define TTM_U_GHALF      12   /* doubles per coefficient set of a group in the U section: B[0..11] then A[0..11]          */
+#define TTM_U_GSTRIDE    24   /* doubles per group in the U section                                                       */
 #define TTM_U_DEG        11   /* degree of the spline pieces                                    */
 #define TTM_U_TSTRIDE    14   /* doubles per spline column (16-byte reads of 16 consecutive columns hit disjoint banks) */
 #define TTM_U_NI_MAX    128   /* most columns a spline may have (LDS budget of the staged table) */
@@ -247,7 +249,8 @@ extern "C" {
  *           nonmonotone part alone (c0 also carries the monotone constants)
  *   u_h_ng group records of GS doubles: int32 {slot of the column (2 x way), 1} ({0, 0} for the padding records
  *           beyond the component's own groups), B[0..DB], A[0..DA], zero padding;
- *           (DB, DA, GS) = (3,1,8) / (5,5,16) / (7,7,24) for u_h_cls = 1 / 2 / 3.
+ *           (DB, DA, GS) = (3,1,8) / (5,5,16) / (7,7,24) / (10,10,24) for u_h_cls = 1 / 2 / 3 / 4 (class 4: maps of at most
+ *           TTM_P_FEW_D components only - their records exist as the source of the push records).
  * Available (u_h_cls > 0) when every group of a full sweep reads a column the sweep itself produced (all cache
  * hits), no component has polynomial / Hermite-function terms in its monotone list and none has more than
  * TTM_H_NG_MAX nonmonotone groups.                                                                              */

@@ -809,7 +809,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
                       int32_t T, const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb,
                       int32_t truncate, const double*, int64_t, void*) {
     const Prog g = make_prog(p);
-    if (u_on(p) && p->u_h_cls >= 1 && p->u_p_lag <= 2 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
+    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 3 && p->u_p_lag <= 2 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) && h_y_affine && ldy == 0 &&
         (nb + 1) % 4 == 0 && !getenv("TTM_EMU_NO_HOT")) {
         // hot records + bucket scan + computed linspace abscissae: what k_inverse_hl evaluates
         const double* U = fold + fold_base_size(p);

@@ -206,6 +206,31 @@ def test_c2b_full_size_forward_inverse_pullback():
     assert np.max(np.abs(Xb[1:] - Xo[1:])) < 1e-6                           # (row 0: the reference's loop-guard quirk depends on the batch)
 
 
+def test_example03_order10_separable_map_takes_the_few_component_kernels():
+    """example_03.py:103-159 at its shipped maxorder = 10 (LET + 9 iRBF + RET, Hermite-function orders 1..10 of x_{k-1}; round 4
+    stopped at order 7 and lost the U-form for it): order class 4 of the push records, N = 1e6 through k_band_few /
+    k_band_few_inverse by name, against the oracle with the reference-optimised coefficients of the fixture."""
+    N = 1000000
+    tm, om, X = build('EX03', 'ex03_order10', N)
+    assert tm._cm.u_enabled and tm._cm.u_h_cls == 4 and tm._cm.u_p_lag > 0
+    idx = subset_with_tails(X)
+    Z = tm.map(X)
+    tm.forward_device(tm._Xs, tm._N)
+    assert _last_kernel(tm) == 'k_band_few'
+    record_parity('ex03_order10_full/map(k_band_few)_vs_oracle', relerr(Z[idx], om.map(X[idx])), 1e-11)
+    assert relerr(Z[idx], om.map(X[idx])) < 1e-11
+    Xi = tm.inverse_map(Z)
+    tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
+    assert _last_kernel(tm) == 'k_band_few_inverse'
+    record_parity('ex03_order10_full/table_inverse(k_band_few_inverse)_vs_oracle', relerr(Xi[idx], om.inverse_map(Z[idx])), 1e-11)
+    assert relerr(Xi[idx], om.inverse_map(Z[idx])) < 1e-11
+    pd, pdo = tm.evaluate_pullback_density(X[idx]), om.evaluate_pullback_density(X[idx])
+    record_parity('ex03_order10_full/pullback_density_vs_oracle', relerr(pd, pdo), 1e-10)
+    assert relerr(pd, pdo) < 1e-10
+    perm = np.random.default_rng(5).permutation(N)
+    assert np.array_equal(tm.map(X[perm]), Z[perm])
+
+
 def test_c2a_full_size_integrated_forward_and_bisection_inverse():
     N = 1000000
     tm, om, X = build('C2a', 'c2a_int', N)

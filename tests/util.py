@@ -7,11 +7,11 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, 'golden')
 
-ALL_CASES = ['c1_int', 'c2a_int', 'c2b_sep', 'c3_sep', 'c3_int', 'c5_sep', 'c5_int', 'misc_grid', 'misc_sep',
+ALL_CASES = ['c1_int', 'c2a_int', 'c2b_sep', 'c3_sep', 'c3_int', 'c5_sep', 'c5_int', 'misc_grid', 'misc_sep', 'ex03_order10',
              'misc_family_hermite_e', 'misc_family_hermite', 'misc_family_power_series',
              'misc_family_chebyshev', 'misc_family_laguerre', 'misc_family_legendre']
 INTEGRATED = [c for c in ALL_CASES if c.endswith('_int') or c == 'misc_grid' or c.startswith('misc_family')]
-SEPARABLE = ['c2b_sep', 'c3_sep', 'c5_sep', 'misc_sep']
+SEPARABLE = ['c2b_sep', 'c3_sep', 'c5_sep', 'misc_sep', 'ex03_order10']
 
 
 def load_case(name):

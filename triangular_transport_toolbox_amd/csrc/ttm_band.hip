@@ -35,8 +35,8 @@ __device__ const double g_band_etab[2 * TTM_BAND_ET_N] = { TTM_BAND_ETAB_VALUES 
 // Taylor coefficients of exp(w): 1/7! .. 1/2! (scalar operands of the fma chain)
 __device__ double g_band_taylor[6] = {1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
 
-__host__ __device__ constexpr int cls_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : 7); }
-__host__ __device__ constexpr int cls_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : 7); }
+__host__ __device__ constexpr int cls_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : (cls == 3 ? 7 : 10)); }   // (class 4: few-component kernels only)
+__host__ __device__ constexpr int cls_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : (cls == 3 ? 7 : 10)); }
 __host__ __device__ constexpr int cls_gs(int cls) { return cls == 1 ? 8 : (cls == 2 ? 16 : 24); }
 __host__ __device__ constexpr int cls_gp(int cls) { return cls_db(cls) + 1 + cls_da(cls); }
 __host__ __device__ constexpr int rec_stride(int cls, int lag) { return (TTM_P_HDR + lag * cls_gp(cls) + 7) / 8 * 8; }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void k_band_records(const int* __restrict__ uco
     // the nonmonotone ones in the component's U-form block)
     auto own = [&](int kk, int deg) {
         const int* uc = ucomp + kk * TTM_UC_LEN;
-        return (uc[TTM_UC_FLAGS] & TTM_UCF_OWN) ? U[uc[TTM_UC_DBL_OFF] + 4 + 16 * uc[TTM_UC_N_GRP] + 8 + deg] : 0.0;
+        return (uc[TTM_UC_FLAGS] & TTM_UCF_OWN) ? U[uc[TTM_UC_DBL_OFF] + 4 + TTM_U_GSTRIDE * uc[TTM_UC_N_GRP] + TTM_U_GHALF + deg] : 0.0;
     };
     // the group of component kk that reads the column `lg` columns in front of it: index into its hot record, -1: none
     auto group_at = [&](int kk, int lg) {
@@ -1994,7 +1994,8 @@ static int64_t chunk_rows(int64_t N, int cus) {
 int record_stride(int cls, int lag) { return rec_stride(cls, lag); }
 
 bool usable(const ttm_program* p, int k0, int k1) {
-    return p && p->u_enabled && (p->u_p_lag == 2 || (p->u_p_lag == 3 && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 && p->u_h_cls <= 3 &&
+    return p && p->u_enabled && (p->u_p_lag == 2 || (p->u_p_lag == 3 && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 &&
+           (p->u_h_cls <= 3 || (p->u_h_cls == 4 && p->D <= TTM_P_FEW_D)) &&
            p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 && p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);
 }
 
@@ -2116,7 +2117,7 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
             sweep_shape(p, k0, k1, &lage, &plain);
             if (lage > p->u_p_lag) return 1;
             fkern_t fk = nullptr;
-#define BAND_FEW_C(L, E, PL, DN) (cls == 1 ? k_band_few<1, L, E, PL, DN> : cls == 2 ? k_band_few<2, L, E, PL, DN> : k_band_few<3, L, E, PL, DN>)
+#define BAND_FEW_C(L, E, PL, DN) (cls == 1 ? k_band_few<1, L, E, PL, DN> : cls == 2 ? k_band_few<2, L, E, PL, DN> : cls == 3 ? k_band_few<3, L, E, PL, DN> : k_band_few<4, L, E, PL, DN>)
 #define BAND_FEW_P(L, E, DN) (plain ? BAND_FEW_C(L, E, true, DN) : BAND_FEW_C(L, E, false, DN))
 #define BAND_FEW_E(L, E) (dens ? BAND_FEW_P(L, E, true) : BAND_FEW_P(L, E, false))
             if (p->u_p_lag == 3) {
@@ -2137,7 +2138,7 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
             return 0;
         }
     }
-    if (p->u_p_lag != 2) return 1;
+    if (p->u_p_lag != 2 || cls > 3) return 1;             // (lag-3 records / order class 4: the few-component kernels only)
     if (logdet || sumsq) {
         typedef void (*dkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
                                 double*, int64_t, int);
@@ -2200,7 +2201,7 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
                                     double, double, double, const double*, const double*, const int*, int, int, int);
             const int cls = p->u_h_cls;
             fkern_t fk = nullptr;
-#define BAND_FEWI_C(L, E, PL) (cls == 1 ? k_band_few_inverse<1, L, E, PL> : cls == 2 ? k_band_few_inverse<2, L, E, PL> : k_band_few_inverse<3, L, E, PL>)
+#define BAND_FEWI_C(L, E, PL) (cls == 1 ? k_band_few_inverse<1, L, E, PL> : cls == 2 ? k_band_few_inverse<2, L, E, PL> : cls == 3 ? k_band_few_inverse<3, L, E, PL> : k_band_few_inverse<4, L, E, PL>)
 #define BAND_FEWI_E(L, E) (plain ? BAND_FEWI_C(L, E, true) : BAND_FEWI_C(L, E, false))
             if (p->u_p_lag == 3) fk = lage == 1 ? BAND_FEWI_E(3, 1) : lage == 2 ? BAND_FEWI_E(3, 2) : BAND_FEWI_E(3, 3);
             else fk = lage == 1 ? BAND_FEWI_E(2, 1) : BAND_FEWI_E(2, 2);
@@ -2216,7 +2217,7 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
             return 0;
         }
     }
-    if (p->u_p_lag != 2) return 1;
+    if (p->u_p_lag != 2 || p->u_h_cls > 3) return 1;       // (lag-3 records / order class 4: the few-component kernels only)
     static const int stagger = [] { const char* e = getenv("TTM_BAND_STAGGER"); return e ? atoi(e) : 1; }();
     const double wfrac = window_fraction();
     // resident-table images at hand (ttm_inverse_table_build_index wrote them): the ring kernel

@@ -2882,9 +2882,9 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                         if ((fl & TTM_UGF_POLY) && TTM_UG_DEGA(fl) > ma) ma = TTM_UG_DEGA(fl);
                     }
                 }
-                const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
-                lkern_t lk = logdet ? (cls == 0 ? k_forward_ul<true, 3, 1> : cls == 1 ? k_forward_ul<true, 5, 5> : k_forward_ul<true, 7, 7>)
-                                    : (cls == 0 ? k_forward_ul<false, 3, 1> : cls == 1 ? k_forward_ul<false, 5, 5> : k_forward_ul<false, 7, 7>);
+                const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : ((mb <= 7 && ma <= 7) ? 2 : 3));
+                lkern_t lk = logdet ? (cls == 0 ? k_forward_ul<true, 3, 1> : cls == 1 ? k_forward_ul<true, 5, 5> : cls == 2 ? k_forward_ul<true, 7, 7> : k_forward_ul<true, 10, 10>)
+                                    : (cls == 0 ? k_forward_ul<false, 3, 1> : cls == 1 ? k_forward_ul<false, 5, 5> : cls == 2 ? k_forward_ul<false, 7, 7> : k_forward_ul<false, 10, 10>);
                 int wgs = (int)(device_info().lds_per_cu / lds_ul);
                 if (wgs > 32 / (TTM_UL_CW + 2)) wgs = 32 / (TTM_UL_CW + 2);                                    // 6 waves per workgroup, 32 per CU
                 if (wgs < 1) wgs = 1;
@@ -2916,8 +2916,8 @@ int ttm_forward(const ttm_program* p, const double* coef, const double* fold, co
                     if ((fl & TTM_UGF_POLY) && TTM_UG_DEGA(fl) > ma) ma = TTM_UG_DEGA(fl);
                 }
             }
-            const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : 2);
-#define TTM_UK(L, NSV) (cls == 0 ? k_forward_u<L, NSV, 3, 1> : cls == 1 ? k_forward_u<L, NSV, 5, 5> : k_forward_u<L, NSV, 7, 7>)
+            const int cls = (mb <= 3 && ma <= 1) ? 0 : ((mb <= 5 && ma <= 5) ? 1 : ((mb <= 7 && ma <= 7) ? 2 : 3));
+#define TTM_UK(L, NSV) (cls == 0 ? k_forward_u<L, NSV, 3, 1> : cls == 1 ? k_forward_u<L, NSV, 5, 5> : cls == 2 ? k_forward_u<L, NSV, 7, 7> : k_forward_u<L, NSV, 10, 10>)
             ukern_t uk = logdet ? (uNS == 4 ? TTM_UK(true, 4) : uNS == 2 ? TTM_UK(true, 2) : TTM_UK(true, 1))
                                 : (uNS == 4 ? TTM_UK(false, 4) : uNS == 2 ? TTM_UK(false, 2) : TTM_UK(false, 1));
 #undef TTM_UK
@@ -3094,7 +3094,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
     // large ensembles of maps with hot records: resident-table kernel (components in blocks, tables resident in LDS)
-    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 3 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
+    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 4 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
         h_y_affine && ldy == 0 && T <= 4096 && nb <= 65535 && N < ((int64_t)1 << 28) && !tuning().rt_off && !tuning().u_no_hot &&
         (N >= 64 * 1024 || tuning().u_loader == 1)) {                       // (small ensembles: the table load per workgroup does not pay;
                                                                             // option u_loader = 1 forces it)
@@ -3109,7 +3109,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         }
       // k_inverse_rt sweeps the hot records themselves: not for lag-3 maps (include/ttm.h), and with fewer than four
       // components its table load per workgroup does not pay
-      if (p->u_p_lag <= 2 && (k1 - k0 >= 4 || tn.u_loader == 1)) {
+      if (p->u_p_lag <= 2 && p->u_h_cls <= 3 && (k1 - k0 >= 4 || tn.u_loader == 1)) {      // (order class 4: the few-component kernels only)
         const int ways = plan_ways_of(p);
         const int ncomp = k1 - k0;
         int NS = tn.rt_ns == 4 ? 4 : 2;

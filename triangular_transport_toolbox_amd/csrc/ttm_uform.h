@@ -97,13 +97,13 @@ TTM_HD void uform_build_groups(const int* uc, const int* ug, const int* fd, cons
     const int ng = uc[TTM_UC_N_GRP] + (uc[TTM_UC_FLAGS] & TTM_UCF_OWN ? 1 : 0);
     double* cd = U + uc[TTM_UC_DBL_OFF];
     const int* g0 = ug + TTM_UG_LEN * uc[TTM_UC_GRP_OFF];
-    for (int idx = first; idx < ng * 16; idx += stride) {
-        const int g = idx >> 4, j = idx & 15, deg = j & 7;
+    for (int idx = first; idx < ng * TTM_U_GSTRIDE; idx += stride) {
+        const int g = idx / TTM_U_GSTRIDE, j = idx % TTM_U_GSTRIDE, deg = j % TTM_U_GHALF;
         const int* G = g0 + TTM_UG_LEN * g;
-        const int src = (j < 8) ? G[TTM_UG_SRCB] : G[TTM_UG_SRCA];
-        const int P = (j < 8) ? G[TTM_UG_PB] : G[TTM_UG_PA];
+        const int src = (j < TTM_U_GHALF) ? G[TTM_UG_SRCB] : G[TTM_UG_SRCA];
+        const int P = (j < TTM_U_GHALF) ? G[TTM_UG_PB] : G[TTM_UG_PA];
         double acc = 0.0;
-        if (src >= 0)
+        if (src >= 0 && deg <= TTM_U_PMAX)
             for (int n = 1; n <= P; ++n) acc = fma(foldk[src + n - 1], umono[n * (TTM_U_PMAX + 1) + deg], acc);
         cd[4 + idx] = acc;
     }
@@ -179,8 +179,8 @@ TTM_HD double u_pack2(int lo, int hi) {
 }
 
 TTM_HD int u_h_gs(int cls) { return cls == 1 ? 8 : (cls == 2 ? 16 : 24); }
-TTM_HD int u_h_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : 7); }
-TTM_HD int u_h_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : 7); }
+TTM_HD int u_h_db(int cls) { return cls == 1 ? 3 : (cls == 2 ? 5 : (cls == 3 ? 7 : 10)); }
+TTM_HD int u_h_da(int cls) { return cls == 1 ? 1 : (cls == 2 ? 5 : (cls == 3 ? 7 : 10)); }
 
 // hot record of one component (include/ttm.h "H section"), from its U-form block; run after uform_build_groups.
 // nm0: the constant of the nonmonotone part alone (folded[0]; c0 also carries the monotone constants)
@@ -205,8 +205,8 @@ TTM_HD void uform_build_hot(const int* uc, const int* ug, double* U, int64_t h_o
                 const int* G = ug + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + g);
                 const int fl = G[TTM_UG_FLAGS];
                 if (j == 0) v = u_pack2(2 * TTM_PLAN_SLOT(fl), 1);
-                else if (j <= 1 + DB) v = (fl & TTM_PLAN_HF) ? cd[4 + 16 * g + (j - 1)] : 0.0;
-                else if (j <= 2 + DB + DA) v = (fl & TTM_UGF_POLY) ? cd[4 + 16 * g + 8 + (j - 2 - DB)] : 0.0;
+                else if (j <= 1 + DB) v = (fl & TTM_PLAN_HF) ? cd[4 + TTM_U_GSTRIDE * g + (j - 1)] : 0.0;
+                else if (j <= 2 + DB + DA) v = (fl & TTM_UGF_POLY) ? cd[4 + TTM_U_GSTRIDE * g + TTM_U_GHALF + (j - 2 - DB)] : 0.0;
             } else if (j == 0) {
                 v = u_pack2(0, 0);
             }
@@ -234,7 +234,7 @@ TTM_HD void uform_scatter_push_records(const int* ucomp, const int* ugrp, double
     double* P = U + p_off;
     const int n_grp = uc[TTM_UC_N_GRP];
     const bool own = (uc[TTM_UC_FLAGS] & TTM_UCF_OWN) != 0;
-    const double* ownc = U + uc[TTM_UC_DBL_OFF] + 4 + 16 * n_grp + 8;          // {constant, slope} of the linear own term
+    const double* ownc = U + uc[TTM_UC_DBL_OFF] + 4 + TTM_U_GSTRIDE * n_grp + TTM_U_GHALF;          // {constant, slope} of the linear own term
     // chain starts of component k -> record k
     for (int i = first; i < 2; i += stride) {
         double v = i == 0 ? h[2] : h[7];
@@ -372,7 +372,10 @@ TTM_HD void u_horner(int P, cdbl_p c, const R& x, R& v, R& dv) {
         case 4: u_horner_fixed<4, DER>(c, x, v, dv); break;
         case 5: u_horner_fixed<5, DER>(c, x, v, dv); break;
         case 6: u_horner_fixed<6, DER>(c, x, v, dv); break;
-        default: u_horner_fixed<7, DER>(c, x, v, dv); break;
+        case 7: u_horner_fixed<7, DER>(c, x, v, dv); break;
+        case 8: u_horner_fixed<8, DER>(c, x, v, dv); break;
+        case 9: u_horner_fixed<9, DER>(c, x, v, dv); break;
+        default: u_horner_fixed<TTM_U_PMAX, DER>(c, x, v, dv); break;
     }
 }
 
@@ -396,7 +399,7 @@ TTM_HD R u_nonmon(cint_p uc, cint_p ug_all, cdbl_p U, Fetch& x) {
     R s(cd[0]);
     for (int g = 0; g < n_grp; ++g) {
         const int var = ug[TTM_UG_LEN * g + TTM_UG_VAR], fl = ug[TTM_UG_LEN * g + TTM_UG_FLAGS];
-        cdbl_p rec = cd + 4 + 16 * g;
+        cdbl_p rec = cd + 4 + TTM_U_GSTRIDE * g;
         R xv, e(0.0), v, dv;
         if ((fl & (TTM_PLAN_HF | TTM_PLAN_XHIT | TTM_PLAN_EHIT)) == (TTM_PLAN_HF | TTM_PLAN_XHIT | TTM_PLAN_EHIT)) {
             const int slot = TTM_PLAN_SLOT(fl);
@@ -410,7 +413,7 @@ TTM_HD R u_nonmon(cint_p uc, cint_p ug_all, cdbl_p U, Fetch& x) {
             s = vfma(e, v, s);
         }
         if (fl & TTM_UGF_POLY) {
-            u_poly<DA, false>(TTM_UG_DEGA(fl), rec + 8, xv, v, dv);
+            u_poly<DA, false>(TTM_UG_DEGA(fl), rec + TTM_U_GHALF, xv, v, dv);
             s = s + v;
         }
     }
@@ -423,7 +426,7 @@ template <bool DER, class R>
 TTM_HD void u_own(cint_p uc, cint_p ug_all, cdbl_p U, const R& xk, const R& ek, R& m, R& dm) {
     const int g = uc[TTM_UC_N_GRP];
     cint_p G = ug_all + TTM_UG_LEN * (uc[TTM_UC_GRP_OFF] + g);
-    cdbl_p rec = U + uc[TTM_UC_DBL_OFF] + 4 + 16 * g;
+    cdbl_p rec = U + uc[TTM_UC_DBL_OFF] + 4 + TTM_U_GSTRIDE * g;
     const int fl = G[TTM_UG_FLAGS];
     R v, dv;
     if (fl & TTM_PLAN_HF) {
@@ -432,7 +435,7 @@ TTM_HD void u_own(cint_p uc, cint_p ug_all, cdbl_p U, const R& xk, const R& ek, 
         if (DER) dm = vfma(ek, vfma(-0.5 * xk, v, dv), dm);      // d/dx [e^{-x^2/4} B] = e^{-x^2/4} (B' - x B / 2)
     }
     if (fl & TTM_UGF_POLY) {
-        u_horner<DER>(TTM_UG_DEGA(fl), rec + 8, xk, v, dv);
+        u_horner<DER>(TTM_UG_DEGA(fl), rec + TTM_U_GHALF, xk, v, dv);
         m = m + v;
         if (DER) dm = dm + dv;
     }

@@ -258,6 +258,12 @@ def config(name):
         mon, non = temperature_spec(5)
         return dict(monotone=mon, nonmonotone=non, sampler=sample_spiral,
                     kwargs=dict(monotonicity='separable monotonicity'))
+    if name == 'EX03':
+        # example_03.py:103-159 at its shipped maxorder = 10 (LET + 9 iRBF + RET, Hermite-function orders 1..10 of x_{k-1}); the
+        # script's temperature records are data files: the spiral target stands in for them
+        mon, non = temperature_spec(10)
+        return dict(monotone=mon, nonmonotone=non, sampler=sample_spiral,
+                    kwargs=dict(monotonicity='separable monotonicity'))
     if name == 'C3':
         mon, non = dense_separable_spec(4, 4)
         return dict(monotone=mon, nonmonotone=non, sampler=sample_banana,

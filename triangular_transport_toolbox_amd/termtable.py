@@ -809,9 +809,10 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 
 
 # ---- univariate form (include/ttm.h "U-form", csrc/ttm_uform.h) -----------------------------------------
-U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 7, 14, 128, 8, 8
-H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24)
-H_DB, H_DA = (0, 3, 5, 7), (0, 1, 5, 7)
+U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 10, 14, 128, 8, 8
+U_GSTRIDE = 24               # doubles per group in the U section: B[0..11], A[0..11]
+H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24, 24)
+H_DB, H_DA = (0, 3, 5, 7, 10), (0, 1, 5, 7, 10)
 P_HDR, P_LAG_MAX, P_FEW_D = 8, 3, 4
 UCF_OWN, UGF_POLY = 1, 1 << 20
 U_KAPPA = 0.75                # spline interval width / smallest special-term scale (degree 11: fit error < 1e-14;
@@ -897,7 +898,9 @@ def _compile_uform(cm, u_info, polyclass, separable):
     # its push records only, u_p_lag = 3 says so)
     few_only = banded and few and (maxlag == 3 or not all_hit or any(own))
     if ((all_hit and not any(own)) or few_only) and ng <= H_NG_MAX:
-        cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else 3)
+        # (orders 8..10 - class 4, example_03.py:103 - exist for the kernels of maps with a few components only)
+        cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else (3 if (mb <= 7 and ma <= 7) else (4 if (banded and few) else 0)))
+    if cm.u_h_cls:
         cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
         if banded:
             cm.u_p_lag = 3 if few_only else 2
@@ -984,7 +987,7 @@ def uform_geometry(cm, kappa=None):
     for k, u in enumerate(cm.u_info):
         ng = int(uc[k, 2]) + (1 if uc[k, 7] & UCF_OWN else 0)
         uc[k, 6] = off
-        off += 4 + 16 * ng
+        off += 4 + U_GSTRIDE * ng
     for k, u in enumerate(cm.u_info):
         nI = 0
         if len(u['st_p0']):
