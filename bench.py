@@ -49,6 +49,10 @@ WORKLOADS = {
     # the integrated-rectifier variants SURVEY.md section 8 names as canonical (FP64-bound: secondary numbers)
     'C3int': ('C3int', 500000, 'c3_int', 'd=4 band-1 integrated-rectifier map, order 4, Q=25, N=5e5 (banana target)'),
     'C5int': ('C5int', 200000, 'c5_int', 'd=40 band-2 integrated-rectifier map, order 3, Q=25, N=2e5 (Gaussian-mixture target)'),
+    # the reference's own shipped examples at their shipped orders (example_01.py:126, example_03.py:103: maxorder = 10)
+    'EX01': ('EX01', 1000000, 'ex01_order10', 'Example 01 as shipped: spiral d=2 integrated-rectifier map, order 10 (66 coefficients in the second '
+                                              'component, the shipped pickle), Q=25, N=1e6'),
+    'EX03': ('EX03', 1000000, 'ex03_order10', 'Example 03 as shipped: d=2 separable map, order 10 (LET + 9 iRBF + RET, Hermite functions 1..10), N=1e6 (spiral target)'),
 }
 
 
@@ -123,13 +127,13 @@ def cpu_baseline(workload, seconds):
     out = {'unit': 'map-evals/s', 'kind': 'port', 'host': core_info}
     # leg 2: NumPy, one core; sample sized from a short calibration run
     with mp.get_context('fork').Pool(1) as pool:
-        n0 = {'C5': 20000, 'C3': 50000, 'C2b': 100000, 'C2a': 500, 'C3int': 500, 'C5int': 100}[workload]
+        n0 = {'C5': 20000, 'C3': 50000, 'C2b': 100000, 'C2a': 500, 'C3int': 500, 'C5int': 100, 'EX01': 200, 'EX03': 50000}[workload]
         ev, tf, ti = pool.map(_numpy_leg, [(workload, n0, 7000)])[0]
         n1 = int(max(n0, min(20 * n0, n0 * seconds / max(tf + ti, 1e-3))))
         ev, tf, ti = pool.map(_numpy_leg, [(workload, n1, 7013)])[0]
     out['numpy_1core'] = {'value': ev / (tf + ti), 'cores': 1, 'samples': n1, 'forward_s': tf, 'inverse_s': ti,
                           'what': 'oracle/ttm_oracle.py (NumPy restatement of the reference CPU path), one process, one thread'}
-    if workload in ('C2a', 'C3int', 'C5int'):
+    if workload in ('C2a', 'C3int', 'C5int', 'EX01'):
         out.update(value=out['numpy_1core']['value'], cores=1,
                    sample='NumPy oracle, %d samples of the workload, forward + bisection inverse, one core '
                           '(the OpenMP leg restates the separable path only)' % n1)
@@ -1133,7 +1137,7 @@ def main():
         extra.update(api)
     if world == 1 and not args.no_other_configs and args.workload == 'C5':
         try:
-            extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3', 'C3int', 'C5int'])
+            extra['other_configs'] = other_configs(torch, ['C2b', 'C2a', 'C3', 'C3int', 'C5int', 'EX01', 'EX03'])
         except Exception as exc:                       # noqa: BLE001  (never fatal for the headline line)
             extra['other_configs_error'] = repr(exc)
         try:

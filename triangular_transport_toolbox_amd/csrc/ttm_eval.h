@@ -265,7 +265,9 @@ TTM_HD void rect_all(int mode, double delta, const R& g, R& r, R& dr, R& logr) {
         case TTM_RECT_EXPONENTIAL:
             r = fast_exp(g); dr = r; logr = (delta == 0.0) ? g : fast_log(r + delta); break;
         case TTM_RECT_SOFTPLUS:
-            r = rect_eval(mode, g); dr = fast_rcp(1.0 + fast_exp(-kLn2 * g)); logr = fast_log(r + delta); break;
+            // (the exponent capped: 1 / (1 + inf) is 0 in the reference's arithmetic, TM:5140-5147, but NaN through the Newton steps
+            // of fast_rcp; 1 / (1 + e^700) = 1e-304 stands for it)
+            r = rect_eval(mode, g); dr = fast_rcp(1.0 + fast_exp(vmin(-kLn2 * g, 700.0))); logr = fast_log(r + delta); break;
         case TTM_RECT_EXPNEG:
             r = fast_exp(-g); dr = -r; logr = -g; break;
         case TTM_RECT_SQUARED:

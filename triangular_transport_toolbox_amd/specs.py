@@ -249,6 +249,12 @@ def config(name):
         return dict(monotone=mon, nonmonotone=non, sampler=sample_spiral,
                     kwargs=dict(monotonicity='integrated rectifier',
                                 quadrature_input={'order': 25}))
+    if name == 'EX01':
+        # example_01.py:121-170 at its shipped maxorder = 10 (the reference's only known-answer fixture: dict_coeffs_order=10.p)
+        mon, non = spiral_spec(10)
+        return dict(monotone=mon, nonmonotone=non, sampler=sample_spiral,
+                    kwargs=dict(monotonicity='integrated rectifier',
+                                quadrature_input={'order': 25}))
     if name == 'C2a':
         mon, non = spiral_spec(5)
         return dict(monotone=mon, nonmonotone=non, sampler=sample_spiral,
