@@ -397,11 +397,12 @@ __device__ __forceinline__ void band_spline_d(const double* tab, int nI, double 
     m = a; dm = da;
 }
 
-// The log-determinant is taken as the log of the PRODUCT of a row's derivatives, renormalised every BAND_LD_CHUNK columns
-// (mantissa kept, binary exponent counted; a product of four derivatives cannot leave the fp64 range unless one of them
-// does): ONE logarithm per row instead of one per evaluation; the uniform factors of the derivatives (2/h of every
+// The log-determinant is taken as the log of the PRODUCT of a row's derivatives, renormalised every BAND_LD_CHUNK = 2 columns
+// (mantissa kept, binary exponent counted - round 5: every TWO columns; four tail derivatives of 1e-90 each - grid points far
+// outside the samples of a monotone part that saturates - underflow a product of four where the reference's sum of logarithms
+// is finite): ONE logarithm per row instead of one per evaluation; the uniform factors of the derivatives (2/h of every
 // spline, 1/sigma_k) enter as one number per launch.
-#define BAND_LD_CHUNK 4
+#define BAND_LD_CHUNK 2
 #define BAND_UNI 256                                  /* components of a density pass, at most */
 #ifndef BAND_DENS_RT
 #define BAND_DENS_RT 2
@@ -571,13 +572,15 @@ __global__ __launch_bounds__(BAND_CT) void k_band_density(const double* __restri
                 for (; j + 3 < ke; j += 4) {
                     step(j, xa, xb);
                     step(j + 1, xb, xa);
+                    flush_ld();
                     step(j + 2, xa, xb);
                     step(j + 3, xb, xa);
-                    flush_ld();                               // (a flush every other round costs 200 spilled registers)
+                    flush_ld();
                 }
                 for (; j + 1 < ke; j += 2) {
                     step(j, xa, xb);
                     step(j + 1, xb, xa);
+                    flush_ld();
                 }
             }
             if (j < ke) step(j, xa, xb);
