@@ -282,6 +282,21 @@ __device__ __forceinline__ bool finish_stage_b(double* partial, int nsum, unsign
     return true;
 }
 
+// One entry for both shapes of a grid: up to 128 workgroups the last one to arrive adds all rows itself (ONE ticket, one batch of
+// loads); beyond, the two stages above.  true = this workgroup is the last of the grid and `fin` (LDS) holds the nsum totals.
+// partial: gridDim.x (+ 8) rows of nsum doubles written by coherent_store and drained; scr: LDS, (blockDim.x / 64) x nsum doubles.
+__device__ __forceinline__ bool finish_sums(double* partial, int nsum, unsigned int* counter, double* scr, double* fin) {
+    __shared__ int verdict;
+    if (gridDim.x > 128u) return finish_stage_a(partial, nsum, counter, scr, &verdict) && finish_stage_b(partial, nsum, counter, scr, fin, &verdict);
+    __syncthreads();
+    if (threadIdx.x == 0) verdict = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    if (!verdict) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    add_rows(partial, 0, 1, (int)gridDim.x, nsum, scr, fin, nullptr);
+    return true;
+}
+
 // Results of a finishing workgroup and the completion mark behind them (all threads of the workgroup call; fin: the n
 // results in LDS).  ONE wave stores the results, waits until every one of those stores has been acknowledged
 // (s_waitcnt vmcnt(0): the results span several cache lines, which travel through different L2 channels and would

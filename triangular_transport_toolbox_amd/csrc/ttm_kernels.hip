@@ -2112,18 +2112,14 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     }
     __syncthreads();
     const int nacc = 1 + M;
-    if (tid < nacc) partial[(int64_t)blockIdx.x * nacc + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    // counter == nullptr: the finishing sum is a second launch (large grids: a device-scope fence per workgroup - an L2
-    // write-back + invalidate on gfx950 - costs ~60 ns each and they serialise: 64 us for the 977 workgroups of N = 1e6)
-    if (counter && last_workgroup(counter)) {
+    if (tid < nacc) coherent_store(partial + (int64_t)blockIdx.x * nacc + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    drain_stores();
+    // counter != nullptr: the workgroup that draws the last ticket finishes (grids of up to 128 workgroups; the partial sums
+    // travel as agent-scope stores / loads, no fence - csrc/ttm_dev.h: finish_sums); nullptr: a second launch does
+    if (counter) {
         __shared__ double fin[M + 1];
-        for (int i = wv; i < nacc; i += 4) {
-            double v = 0.0;
-            for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
-            v = wave_sum(v);
-            if (lane == 0) fin[i] = v;
-        }
-        publish(fin, nacc, out, flag, mark);
+        __shared__ double scr[4 * (M + 1)];
+        if (finish_sums(partial, nacc, counter, scr, fin)) publish(fin, nacc, out, flag, mark);
     }
 }
 
@@ -2191,16 +2187,12 @@ __global__ __launch_bounds__(256) void k_objective_sep_direct(const double* __re
     }
     __syncthreads();
     const int nacc = 1 + M;
-    if (tid < nacc) partial[(int64_t)blockIdx.x * nacc + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (counter && last_workgroup(counter)) {
+    if (tid < nacc) coherent_store(partial + (int64_t)blockIdx.x * nacc + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    drain_stores();
+    if (counter) {
         __shared__ double fin[M + 1];
-        for (int i = wv; i < nacc; i += 4) {
-            double v = 0.0;
-            for (int b = lane; b < (int)gridDim.x; b += 64) v += partial[(int64_t)b * nacc + i];
-            v = wave_sum(v);
-            if (lane == 0) fin[i] = v;
-        }
-        publish(fin, nacc, out, flag, mark);
+        __shared__ double scr[4 * (M + 1)];
+        if (finish_sums(partial, nacc, counter, scr, fin)) publish(fin, nacc, out, flag, mark);
     }
 }
 
@@ -3385,14 +3377,17 @@ int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, 
     SepCoef hc;
     for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
     int nb = grid_for(N, 256 * 4);
-    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;         // (eight more rows of partial sums: the group sums of finish_sums)
     typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*, double*, double);
     static const skern_t kerns[TTM_SEPC_MAXM] = {
         k_objective_sep_cached<1>, k_objective_sep_cached<2>, k_objective_sep_cached<3>, k_objective_sep_cached<4>,
         k_objective_sep_cached<5>, k_objective_sep_cached<6>, k_objective_sep_cached<7>, k_objective_sep_cached<8>,
         k_objective_sep_cached<9>, k_objective_sep_cached<10>, k_objective_sep_cached<11>, k_objective_sep_cached<12>,
         k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
-    const bool ticket = nb <= 64;                    // small grids: one launch, the last workgroup finishes
+    // up to 128 workgroups (N <= 131 072: the filter's ensembles): ONE launch, the workgroup that draws the last ticket adds the rows
+    // of partial sums itself (csrc/ttm_dev.h: finish_sums, no fence).  Larger grids finish in a second launch: the in-kernel
+    // two-stage finish was measured at + 8 us per evaluation at N = 1e6 (21.6 against 13.4 us; rounds of agent-scope loads)
+    const bool ticket = nb <= 128;
     hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta,
                        work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
     if (!ticket) {
@@ -3415,14 +3410,14 @@ int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, cons
     SepCoef hc;
     for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
     int nb = grid_for(N, 256 * 4);
-    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;
     typedef void (*dkern_t)(const double*, int64_t, const int*, const double*, SepCoef, double, double*, unsigned int*, double*, double*, double);
     static const dkern_t kerns[TTM_SEPC_MAXM] = {
         k_objective_sep_direct<1>, k_objective_sep_direct<2>, k_objective_sep_direct<3>, k_objective_sep_direct<4>,
         k_objective_sep_direct<5>, k_objective_sep_direct<6>, k_objective_sep_direct<7>, k_objective_sep_direct<8>,
         k_objective_sep_direct<9>, k_objective_sep_direct<10>, k_objective_sep_direct<11>, k_objective_sep_direct<12>,
         k_objective_sep_direct<13>, k_objective_sep_direct<14>, k_objective_sep_direct<15>, k_objective_sep_direct<16>};
-    const bool ticket = nb <= 64;
+    const bool ticket = nb <= 128;                   // (see ttm_objective_sep_cached_marked)
     hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta,
                        work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
     if (!ticket) {
