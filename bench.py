@@ -268,7 +268,7 @@ def objective_roofline(torch, tm, workload, passes=3):
     out = {}
     if not separable:
         cs = [np.ascontiguousarray(np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k])), dtype=float) for k in range(D)]
-        if any(len(c) > 64 for c in cs):
+        if any(len(c) > 128 for c in cs):
             return None
 
         def one_pass():
