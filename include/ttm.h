@@ -255,13 +255,14 @@ extern "C" {
  * hits), no component has polynomial / Hermite-function terms in its monotone list and none has more than
  * TTM_H_NG_MAX nonmonotone groups.                                                                              */
 #define TTM_H_HDR         8
-#define TTM_H_NG_MAX      4
+#define TTM_H_NG_MAX      5   /* (hot kernels: 2 or 4 group records; 5: maps of a few components whose records only feed the push records) */
 
 /* "push" records of a BANDED U-form map (P section, behind the H section; written by ttm_fold when u_p_lag > 0).
  * Banded: the components' columns are consecutive (kc_k = kc_0 + k), every nonmonotone group of component k reads a
  * column kc_k - 1 .. kc_k - u_p_lag, the monotone part of every component is a special-term spline (maps of a few components:
  * and / or one linear term of its own variable) and hot records exist (u_h_cls > 0).
- * u_p_lag is 2, or 3 (= TTM_P_LAG_MAX) for a map of at most TTM_P_FEW_D components whose groups do not all hit the planned
+ * u_p_lag is 2, or 3 / 5 (= TTM_P_LAG_MAX: a group four or five columns back - the smoother's block map of example_07.py:368-408)
+ * for a map of at most TTM_P_FEW_D components whose groups do not all hit the planned
  * column cache (a group three columns back; conditioning columns in front of the first component) or that have linear own
  * terms; in the latter case the
  * hot records exist ONLY as the source of the push records (the kernels that sweep hot records do not take such a map).
@@ -282,7 +283,7 @@ extern "C" {
  * ttm_fold also writes, into padding slot 12 of every spline column c of such a map, the offset s0 of its local
  * coordinate: s = x [4] + s0.                                                                                     */
 #define TTM_P_HDR         8
-#define TTM_P_LAG_MAX     3
+#define TTM_P_LAG_MAX     5
 #define TTM_P_FEW_D       4   /* components of a map the lag-3 kernels take, at most */
 
 typedef struct ttm_program {

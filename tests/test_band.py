@@ -41,6 +41,9 @@ CASES = {
     'few_entf': dict(D=3, d=4, spec=lambda: _specs().entf_filter_spec(3), cls=1, lag=3, few=True),
     'few_ex05': dict(D=2, d=2, spec=lambda: _specs().density_example_spec(3), cls=1, lag=3, few=True),
     'few_cond2': dict(D=4, d=6, spec=lambda: _banded_with_conditioning(4, 2), cls=1, lag=3, few=True),   # (lag 2, but conditioning columns: records of three groups)
+    # the smoother's block map of example 07 (6 columns, D = 3, skip 3: its third component reads five columns back, five groups;
+    # linear monotone parts, no spline anywhere): push records of five groups
+    'few_ents': dict(D=3, d=6, spec=lambda: _specs().ents_smoother_spec(3), cls=1, lag=5, few=True, kw=dict(polynomial_type="probabilist's hermite")),
 }
 
 
@@ -57,7 +60,7 @@ def _build(case, n=5003, seed=0):
     d = c['d']
     X = rng.standard_normal((n, d)) @ (np.tril(rng.standard_normal((d, d)) * 0.4) + np.eye(d)).T + 0.3 * rng.standard_normal((n, d)) ** 2
     mon, non = c['spec']()
-    kw = dict(monotonicity='separable monotonicity')
+    kw = dict(monotonicity='separable monotonicity', **c.get('kw', {}))
     tm = transport_map(X=X, monotone=mon, nonmonotone=non, verbose=False, **kw)
     om = OracleMap(X=X, monotone=mon, nonmonotone=non, **kw)
     for k in range(c['D']):
@@ -77,7 +80,7 @@ def test_band_detection_and_push_record_geometry(case):
         tm, om, X, rng = _build(case, n=400)
         cm = tm._cm
         assert cm.u_enabled and cm.u_h_cls == CASES[case]['cls']
-        assert cm.u_p_lag == CASES[case].get('lag', 2) and termtable.P_LAG_MAX == 3
+        assert cm.u_p_lag == CASES[case].get('lag', 2) and termtable.P_LAG_MAX == 5
         gp = termtable.H_DB[cm.u_h_cls] + 1 + termtable.H_DA[cm.u_h_cls]
         assert cm.u_p_stride % 8 == 0
         assert cm.u_p_off % 8 == 0 and cm.u_p_off >= cm.u_h_off + cm.D * (termtable.H_HDR + cm.u_h_ng * termtable.H_GS[cm.u_h_cls])

@@ -375,6 +375,9 @@ def test_c4_block_map_backward_step_at_1e5_against_the_oracle():
     got = tm.inverse_map(X_star=Xnext.copy(), Z=Zp)
     tm.forward_device(tm._Xs, tm._N)
     fk = _last_kernel(tm)
+    assert fk == 'k_band_few'                                # (push records of five groups, lag 5: round 5)
+    tm.inverse_device(tm._cols(tm.D, tm._N, zero=True), tm._N)
+    assert _last_kernel(tm) == 'k_band_few_inverse'
     mon, non = specs.ents_smoother_spec(3)
     om = OracleMap(X=inp.copy(), monotone=mon, nonmonotone=non, polynomial_type="probabilist's hermite",
                    monotonicity='separable monotonicity', regularization='l2', regularization_lambda=0.05)

@@ -1997,7 +1997,7 @@ static int64_t chunk_rows(int64_t N, int cus) {
 int record_stride(int cls, int lag) { return rec_stride(cls, lag); }
 
 bool usable(const ttm_program* p, int k0, int k1) {
-    return p && p->u_enabled && (p->u_p_lag == 2 || (p->u_p_lag == 3 && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 &&
+    return p && p->u_enabled && (p->u_p_lag == 2 || ((p->u_p_lag == 3 || p->u_p_lag == TTM_P_LAG_MAX) && p->D <= TTM_P_FEW_D)) && p->u_h_cls >= 1 &&
            (p->u_h_cls <= 3 || (p->u_h_cls == 4 && p->D <= TTM_P_FEW_D)) &&
            p->h_ucomp && k0 >= 0 && k1 <= p->D && k0 < k1 && p->u_p_stride == rec_stride(p->u_h_cls, p->u_p_lag);
 }
@@ -2058,7 +2058,14 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     if (lds_per_cu <= fixed) return 1;
     int nblk = 0;
     int Bc = plan_blocks(p, k0, k1, lds_per_cu - fixed, &nblk);
-    if (Bc <= 0) return 1;
+    if (Bc <= 0) {
+        // a sweep without any spline (linear monotone parts: the smoother's block map) of a few components: one block, no tables
+        bool any = false;
+        for (int k = k0; k < k1; ++k) any = any || p->h_ucomp[k * TTM_UC_LEN + TTM_UC_NI] > 0;
+        if (any || k1 - k0 > TTM_P_FEW_D) return 1;
+        Bc = k1 - k0;
+        nblk = 1;
+    }
     if (block > 0 && block < Bc) Bc = block;
     size_t lds = 0;
     for (int kb = k0; kb < k1; kb += Bc) {
@@ -2094,7 +2101,8 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
                 typedef void (*lkern_t)(const double*, int64_t, int, int, int, int, const double*, int64_t, int64_t, double*, const double*, int64_t, int);
                 int64_t rows = chunk_rows(N, cus);
                 const bool wide = rows >= 3 * BAND_CT;
-                lkern_t lk = p->u_p_lag == 3 ? (wide ? k_band_logdet<3, 4> : k_band_logdet<3, 2>) : (wide ? k_band_logdet<2, 4> : k_band_logdet<2, 2>);
+                lkern_t lk = p->u_p_lag == 5 ? (wide ? k_band_logdet<5, 4> : k_band_logdet<5, 2>)
+                           : p->u_p_lag == 3 ? (wide ? k_band_logdet<3, 4> : k_band_logdet<3, 2>) : (wide ? k_band_logdet<2, 4> : k_band_logdet<2, 2>);
                 const int64_t grid = (N + rows - 1) / rows;
                 allow_lds((const void*)lk, llds);
                 hipLaunchKernelGGL(lk, dim3((unsigned)grid), dim3(BAND_CT), llds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
@@ -2109,8 +2117,9 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     static const int few_on = [] { const char* e = getenv("TTM_BAND_FEW"); return e ? atoi(e) : 1; }();
     if (k1 - k0 <= TTM_P_FEW_D && few_on) {
         // the splines of the sweep as they stand in the U section (padding between them included)
-        const int tab0 = p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_TAB_OFF];
-        const int ntab = p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_TAB_OFF] + TTM_U_TSTRIDE * p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_NI] - tab0;
+        int tab0 = p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_TAB_OFF];
+        int ntab = p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_TAB_OFF] + TTM_U_TSTRIDE * p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_NI] - tab0;
+        if (ntab <= 0) { tab0 = 0; ntab = 2; }                 // (no spline in the sweep - linear monotone parts: two doubles of the U section stand in)
         const size_t flds = (size_t)BAND_ET_DOUBLES * 8 + ((size_t)(ntab > 0 ? ntab : 0) + 2) * 8;
         if (ntab >= 2 && ntab % 2 == 0 && tab0 % 2 == 0 && ntab <= BAND_FEW_TAB && flds <= lds_per_cu && (!sigma || logdet)) {
             typedef void (*fkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, const double*,
@@ -2123,7 +2132,9 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
 #define BAND_FEW_C(L, E, PL, DN) (cls == 1 ? k_band_few<1, L, E, PL, DN> : cls == 2 ? k_band_few<2, L, E, PL, DN> : cls == 3 ? k_band_few<3, L, E, PL, DN> : k_band_few<4, L, E, PL, DN>)
 #define BAND_FEW_P(L, E, DN) (plain ? BAND_FEW_C(L, E, true, DN) : BAND_FEW_C(L, E, false, DN))
 #define BAND_FEW_E(L, E) (dens ? BAND_FEW_P(L, E, true) : BAND_FEW_P(L, E, false))
-            if (p->u_p_lag == 3) {
+            if (p->u_p_lag == 5) {
+                fk = BAND_FEW_E(5, 5);                        // (records of five groups - the smoother's block map: one shape, zeros beyond a sweep's reach)
+            } else if (p->u_p_lag == 3) {
                 fk = lage == 1 ? BAND_FEW_E(3, 1) : lage == 2 ? BAND_FEW_E(3, 2) : BAND_FEW_E(3, 3);
             } else {
                 fk = lage == 1 ? BAND_FEW_E(2, 1) : BAND_FEW_E(2, 2);
@@ -2206,7 +2217,8 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
             fkern_t fk = nullptr;
 #define BAND_FEWI_C(L, E, PL) (cls == 1 ? k_band_few_inverse<1, L, E, PL> : cls == 2 ? k_band_few_inverse<2, L, E, PL> : cls == 3 ? k_band_few_inverse<3, L, E, PL> : k_band_few_inverse<4, L, E, PL>)
 #define BAND_FEWI_E(L, E) (plain ? BAND_FEWI_C(L, E, true) : BAND_FEWI_C(L, E, false))
-            if (p->u_p_lag == 3) fk = lage == 1 ? BAND_FEWI_E(3, 1) : lage == 2 ? BAND_FEWI_E(3, 2) : BAND_FEWI_E(3, 3);
+            if (p->u_p_lag == 5) fk = BAND_FEWI_E(5, 5);
+            else if (p->u_p_lag == 3) fk = lage == 1 ? BAND_FEWI_E(3, 1) : lage == 2 ? BAND_FEWI_E(3, 2) : BAND_FEWI_E(3, 3);
             else fk = lage == 1 ? BAND_FEWI_E(2, 1) : BAND_FEWI_E(2, 2);
 #undef BAND_FEWI_E
 #undef BAND_FEWI_C

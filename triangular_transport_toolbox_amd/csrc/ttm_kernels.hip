@@ -3086,7 +3086,7 @@ int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fo
         return set_err(TTM_E_ARG, "ttm_inverse_table: bad arguments%s");
     if (p->monotonicity != TTM_MONO_SEPARABLE) return set_err(TTM_E_UNSUPPORTED, "table inverse needs separable monotonicity%s");
     // large ensembles of maps with hot records: resident-table kernel (components in blocks, tables resident in LDS)
-    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 4 && (p->u_h_ng == 2 || p->u_h_ng == 4) && all_fast(p, k0, k1) &&
+    if (u_on(p) && p->u_h_cls >= 1 && p->u_h_cls <= 4 && (p->u_h_ng == 2 || p->u_h_ng == 4 || p->u_p_lag > 2) && all_fast(p, k0, k1) &&
         h_y_affine && ldy == 0 && T <= 4096 && nb <= 65535 && N < ((int64_t)1 << 28) && !tuning().rt_off && !tuning().u_no_hot &&
         (N >= 64 * 1024 || tuning().u_loader == 1)) {                       // (small ensembles: the table load per workgroup does not pay;
                                                                             // option u_loader = 1 forces it)

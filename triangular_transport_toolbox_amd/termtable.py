@@ -811,9 +811,9 @@ def compile_map(monotone, nonmonotone, d_cols, polynomial_type='hermite function
 # ---- univariate form (include/ttm.h "U-form", csrc/ttm_uform.h) -----------------------------------------
 U_PMAX, U_TSTRIDE, U_NI_MAX, UC_LEN, UG_LEN = 10, 14, 128, 8, 8
 U_GSTRIDE = 24               # doubles per group in the U section: B[0..11], A[0..11]
-H_HDR, H_NG_MAX, H_GS = 8, 4, (0, 8, 16, 24, 24)
+H_HDR, H_NG_MAX, H_GS = 8, 5, (0, 8, 16, 24, 24)
 H_DB, H_DA = (0, 3, 5, 7, 10), (0, 1, 5, 7, 10)
-P_HDR, P_LAG_MAX, P_FEW_D = 8, 3, 4
+P_HDR, P_LAG_MAX, P_FEW_D = 8, 5, 4
 UCF_OWN, UGF_POLY = 1, 1 << 20
 U_KAPPA = 0.75                # spline interval width / smallest special-term scale (degree 11: fit error < 1e-14;
                               # 0.5: 3e-15, 0.9: 5e-14 - wider intervals = smaller tables to stream per sweep step)
@@ -892,18 +892,20 @@ def _compile_uform(cm, u_info, polyclass, separable):
     banded = cm.D >= 1 and all(int(ucomp[k, 0]) == kc0 + k for k in range(cm.D)) and all(lag >= 1 for lag in lags) and \
         (maxlag <= 2 or (maxlag <= P_LAG_MAX and few)) and \
         all((len(u['st_p0']) > 0 and not o) or (few and ol) for u, o, ol in zip(u_info, own, own_linear)) and \
-        any(len(u['st_p0']) > 0 for u in u_info)
+        (any(len(u['st_p0']) > 0 for u in u_info) or few)            # (no spline at all: the smoother's block map, linear monotone parts)
     # (a banded map of a few components whose groups do not all hit the planned column cache - a group three columns back,
     # conditioning columns in front of the first component - or with linear own terms still gets hot records: as the source of
     # its push records only, u_p_lag = 3 says so)
-    few_only = banded and few and (maxlag == 3 or not all_hit or any(own))
-    if ((all_hit and not any(own)) or few_only) and ng <= H_NG_MAX:
+    few_only = banded and few and (maxlag >= 3 or not all_hit or any(own))
+    # (the hot-record kernels are instantiated for 2 and 4 group records; five groups - the third component of the smoother's block
+    # map, example_07.py:368-408 - exist for maps of a few components, whose records only feed the push records)
+    if ((all_hit and not any(own)) or few_only) and ng <= (H_NG_MAX if few_only else 4):
         # (orders 8..10 - class 4, example_03.py:103 - exist for the kernels of maps with a few components only)
         cm.u_h_cls = 1 if (mb <= 3 and ma <= 1) else (2 if (mb <= 5 and ma <= 5) else (3 if (mb <= 7 and ma <= 7) else (4 if (banded and few) else 0)))
     if cm.u_h_cls:
-        cm.u_h_ng = 2 if ng <= 2 else 4            # the kernels are instantiated for 2 and 4 group records
+        cm.u_h_ng = 2 if ng <= 2 else (4 if ng <= 4 else H_NG_MAX)        # the kernels are instantiated for 2 and 4 group records
         if banded:
-            cm.u_p_lag = 3 if few_only else 2
+            cm.u_p_lag = (3 if maxlag <= 3 else P_LAG_MAX) if few_only else 2
             gp = H_DB[cm.u_h_cls] + 1 + H_DA[cm.u_h_cls]
             cm.u_p_stride = -(-(P_HDR + cm.u_p_lag * gp) // 8) * 8        # whole 64-byte lines
     uform_geometry(cm)
