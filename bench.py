@@ -288,11 +288,16 @@ def objective_roofline(torch, tm, workload, passes=3):
              'what': 'one objective + gradient evaluation of every component (sums over the whole ensemble), one launch each'}
         name, c = counted(kern)
         if c is not None:
-            flop = c['flop_per_launch'] * D * scale
+            # a pass launches one template instance per component (chunk count by coefficient count): the flop of a pass is the
+            # dispatch-weighted sum over the instances of the counting run, which ran whole passes only
+            inst = [v for k, v in counts.get('kernels', {}).items() if k.startswith(kern + '<') or k == kern]
+            launches = sum(v['dispatches'] or 0 for v in inst)
+            flop = (sum(v['flop_per_launch'] * (v['dispatches'] or 0) for v in inst) / launches * D if launches
+                    else c['flop_per_launch'] * D) * scale
             e.update(counted_kernel=name, flop_per_pass=flop, achieved=flop / (ms * 1e-3) / 1e12,
                      frac=flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, wait_any_frac=c.get('wait_any_frac'),
                      salu_per_valu=(c['salu_per_launch'] / c['valu_per_launch'] if c.get('valu_per_launch') else None),
-                     source='profiles/fp64_counts.json (rocprofv3 --pmc, counted; mean over the components of a pass)')
+                     source='profiles/fp64_counts.json (rocprofv3 --pmc, counted; dispatch-weighted over the template instances of a pass)')
         out['objective'] = e
         return out
     # separable: Gram pass

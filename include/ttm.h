@@ -371,11 +371,21 @@ int  ttm_device_count(int* count);
  * ttm_colstats: mean and ddof-0 standard deviation of every column of a
  *   row-major N x d host-layout matrix resident on the device.
  *   work: >= ttm_colstats_work_size(N, d) doubles.
+ *   Up to 8 columns and 131 072 rows: ONE launch (per-workgroup mean and squared deviations, combined in workgroup
+ *   order by the last workgroup; option `colstats_one` = 0: the four launches of the general shape).
+ * ttm_colstats_cols: the same moments of a COLUMN-major matrix Xcols[j*ld + n] that is already on the device (reset of
+ *   device-resident samples: no row-major copy); shapes outside the one-launch range: TTM_E_UNSUPPORTED (export, then
+ *   ttm_colstats).  Same sums, same bits, as ttm_colstats of the row-major copy.
+ * ttm_standardize_cols: Xs[j*ldx + n] = (Xcols[j*ld + n] - mean[j]) / std[j].
  * ttm_import:  Xsoa[j*ldx + n] = (Xrow[n*d + j] - mean[j]) / std[j]   (mean/std NULL: plain transpose)
  * ttm_export:  Xrow[n*dout + j] = Xsoa[(j0+j)*ldx + n] * std[j0+j] + mean[j0+j]          */
 int64_t ttm_colstats_work_size(int64_t N, int32_t d);
 int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double* std,
                  double* work, void* stream);
+int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* std,
+                      double* work, void* stream);
+int ttm_standardize_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, const double* mean,
+                         const double* std, double* Xs, int64_t ldx, void* stream);
 int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, const double* std,
                double* Xsoa, int64_t ldx, void* stream);
 int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t dout,
@@ -385,7 +395,10 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
  * np.quantile (method 'linear') of TM:775-778 (quantile standardisation) and TM:2266-2296 (special-term
  * centres) interpolates between two order statistics; this entry point returns them exactly:
  * out[j] = ranks[j]-th smallest value of col[0..N) (0-based).  ranks: device int64[nr], nr <= 16.
- * work: device, ttm_select_work_size(nr) bytes.  Eight histogram passes over the column, no host sync. */
+ * work: device scratch, ttm_select_work_size(nr) bytes, no initial state needed.  Eight histogram passes over the column, no
+ * host sync: columns of up to 131 072 rows in ONE launch (k_select_coop: the keys stay in registers, the <= 64 workgroups meet
+ * at a grid barrier per pass - every wait bounded, workgroup 0 finishes alone if its partners do not arrive -; option
+ * `select_coop` = 0 switches it off), longer columns and sharded ones as 17 launches. */
 int64_t ttm_select_work_size(int32_t nr);
 int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out,
                          void* work, void* stream);
@@ -546,6 +559,17 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
 int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_coef_k, const double* Xsoa,
                               int64_t ldx, int64_t N, double* work, uint32_t* counter, double* out, double* flag,
                               double mark, void* stream);
+/* The same evaluation with SELF-VALIDATING sums for grids of up to 128 workgroups (N <= 131 072) - no ticket, no fence, no
+ * mark: ttm_sentinel_fill arms the rows of partial sums in `work` once (every slot a signalling-NaN pattern no arithmetic
+ * produces; TTM_E_UNSUPPORTED: the grid is larger, take the marked call); ttm_objective_sep_cached_sent evaluates, the
+ * workgroup that finishes polls the slots of the others, leaves them armed again, and writes the 1 + m sums to out_host -
+ * page-locked host memory whose slots the CALLER has armed with the same pattern (0x7FF4DEADBEEF0001) and polls until none
+ * holds it; 0x7FF4DEADBEEF0002 in a slot: the device gave up waiting (csrc/ttm_optim.cpp: arm_values / poll_values).   */
+int ttm_sentinel_fill(double* work, int32_t m, int64_t N, void* stream);
+int ttm_objective_sep_cached_sent(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
+                                  double delta, double* work, double* out_host, void* stream);
+int ttm_objective_sep_direct_sent(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
+                                  const double* h_coef_mon, double delta, double* work, double* out_host, void* stream);
 int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
                                     double delta, double* work, uint32_t* counter, double* out, double* flag,
                                     double mark, void* stream);

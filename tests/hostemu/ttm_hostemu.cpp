@@ -266,6 +266,27 @@ int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double*
     return 0;
 }
 
+int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double*, void*) {
+    if (d > 8 || N > 131072) return TTM_E_UNSUPPORTED;            // (the device library's one-launch range)
+    for (int j = 0; j < d; ++j) {
+        const double* c = Xcols + (int64_t)j * ld;
+        double s = 0.0;
+        for (int64_t n = 0; n < N; ++n) s += c[n];
+        mean[j] = s / (double)N;
+        double q = 0.0;
+        for (int64_t n = 0; n < N; ++n) { const double v = c[n] - mean[j]; q += v * v; }
+        sd[j] = sqrt(q / (double)N);
+    }
+    return 0;
+}
+
+int ttm_standardize_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, const double* mean, const double* sd, double* Xs,
+                         int64_t ldx, void*) {
+    for (int j = 0; j < d; ++j)
+        for (int64_t n = 0; n < N; ++n) Xs[(int64_t)j * ldx + n] = (Xcols[(int64_t)j * ld + n] - mean[j]) / sd[j];
+    return 0;
+}
+
 int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, const double* sd, double* Xsoa, int64_t ldx, void*) {
     for (int64_t n = 0; n < N; ++n)
         for (int j = 0; j < d; ++j) {
@@ -717,6 +738,17 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
     if (!rc && flag) *flag = mark;
     return rc;
 }
+// (the device library's evaluation with self-validating sums: the double has nothing to wait for and declines - the loops
+// of csrc/ttm_optim.cpp then take the marked call)
+int ttm_sentinel_fill(double*, int32_t, int64_t, void*) { return TTM_E_UNSUPPORTED; }
+int ttm_objective_sep_cached_sent(const double*, int64_t, int64_t, int32_t, const double*, double, double*, double*, void*) {
+    return TTM_E_UNSUPPORTED;
+}
+int ttm_objective_sep_direct_sent(const double*, int64_t, int32_t, const int32_t*, const double*, const double*, double, double*, double*,
+                                  void*) {
+    return TTM_E_UNSUPPORTED;
+}
+
 int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
                                     double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
     const int rc = ttm_objective_sep_cached(dPsi, ldp, N, m, h_coef_mon, delta, work, counter, out, stream);

@@ -29,14 +29,21 @@ def small_map(**kw):
                          quadrature_input={'order': 5}, **kw)
 
 
-def test_order_statistics_exact(backend):
+@pytest.mark.parametrize('coop', [-1, 0])
+def test_order_statistics_exact(backend, ttm_opt, coop):
+    # coop -1: columns of up to 131 072 rows through the one-launch select (k_select_coop: keys in registers, a grid barrier
+    # per pass), longer ones through the 17 launches; 0: the launches for every length
+    ttm_opt('select_coop', coop)
     tm = small_map()
     rng = np.random.default_rng(1)
-    for n in (1, 2, 17, 1000, 100003):
+    for n in (1, 2, 17, 1000, 2048, 2049, 100003, 131072, 131073):
         x = rng.standard_normal(n) * 5
         x[rng.integers(0, n, max(n // 10, 1))] = x[0]               # ties
         if n > 10:
             x[:3] = [0.0, -0.0, 1e-310]
+            x[3:7] = [np.inf, -np.inf, -1e-310, 1e300]
+        if n == 2048:
+            x[:] = 1.25                                             # one value only
         xs = np.sort(x)
         ranks = np.unique(np.clip(rng.integers(0, n, 20), 0, n - 1))
         ranks = np.unique(np.concatenate((ranks, [0, n - 1])))

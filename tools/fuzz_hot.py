@@ -55,6 +55,22 @@ for seed in range(lo, hi):
         e4 = relerr(om.map(Xi[sub][fin]), om.map(Xo[fin]))
         bad = e1 > 1e-11 or e2 > 1e-9 or (e3 > 1e-9 and e4 > 1e-10)   # (targets outside a table's range are left out)
         print(('FAIL ' if bad else 'ok   ') + tag, 'map %.1e pullback %.1e inverse %.1e (through S: %.1e)' % (e1, e2, e3, e4), flush=True)
+        if bad and len(sys.argv) > 3 and sys.argv[3] == 'paths':
+            # the same inverse on the other kernel paths (is the distance the oracle's table conditioning or one kernel's?)
+            import ctypes
+            lib = tm._lib
+            lib.ttm_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+            lib.ttm_last_kernel.restype = ctypes.c_char_p
+            for opts in (dict(band_inv=0), dict(band_inv=0, rt_off=1), dict(no_uform=1), dict(no_plan=1, no_uform=1)):
+                for kk, vv in opts.items():
+                    lib.ttm_set_option(kk.encode(), int(vv))
+                tm._epoch += 1
+                tm._pack_memo = None
+                Xj = tm.inverse_map(Zin)
+                kern = lib.ttm_last_kernel().decode()
+                lib.ttm_reset_options()
+                print('     ', opts, kern, 'inverse %.1e (through S: %.1e) vs default path %.1e' %
+                      (relerr(Xj[sub][fin], Xo[fin]), relerr(om.map(Xj[sub][fin]), om.map(Xo[fin])), relerr(Xj[sub][fin], Xi[sub][fin])), flush=True)
         fails += bad
     except Exception as exc:          # noqa: BLE001
         fails += 1

@@ -56,6 +56,8 @@ _SIGNATURES = {
     'ttm_device_count': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     'ttm_colstats_work_size': (c_i64, [c_i64, c_i32]),
     'ttm_colstats': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_colstats_cols': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'ttm_standardize_cols': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ttm_import': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'ttm_export': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'ttm_select_work_size': (c_i64, [c_i32]),
@@ -84,6 +86,9 @@ _SIGNATURES = {
     'ttm_objective_host': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_host_marked': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
+    'ttm_sentinel_fill': (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
+    'ttm_objective_sep_cached_sent': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp]),
+    'ttm_objective_sep_direct_sent': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached_marked': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_objective_sep_direct_marked': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
@@ -149,6 +154,9 @@ def load():
 
 class TTMError(RuntimeError):
     pass
+
+
+TTM_E_UNSUPPORTED = -4           # (include/ttm.h: "not for this shape / map - take the general path")
 
 
 def check(rc):

@@ -226,6 +226,112 @@ __global__ __launch_bounds__(64) void k_colfinish(const double* __restrict__ par
     }
 }
 
+// Column moments of up to 8 columns and 131 072 rows in ONE launch (the filter's ensembles; the four launches above are 34 us
+// of an update and leave 60 of 64 lanes idle at d = 4): a thread keeps its <= 4 rows in registers, the workgroup takes its own
+// mean and the squared deviations from it (two passes over registers), and the workgroup that draws the last ticket combines the
+// rows {count, mean_b, M2_b} of all workgroups (Chan et al.: M2 = sum M2_b + count_b (mean_b - mean)^2) in workgroup order - no
+// cancellation whatever the offset of the data, run-to-run deterministic.  COLS: column-major input X[j ld + n], else row-major
+// X[n D + j]; both layouts make the same sums.  counter: one uint32, zero (the host clears it in front of the launch).
+#define TTM_CS1_ROWS 4
+#define TTM_CS1_DMAX 8
+#define TTM_CS1_WGS 128
+
+template <int D, bool COLS>
+__global__ __launch_bounds__(256) void k_colstats_one(const double* __restrict__ X, int64_t ld, int64_t N, double* __restrict__ partial,
+                                                      unsigned int* __restrict__ counter, double* __restrict__ mean, double* __restrict__ sd) {
+    constexpr int NS = 1 + 2 * D;
+    __shared__ double red[4][D + 1];
+    __shared__ double mb[D + 1];
+    __shared__ double all[TTM_CS1_WGS * NS];
+    __shared__ int verdict;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double v[TTM_CS1_ROWS][D];
+    bool have[TTM_CS1_ROWS];
+#pragma unroll
+    for (int r = 0; r < TTM_CS1_ROWS; ++r) {
+        const int64_t n = ((int64_t)r * gridDim.x + blockIdx.x) * 256 + tid;
+        have[r] = n < N;
+#pragma unroll
+        for (int j = 0; j < D; ++j) v[r][j] = have[r] ? (COLS ? X[(int64_t)j * ld + n] : X[n * D + j]) : 0.0;
+    }
+    double s[D + 1];
+#pragma unroll
+    for (int j = 0; j <= D; ++j) s[j] = 0.0;
+#pragma unroll
+    for (int r = 0; r < TTM_CS1_ROWS; ++r)
+        if (have[r]) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s[j] += v[r][j];
+            s[D] += 1.0;
+        }
+#pragma unroll
+    for (int j = 0; j <= D; ++j) {
+        const double t = wave_sum(s[j]);
+        if (lane == 0) red[wv][j] = t;
+    }
+    __syncthreads();
+    if (tid <= D) {
+        const double cnt = (red[0][D] + red[1][D]) + (red[2][D] + red[3][D]);
+        const double tot = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        mb[tid] = tid < D ? tot / cnt : cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) s[j] = 0.0;
+#pragma unroll
+    for (int r = 0; r < TTM_CS1_ROWS; ++r)
+        if (have[r]) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) { const double dl = v[r][j] - mb[j]; s[j] += dl * dl; }
+        }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        const double t = wave_sum(s[j]);
+        if (lane == 0) red[wv][j] = t;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        const int j = tid - 1 - D;
+        const double val = tid == 0 ? mb[D] : tid <= D ? mb[tid - 1] : (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+        coherent_store(partial + (int64_t)blockIdx.x * NS + tid, val);
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) verdict = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1 : 0;
+    __syncthreads();
+    if (!verdict) return;
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nb = (int)gridDim.x;
+    for (int i = tid; i < nb * NS; i += 256) all[i] = coherent_load(partial + i);
+    __syncthreads();
+    // column j by wave j mod 4: lanes = workgroups (a serial walk over 98 rows of LDS costs more than the rest of the kernel)
+    for (int j = wv; j < D; j += 4) {
+        double sw = 0.0;
+        for (int b = lane; b < nb; b += 64) sw += all[b * NS] * all[b * NS + 1 + j];
+        const double mu = __shfl(wave_sum(sw), 0, 64) / (double)N;
+        double m2 = 0.0;
+        for (int b = lane; b < nb; b += 64) {
+            const double dl = all[b * NS + 1 + j] - mu;
+            m2 += all[b * NS + 1 + D + j] + all[b * NS] * (dl * dl);
+        }
+        m2 = wave_sum(m2);
+        if (lane == 0) {
+            mean[j] = mu;
+            sd[j] = sqrt(m2 / (double)N);
+        }
+    }
+}
+
+// Xs[j ldx + n] = (X[j ld + n] - mean[j]) / sd[j]: standardisation of a column-major matrix that is already on the device
+__global__ __launch_bounds__(256) void k_standardize_cols(const double* __restrict__ X, int64_t ld, int64_t N, int d,
+                                                          const double* __restrict__ mean, const double* __restrict__ sd,
+                                                          double* __restrict__ Xs, int64_t ldx) {
+    const int j = blockIdx.y;
+    const double mu = mean[j], sg = sd[j];
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256)
+        Xs[(int64_t)j * ldx + n] = (X[(int64_t)j * ld + n] - mu) / sg;
+}
+
 // ---------------------------------------------------------------------------
 // K9: exact order statistics by radix select (8 passes of 8 bits over order-preserving 64-bit keys)
 // state per requested rank: prefix (determined high bits), remaining rank; hist: nr x 256 counters
@@ -298,6 +404,201 @@ __global__ __launch_bounds__(256) void k_select_pick(int nr, int shift, SelState
         }
     }
     h[t] = 0u;
+}
+
+// The same select in ONE launch for columns of up to 131 072 rows (the filter's ensembles: the 17 launches above are 117 us of
+// an update, each pass a launch floor).  Every thread keeps its <= 8 keys in registers, the workgroups meet at a grid barrier
+// per pass (agent-scope atomics; at most 64 workgroups of 256 threads: one per CU on a quarter of the chip), and every
+// workgroup picks the bins itself from the summed histogram.  Ranks that still share a prefix share a histogram row (the two
+// neighbours a quantile interpolates between do until the last passes).  As soon as every rank's bin holds at most 32 keys
+// (three passes for 1e5 values of a continuous distribution) the passes end: the keys of those bins are gathered into lists
+// and workgroup 0 ranks them by counting - four barriers instead of eight (a pass is four device-scope round trips, ~11 us).
+//   ghist: three regions of TTM_SEL_MAX x 256 counters - pass p adds into region p % 3 and clears region (p + 1) % 3, which
+//          was last read before barrier p - 1;
+//   bar:   [0] arrivals, monotone within a launch, [16 + j] length of candidate list j; bar and region 0 are cleared by the
+//          host (ONE memset node in front of the launch: `work` needs no initial state, and a launch that was cut short leaves
+//          nothing behind);
+//   cand:  TTM_SEL_MAX lists of 32 keys.
+// Every wait is bounded: a workgroup whose partners do not arrive (a grid that is not co-resident because someone else holds
+// the CUs) stops waiting; workgroup 0 then does the selection by itself from the column in memory (select_solo) - slower,
+// same result -, so the grid always drains and `out` is always the exact order statistic.
+#define TTM_SELC_ROWS 8
+#define TTM_SELC_WGS 64
+#define TTM_SELC_SPINS (1 << 17)
+#define TTM_SELC_CAND 32
+
+__device__ __forceinline__ void coherent_store_u32(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int coherent_load_u32(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// all threads of the workgroup call; wait = false: arrive only.  false: the others did not arrive within the bound
+__device__ __forceinline__ bool grid_barrier(unsigned int* bar, unsigned int target, int* verdict, bool wait = true) {
+    drain_stores();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = wait ? 0 : 1;
+        for (int spin = 0; wait && spin < TTM_SELC_SPINS; ++spin)
+            if (coherent_load_u32(bar) >= target) { ok = 1; break; }
+        *verdict = ok;
+    }
+    __syncthreads();
+    return *verdict != 0;
+}
+
+// bin of rank j from histogram row h (256 counters, read by `load`): one wave, four bins per lane; the lane that holds the
+// bin updates prefix and remaining rank (the guard of k_select_pick: a rank beyond the total lands in the last bin) and
+// notes how many keys the bin holds
+template <typename Load>
+__device__ __forceinline__ void wave_pick(Load load, int shift, unsigned long long* pf, long long* rk, long long* held) {
+    const int lane = threadIdx.x & 63;
+    long long c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c[q] = (long long)load(lane * 4 + q);
+    const long long mine = (c[0] + c[1]) + (c[2] + c[3]);
+    long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    const long long total = __shfl(incl, 63, 64);
+    const long long r = *rk;
+    long long before = incl - mine;
+    const bool here = (r >= before && r < incl) || (lane == 63 && r >= total);
+    // (every lane has read *rk before any lane writes it: the wave runs in lock step, and the writes sit behind the reads)
+    if (here) {
+        int q = 0;
+        while (q < 3 && r >= before + c[q]) { before += c[q]; ++q; }
+        *rk = r - before;
+        *pf = *pf | ((unsigned long long)(lane * 4 + q) << shift);
+        *held = c[q];
+    }
+}
+
+__device__ __forceinline__ double key_f64(unsigned long long pfx) {
+    const unsigned long long u = (pfx >> 63) ? (pfx & 0x7fffffffffffffffull) : ~pfx;
+    return __longlong_as_double((long long)u);
+}
+
+// the whole selection by ONE workgroup from the column in memory (the fallback of k_select_coop)
+__device__ void select_solo(const double* __restrict__ col, int64_t N, const long long* __restrict__ ranks, int nr,
+                            unsigned int* lh, unsigned long long* pf, long long* rk, long long* held, double* __restrict__ out) {
+    const int tid = threadIdx.x, wv = tid >> 6;
+    __syncthreads();
+    if (tid < nr) { pf[tid] = 0ull; rk[tid] = ranks[tid]; }
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        for (int i = tid; i < nr * 256; i += blockDim.x) lh[i] = 0u;
+        __syncthreads();
+        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+        for (int64_t n = tid; n < N; n += blockDim.x) {
+            const unsigned long long key = f64_key(col[n]);
+            const unsigned int bin = (unsigned int)((key >> shift) & 255ull);
+            for (int j = 0; j < nr; ++j)
+                if (((key ^ pf[j]) & himask) == 0ull) atomicAdd(&lh[j * 256 + bin], 1u);
+        }
+        __syncthreads();
+        for (int j = wv; j < nr; j += (int)(blockDim.x >> 6)) {
+            const unsigned int* h = lh + j * 256;
+            wave_pick([&](int b) { return h[b]; }, shift, pf + j, rk + j, held + j);
+        }
+        __syncthreads();
+    }
+    if (tid < nr) out[tid] = key_f64(pf[tid]);
+}
+
+__global__ __launch_bounds__(256) void k_select_coop(const double* __restrict__ col, int64_t N, const long long* __restrict__ ranks,
+                                                     int nr, unsigned int* __restrict__ ghist, unsigned int* __restrict__ bar,
+                                                     unsigned long long* __restrict__ cand, double* __restrict__ out) {
+    __shared__ unsigned int lh[TTM_SEL_MAX * 256];
+    __shared__ unsigned long long pf[TTM_SEL_MAX];
+    __shared__ long long rk[TTM_SEL_MAX];
+    __shared__ long long held[TTM_SEL_MAX];    // keys in the bin the rank was found in
+    __shared__ int rep[TTM_SEL_MAX];           // first rank with the same prefix (its histogram row)
+    __shared__ int verdict;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned int nb = gridDim.x;
+    constexpr int REG = TTM_SEL_MAX * 256;
+    unsigned long long key[TTM_SELC_ROWS];
+    bool have[TTM_SELC_ROWS];
+#pragma unroll
+    for (int r = 0; r < TTM_SELC_ROWS; ++r) {
+        const int64_t n = ((int64_t)r * nb + blockIdx.x) * 256 + tid;
+        have[r] = n < N;
+        key[r] = have[r] ? f64_key(col[n]) : 0ull;
+    }
+    if (tid < nr) { pf[tid] = 0ull; rk[tid] = ranks[tid]; rep[tid] = 0; held[tid] = N; }
+    unsigned int* ncand = bar + 16;
+    bool alive = true;
+    int gather_shift = -1;                     // >= 0: the passes ended early; bits >= gather_shift of every rank are known
+    unsigned int arrivals = 0;
+    for (int pass = 0; pass < 8 && alive; ++pass) {
+        const int shift = 56 - 8 * pass;
+        for (int i = tid; i < nr * 256; i += 256) lh[i] = 0u;
+        __syncthreads();
+        const unsigned long long himask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+#pragma unroll
+        for (int r = 0; r < TTM_SELC_ROWS; ++r) {
+            if (!have[r]) continue;
+            const unsigned int bin = (unsigned int)((key[r] >> shift) & 255ull);
+            for (int j = 0; j < nr; ++j)
+                if (rep[j] == j && ((key[r] ^ pf[j]) & himask) == 0ull) atomicAdd(&lh[j * 256 + bin], 1u);
+        }
+        __syncthreads();
+        unsigned int* mine = ghist + (pass % 3) * REG;
+        unsigned int* next = ghist + ((pass + 1) % 3) * REG;
+        for (int i = tid; i < nr * 256; i += 256)
+            if (lh[i]) __hip_atomic_fetch_add(mine + i, lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = blockIdx.x * 256 + tid; i < nr * 256; i += (int)nb * 256) coherent_store_u32(next + i, 0u);
+        arrivals += nb;
+        alive = grid_barrier(bar, arrivals, &verdict);
+        if (!alive) break;
+        for (int j = wv; j < nr; j += 4) {
+            const unsigned int* h = mine + rep[j] * 256;
+            wave_pick([&](int b) { return coherent_load_u32(h + b); }, shift, pf + j, rk + j, held + j);
+        }
+        __syncthreads();
+        if (tid < nr) {
+            int first = tid;
+            for (int i = tid - 1; i >= 0; --i)
+                if (pf[i] == pf[tid]) first = i;
+            rep[tid] = first;
+        }
+        __syncthreads();
+        long long most = 0;
+        for (int j = 0; j < nr; ++j) most = held[j] > most ? held[j] : most;
+        if (shift > 0 && most <= TTM_SELC_CAND) { gather_shift = shift; break; }
+    }
+    if (alive && gather_shift >= 0) {
+        // the keys of the bins the ranks were found in, list by list (a list per distinct prefix), then workgroup 0 ranks them
+        const unsigned long long known = ~0ull << gather_shift;
+#pragma unroll
+        for (int r = 0; r < TTM_SELC_ROWS; ++r) {
+            if (!have[r]) continue;
+            for (int j = 0; j < nr; ++j)
+                if (rep[j] == j && ((key[r] ^ pf[j]) & known) == 0ull) {
+                    const unsigned int slot = __hip_atomic_fetch_add(ncand + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (slot < TTM_SELC_CAND) __hip_atomic_store(cand + j * TTM_SELC_CAND + slot, key[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        arrivals += nb;
+        alive = grid_barrier(bar, arrivals, &verdict, blockIdx.x == 0);
+        if (alive && blockIdx.x == 0) {
+            for (int j = wv; j < nr; j += 4) {
+                const int list = rep[j];
+                const int nc = (int)held[list];
+                const unsigned long long k = lane < nc ? __hip_atomic_load(cand + list * TTM_SELC_CAND + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+                int pos = 0;
+                for (int l = 0; l < nc; ++l) {
+                    const unsigned long long kl = __shfl(k, l, 64);
+                    pos += (kl < k || (kl == k && l < lane)) ? 1 : 0;
+                }
+                if (lane < nc && pos == (int)rk[j]) out[j] = key_f64(k);
+            }
+        }
+    } else if (alive && blockIdx.x == 0) {
+        if (tid < nr) out[tid] = key_f64(pf[tid]);
+    }
+    if (!alive && blockIdx.x == 0) select_solo(col, N, ranks, nr, lh, pf, rk, held, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -2057,6 +2358,68 @@ __global__ __launch_bounds__(64) void k_fold_host(DevProg P, int k, HostCoef hc,
     fold_st8(P.fdesc + k * TTM_FDESC_LEN, P.fints, fold, threadIdx.x, blockDim.x);
 }
 
+// The evaluation of a host optimiser loop with NO ticket, NO fence and NO completion mark (grids of up to 128 workgroups: the
+// filter's ensembles, where an evaluation is a chain of device-scope round trips - drain the stores, draw a ticket, two batches
+// of loads, drain the results, the mark: 8.9 us of which 3 are arithmetic).  The rows of partial sums are SELF-VALIDATING: every
+// slot holds a signalling-NaN pattern no arithmetic produces (TTM_SENT_BITS) until its workgroup stores the sum - one 8-byte
+// agent-scope store, whole or absent.  Workgroup 0 stores its own row and then polls the others' slots until none holds the
+// pattern (every wait bounded), adds the rows in a fixed order (wave i mod 4 takes sum i: lanes = rows, DPP-free shuffle sum),
+// hands the slots back with the pattern in them for the next evaluation, and writes the results to `out` - page-locked host
+// memory whose slots the HOST has filled with the same pattern and polls the same way (csrc/ttm_optim.cpp: poll_values), so
+// no mark and no drain in front of it.  A wait that runs out writes TTM_SENT_FAIL instead (the host then fails the loop).
+// partial: gridDim.x rows of 1 + M slots, all TTM_SENT_BITS at entry (ttm_sentinel_fill before the first evaluation), and at exit.
+#define TTM_SENT_BITS 0x7FF4DEADBEEF0001ull
+#define TTM_SENT_FAIL 0x7FF4DEADBEEF0002ull
+#define TTM_SENT_WGS 128
+#define TTM_SENT_SPINS (1 << 16)
+
+// (all threads of workgroup 0 call, behind the coherent_store of its own row; all: LDS, gridDim.x x nacc doubles; fin: nacc)
+__device__ __forceinline__ void sentinel_finish(double* __restrict__ partial, int nacc, double* all, double* fin, double* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int total = (int)gridDim.x * nacc;
+    bool done = false;
+    for (int spin = 0; spin < TTM_SENT_SPINS && !done; ++spin) {
+        int ok = 1;
+        for (int i = tid; i < total; i += (int)blockDim.x) {
+            const double v = coherent_load(partial + i);
+            all[i] = v;
+            ok &= (unsigned long long)__double_as_longlong(v) != TTM_SENT_BITS ? 1 : 0;
+        }
+        done = __syncthreads_and(ok) != 0;
+    }
+    const double sent = __longlong_as_double((long long)TTM_SENT_BITS);
+    for (int i = tid; i < total; i += (int)blockDim.x) coherent_store(partial + i, sent);           // (the slots of the next evaluation)
+    if (!done) {
+        if (tid < nacc) __hip_atomic_store(out + tid, __longlong_as_double((long long)TTM_SENT_FAIL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // the order of add_rows / finish_sums (csrc/ttm_dev.h), so that both finishes make the same bits: wave w adds rows w, w + nw,
+    // ... alternately into two accumulators, then the waves' sums in wave order
+    const int nw = (int)(blockDim.x >> 6);
+    __syncthreads();                                  // (`all` is complete; fin doubles as the waves' scratch rows below)
+    double mine = 0.0;
+    if (lane < nacc) {
+        double a0 = 0.0, a1 = 0.0;
+        int r = wv;
+        for (; r + nw < (int)gridDim.x; r += 2 * nw) { a0 += all[r * nacc + lane]; a1 += all[(r + nw) * nacc + lane]; }
+        if (r < (int)gridDim.x) a0 += all[r * nacc + lane];
+        mine = a0 + a1;
+    }
+    __syncthreads();                                  // (everybody has read `all`: its head is reused for the waves' sums)
+    if (lane < nacc) all[wv * nacc + lane] = mine;
+    __syncthreads();
+    if (tid < nacc) {
+        double v = 0.0;
+        for (int w = 0; w < nw; ++w) v += all[w * nacc + tid];
+        fin[tid] = v;
+        __hip_atomic_store(out + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fill_bits(unsigned long long* __restrict__ p, int n, unsigned long long bits) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = bits;
+}
+
 // Separable objective from a cached derivative basis (TM:2978-3018 with the der_Psi_mon the reference precalculates,
 // TM:789-821): dPsi is m rows of N doubles (ttm_basis(which = 2)), constant while a component is optimised, so one
 // evaluation is a streaming pass: dS = dPsi.c + delta rowsum(dPsi); acc[0] += log dS, acc[1+i] += dPsi_i / dS.
@@ -2068,7 +2431,7 @@ template <int M>
 __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __restrict__ dPsi, int64_t ldp, int64_t N,
                                                               SepCoef hc, double delta, double* __restrict__ partial,
                                                               unsigned int* __restrict__ counter, double* __restrict__ out,
-                                                              double* flag, double mark) {
+                                                              double* flag, double mark, int sentinel) {
     // M is a template parameter: the M column loads of a row are issued together (a run-time `i < m` guard per load
     // made every load wait for the one before it: 77 us per launch at N = 1e6, m = 4 - 0.4 TB/s), two rows per
     // pass of the loop are independent chains
@@ -2113,6 +2476,12 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     __syncthreads();
     const int nacc = 1 + M;
     if (tid < nacc) coherent_store(partial + (int64_t)blockIdx.x * nacc + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    if (sentinel) {                                   // self-validating rows: workgroup 0 polls them (sentinel_finish)
+        __shared__ double all_s[TTM_SENT_WGS * (M + 1)];
+        __shared__ double fin_s[M + 1];
+        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out);
+        return;
+    }
     drain_stores();
     // counter != nullptr: the workgroup that draws the last ticket finishes (grids of up to 128 workgroups; the partial sums
     // travel as agent-scope stores / loads, no fence - csrc/ttm_dev.h: finish_sums); nullptr: a second launch does
@@ -2131,7 +2500,7 @@ template <int M>
 __global__ __launch_bounds__(256) void k_objective_sep_direct(const double* __restrict__ xk, int64_t N, const int* __restrict__ kinds,
                                                               const double* __restrict__ pars, SepCoef hc, double delta,
                                                               double* __restrict__ partial, unsigned int* __restrict__ counter,
-                                                              double* __restrict__ out, double* flag, double mark) {
+                                                              double* __restrict__ out, double* flag, double mark, int sentinel) {
     __shared__ double et[TTM_ERF_TABLE_LEN];
     __shared__ double red[4][M + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -2188,6 +2557,12 @@ __global__ __launch_bounds__(256) void k_objective_sep_direct(const double* __re
     __syncthreads();
     const int nacc = 1 + M;
     if (tid < nacc) coherent_store(partial + (int64_t)blockIdx.x * nacc + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+    if (sentinel) {                                   // (as k_objective_sep_cached: the same finish, the same bits)
+        __shared__ double all_s[TTM_SENT_WGS * (M + 1)];
+        __shared__ double fin_s[M + 1];
+        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out);
+        return;
+    }
     drain_stores();
     if (counter) {
         __shared__ double fin[M + 1];
@@ -2436,7 +2811,10 @@ static const DeviceInfo& device_info() {
     X(int_chunks, -1)    /* > 0: component chunks of the dense integrated forward kernel (default: planned from the ensemble size) */ \
     X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
     X(table_fused, -1)   /* 0: inverse tables as two launches (k_table_build, k_table_index) instead of one               */ \
-    X(setup_fused, -1)   /* 0: ttm_setup_staged declines (the caller then launches ttm_fold_staged and the table kernel)           */
+    X(setup_fused, -1)   /* 0: ttm_setup_staged declines (the caller then launches ttm_fold_staged and the table kernel)           */ \
+    X(select_coop, -1)   /* 0: order statistics by 17 launches (k_select_hist / k_select_pick) whatever the column length          */ \
+    X(colstats_one, -1)  /* 0: column moments by four launches (k_colsum / k_colfinish) whatever the shape                        */ \
+    X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid        */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -2536,8 +2914,34 @@ static int pick_block(int nslots, int extra_doubles, int ns = 1) {
     return 0;
 }
 
+// the one-launch moments (k_colstats_one) when they apply: 0 launched, 1 not applicable
+template <bool COLS>
+static int colstats_one(const double* X, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double* work, hipStream_t s) {
+    if (d > TTM_CS1_DMAX || N > (int64_t)TTM_CS1_WGS * 256 * TTM_CS1_ROWS || tuning().colstats_one == 0) return 1;
+    typedef void (*kern_t)(const double*, int64_t, int64_t, double*, unsigned int*, double*, double*);
+    static const kern_t kerns[TTM_CS1_DMAX] = {k_colstats_one<1, COLS>, k_colstats_one<2, COLS>, k_colstats_one<3, COLS>, k_colstats_one<4, COLS>,
+                                               k_colstats_one<5, COLS>, k_colstats_one<6, COLS>, k_colstats_one<7, COLS>, k_colstats_one<8, COLS>};
+    unsigned int* counter = (unsigned int*)work;                     // work: [ticket (16 bytes) | rows of partial results]
+    if (hipMemsetAsync(counter, 0, 4, s) != hipSuccess) return set_err(TTM_E_HIP, "ttm_colstats: hipMemsetAsync failed%s");
+    const int nb = (int)((N + 256 * TTM_CS1_ROWS - 1) / (256 * TTM_CS1_ROWS));
+    hipLaunchKernelGGL(kerns[d - 1], dim3(nb), dim3(256), 0, s, X, ld, N, work + 2, counter, mean, sd);
+    return check_launch("k_colstats_one") == TTM_OK ? 0 : TTM_E_HIP;
+}
+
 static int select_passes(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, SelState* st, unsigned int* hist,
                          ttm_comm* comm, hipStream_t s) {
+    if (!comm && tuning().select_coop != 0 && N <= (int64_t)TTM_SELC_WGS * 256 * TTM_SELC_ROWS) {
+        // one launch: keys in registers, a grid barrier per pass (k_select_coop); the barrier words and the three histogram
+        // regions sit behind the multi-launch state in `work`
+        unsigned int* bar = hist + TTM_SEL_MAX * 256;                     // 32 words: arrivals, candidate-list lengths
+        unsigned int* ghist = bar + 32;                                   // three regions; the first one is cleared with `bar`
+        unsigned long long* cand = (unsigned long long*)(ghist + 3 * TTM_SEL_MAX * 256);
+        const int nb = (int)((N + 256 * TTM_SELC_ROWS - 1) / (256 * TTM_SELC_ROWS));
+        if (hipMemsetAsync(bar, 0, (32 + TTM_SEL_MAX * 256) * 4, s) != hipSuccess)
+            return set_err(TTM_E_HIP, "ttm_order_statistics: hipMemsetAsync failed%s");
+        hipLaunchKernelGGL(k_select_coop, dim3(nb), dim3(256), 0, s, col, N, (const long long*)ranks, (int)nr, ghist, bar, cand, out);
+        return check_launch("k_select_coop");
+    }
     hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
     const int nb = N > 0 ? grid_for(N, 256 * 8) : 0;
     for (int shift = 56; shift >= 0; shift -= 8) {
@@ -2597,11 +3001,17 @@ int ttm_device_count(int* count) {
     return n > 0 ? TTM_OK : TTM_E_HIP;
 }
 
-int64_t ttm_colstats_work_size(int64_t N, int32_t d) { (void)N; return (int64_t)TTM_STAT_BLOCKS * d; }
+int64_t ttm_colstats_work_size(int64_t N, int32_t d) {
+    (void)N;        // the four-launch path: TTM_STAT_BLOCKS rows of d sums; the one-launch path: a ticket + 128 rows of 1 + 2 d
+    const int64_t a = (int64_t)TTM_STAT_BLOCKS * d, b = 2 + (int64_t)TTM_CS1_WGS * (1 + 2 * TTM_CS1_DMAX);
+    return a > b ? a : b;
+}
 
 int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double* sd, double* work, void* stream) {
     if (!Xrow || !mean || !sd || !work || N < 1 || d < 1) return set_err(TTM_E_ARG, "ttm_colstats: bad arguments%s");
     hipStream_t s = (hipStream_t)stream;
+    const int one = colstats_one<false>(Xrow, d, N, d, mean, sd, work, s);
+    if (one <= 0) return one;
     int nb = (int)((N + 3) / 4 < TTM_STAT_BLOCKS ? (N + 3) / 4 : TTM_STAT_BLOCKS);
     dim3 grid(nb, (d + 63) / 64);
     hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, Xrow, N, (int)d, (const double*)nullptr, work);
@@ -2609,6 +3019,21 @@ int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double*
     hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, Xrow, N, (int)d, (const double*)mean, work);
     hipLaunchKernelGGL(k_colfinish, dim3(d), dim3(64), 0, s, work, nb, (int)d, N, sd, 1);
     return check_launch("k_colsum/k_colfinish");
+}
+
+int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double* work, void* stream) {
+    if (!Xcols || !mean || !sd || !work || N < 1 || d < 1 || ld < N) return set_err(TTM_E_ARG, "ttm_colstats_cols: bad arguments%s");
+    const int one = colstats_one<true>(Xcols, ld, N, d, mean, sd, work, (hipStream_t)stream);
+    return one == 1 ? TTM_E_UNSUPPORTED : one;
+}
+
+int ttm_standardize_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, const double* mean, const double* sd, double* Xs,
+                         int64_t ldx, void* stream) {
+    if (!Xcols || !mean || !sd || !Xs || N < 1 || d < 1 || ld < N || ldx < N)
+        return set_err(TTM_E_ARG, "ttm_standardize_cols: bad arguments%s");
+    dim3 grid((unsigned)grid_for(N, 256 * 4), (unsigned)d);
+    hipLaunchKernelGGL(k_standardize_cols, grid, dim3(256), 0, (hipStream_t)stream, Xcols, ld, N, (int)d, mean, sd, Xs, ldx);
+    return check_launch("k_standardize_cols");
 }
 
 int ttm_import(const double* Xrow, int64_t N, int32_t d, const double* mean, const double* sd, double* Xsoa,
@@ -2637,7 +3062,11 @@ int ttm_export(const double* Xsoa, int64_t ldx, int64_t N, int32_t j0, int32_t d
     return check_launch("k_export");
 }
 
-int64_t ttm_select_work_size(int32_t nr) { (void)nr; return (int64_t)sizeof(SelState) + (int64_t)TTM_SEL_MAX * 256 * 4; }
+int64_t ttm_select_work_size(int32_t nr) {
+    (void)nr;       // multi-launch state + histogram | 16 barrier words | three histogram regions of the one-launch select
+    return (int64_t)sizeof(SelState) + (int64_t)TTM_SEL_MAX * 256 * 4 + 128 + 3 * (int64_t)TTM_SEL_MAX * 256 * 4 +
+           (int64_t)TTM_SEL_MAX * 32 * 8;
+}
 
 int ttm_order_statistics(const double* col, int64_t N, const int64_t* ranks, int32_t nr, double* out, void* work,
                          void* stream) {
@@ -3369,36 +3798,82 @@ int ttm_objective_sep_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t
     return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, h_coef_mon, delta, work, counter, out, nullptr, 0.0, stream);
 }
 
+// one evaluation of the reduced separable objective: cached basis (dPsi) or recomputed from the x_k column (xk, kinds, pars).
+// sentinel: self-validating rows and results (<= 128 workgroups; out = page-locked host slots armed by the caller); else up to
+// 128 workgroups (N <= 131 072: the filter's ensembles) ONE launch, the workgroup that draws the last ticket adds the rows of
+// partial sums itself (csrc/ttm_dev.h: finish_sums, no fence), and larger grids finish in a second launch: the in-kernel
+// two-stage finish was measured at + 8 us per evaluation at N = 1e6 (21.6 against 13.4 us; rounds of agent-scope loads)
+static int launch_sep_objective(const double* dPsi, int64_t ldp, const double* xk, const int32_t* kinds, const double* pars, int64_t N,
+                                int32_t m, const double* h_coef_mon, double delta, double* work, uint32_t* counter, double* out,
+                                double* flag, double mark, bool sentinel, void* stream) {
+    SepCoef hc;
+    for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
+    int nb = grid_for(N, 256 * 4);
+    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;         // (eight more rows of partial sums: the group sums of finish_sums)
+    if (sentinel && nb > TTM_SENT_WGS) return TTM_E_UNSUPPORTED;
+    const bool ticket = nb <= 128;
+    unsigned int* cnt = ticket && !sentinel ? (unsigned int*)counter : (unsigned int*)nullptr;
+    double* partial = work + TTM_OBJ_FOLD_MAX;
+    if (dPsi) {
+        typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*, double*, double, int);
+        static const skern_t kerns[TTM_SEPC_MAXM] = {
+            k_objective_sep_cached<1>, k_objective_sep_cached<2>, k_objective_sep_cached<3>, k_objective_sep_cached<4>,
+            k_objective_sep_cached<5>, k_objective_sep_cached<6>, k_objective_sep_cached<7>, k_objective_sep_cached<8>,
+            k_objective_sep_cached<9>, k_objective_sep_cached<10>, k_objective_sep_cached<11>, k_objective_sep_cached<12>,
+            k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
+        hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta, partial, cnt, out, flag, mark,
+                           sentinel ? 1 : 0);
+    } else {
+        typedef void (*dkern_t)(const double*, int64_t, const int*, const double*, SepCoef, double, double*, unsigned int*, double*, double*,
+                                double, int);
+        static const dkern_t kerns[TTM_SEPC_MAXM] = {
+            k_objective_sep_direct<1>, k_objective_sep_direct<2>, k_objective_sep_direct<3>, k_objective_sep_direct<4>,
+            k_objective_sep_direct<5>, k_objective_sep_direct<6>, k_objective_sep_direct<7>, k_objective_sep_direct<8>,
+            k_objective_sep_direct<9>, k_objective_sep_direct<10>, k_objective_sep_direct<11>, k_objective_sep_direct<12>,
+            k_objective_sep_direct<13>, k_objective_sep_direct<14>, k_objective_sep_direct<15>, k_objective_sep_direct<16>};
+        hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta, partial, cnt, out,
+                           flag, mark, sentinel ? 1 : 0);
+    }
+    if (!ticket) {
+        if (flag)
+            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
+                               (const double*)partial, nb, 1 + (int)m, out, flag, mark);
+        else
+            hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, 1 + (int)m, out);
+    }
+    return check_launch(dPsi ? "k_objective_sep_cached" : "k_objective_sep_direct");
+}
+
 int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
                                     double* work, uint32_t* counter, double* out, double* flag, double mark, void* stream) {
     if (!dPsi || !h_coef_mon || !work || !counter || !out || N < 1 || ldp < N || m < 1)
         return set_err(TTM_E_ARG, "ttm_objective_sep_cached: bad arguments%s");
     if (m > TTM_SEPC_MAXM) return set_err(TTM_E_LIMIT, "ttm_objective_sep_cached: more than %s%lld monotone terms", "", TTM_SEPC_MAXM);
-    SepCoef hc;
-    for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
-    int nb = grid_for(N, 256 * 4);
-    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;         // (eight more rows of partial sums: the group sums of finish_sums)
-    typedef void (*skern_t)(const double*, int64_t, int64_t, SepCoef, double, double*, unsigned int*, double*, double*, double);
-    static const skern_t kerns[TTM_SEPC_MAXM] = {
-        k_objective_sep_cached<1>, k_objective_sep_cached<2>, k_objective_sep_cached<3>, k_objective_sep_cached<4>,
-        k_objective_sep_cached<5>, k_objective_sep_cached<6>, k_objective_sep_cached<7>, k_objective_sep_cached<8>,
-        k_objective_sep_cached<9>, k_objective_sep_cached<10>, k_objective_sep_cached<11>, k_objective_sep_cached<12>,
-        k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
-    // up to 128 workgroups (N <= 131 072: the filter's ensembles): ONE launch, the workgroup that draws the last ticket adds the rows
-    // of partial sums itself (csrc/ttm_dev.h: finish_sums, no fence).  Larger grids finish in a second launch: the in-kernel
-    // two-stage finish was measured at + 8 us per evaluation at N = 1e6 (21.6 against 13.4 us; rounds of agent-scope loads)
-    const bool ticket = nb <= 128;
-    hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta,
-                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
-    if (!ticket) {
-        if (flag)
-            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
-                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out, flag, mark);
-        else
-            hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
-    }
-    return check_launch("k_objective_sep_cached");
+    return launch_sep_objective(dPsi, ldp, nullptr, nullptr, nullptr, N, m, h_coef_mon, delta, work, counter, out, flag, mark, false, stream);
+}
+
+int ttm_sentinel_fill(double* work, int32_t m, int64_t N, void* stream) {
+    if (!work || m < 1 || m > TTM_SEPC_MAXM || N < 1) return set_err(TTM_E_ARG, "ttm_sentinel_fill: bad arguments%s");
+    const int nb = grid_for(N, 256 * 4);
+    if (nb > TTM_SENT_WGS || tuning().sep_sentinel == 0) return TTM_E_UNSUPPORTED;
+    const int n = nb * (1 + m);
+    hipLaunchKernelGGL(k_fill_bits, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)(work + TTM_OBJ_FOLD_MAX), n,
+                       (unsigned long long)TTM_SENT_BITS);
+    return check_launch("k_fill_bits");
+}
+
+int ttm_objective_sep_cached_sent(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,
+                                  double* work, double* out_host, void* stream) {
+    if (!dPsi || !h_coef_mon || !work || !out_host || N < 1 || ldp < N || m < 1 || m > TTM_SEPC_MAXM)
+        return set_err(TTM_E_ARG, "ttm_objective_sep_cached_sent: bad arguments%s");
+    return launch_sep_objective(dPsi, ldp, nullptr, nullptr, nullptr, N, m, h_coef_mon, delta, work, nullptr, out_host, nullptr, 0.0, true, stream);
+}
+
+int ttm_objective_sep_direct_sent(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
+                                  const double* h_coef_mon, double delta, double* work, double* out_host, void* stream) {
+    if (!xk || !kinds || !pars || !h_coef_mon || !work || !out_host || N < 1 || m < 1 || m > TTM_SEPC_MAXM)
+        return set_err(TTM_E_ARG, "ttm_objective_sep_direct_sent: bad arguments%s");
+    return launch_sep_objective(nullptr, 0, xk, kinds, pars, N, m, h_coef_mon, delta, work, nullptr, out_host, nullptr, 0.0, true, stream);
 }
 
 int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
@@ -3407,28 +3882,7 @@ int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, cons
     if (!xk || !kinds || !pars || !h_coef_mon || !work || !counter || !out || N < 1 || m < 1)
         return set_err(TTM_E_ARG, "ttm_objective_sep_direct_marked: bad arguments%s");
     if (m > TTM_SEPC_MAXM) return set_err(TTM_E_LIMIT, "ttm_objective_sep_direct_marked: more than %s%lld monotone terms", "", TTM_SEPC_MAXM);
-    SepCoef hc;
-    for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
-    int nb = grid_for(N, 256 * 4);
-    if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;
-    typedef void (*dkern_t)(const double*, int64_t, const int*, const double*, SepCoef, double, double*, unsigned int*, double*, double*, double);
-    static const dkern_t kerns[TTM_SEPC_MAXM] = {
-        k_objective_sep_direct<1>, k_objective_sep_direct<2>, k_objective_sep_direct<3>, k_objective_sep_direct<4>,
-        k_objective_sep_direct<5>, k_objective_sep_direct<6>, k_objective_sep_direct<7>, k_objective_sep_direct<8>,
-        k_objective_sep_direct<9>, k_objective_sep_direct<10>, k_objective_sep_direct<11>, k_objective_sep_direct<12>,
-        k_objective_sep_direct<13>, k_objective_sep_direct<14>, k_objective_sep_direct<15>, k_objective_sep_direct<16>};
-    const bool ticket = nb <= 128;                   // (see ttm_objective_sep_cached_marked)
-    hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta,
-                       work + TTM_OBJ_FOLD_MAX, ticket ? (unsigned int*)counter : (unsigned int*)nullptr, out, flag, mark);
-    if (!ticket) {
-        if (flag)
-            hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
-                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out, flag, mark);
-        else
-            hipLaunchKernelGGL(k_reduce_partials, dim3((1 + m + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                               (const double*)(work + TTM_OBJ_FOLD_MAX), nb, 1 + (int)m, out);
-    }
-    return check_launch("k_objective_sep_direct");
+    return launch_sep_objective(nullptr, 0, xk, kinds, pars, N, m, h_coef_mon, delta, work, counter, out, flag, mark, false, stream);
 }
 
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N, double* work, double* out,

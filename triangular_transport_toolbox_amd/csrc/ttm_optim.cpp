@@ -50,6 +50,42 @@ int poll_mark(const double* flag_, double mark, void* stream) {
 }
 #endif
 
+// The self-validating results of ttm_objective_sep_cached_sent: the host fills the n slots with a bit pattern no arithmetic
+// produces (arm_values), the finishing workgroup overwrites each slot with one 8-byte store, and the slots are polled until
+// none holds the pattern - no completion mark, no drain on the device in front of it.  TTM_E_HIP: the stream went idle or
+// failed without results, or the device gave up waiting for its own workgroups (the FAIL pattern).
+const uint64_t kSentBits = 0x7FF4DEADBEEF0001ull, kSentFail = 0x7FF4DEADBEEF0002ull;
+void arm_values(double* v_, int n) {
+    std::atomic<uint64_t>* v = reinterpret_cast<std::atomic<uint64_t>*>(v_);
+    for (int i = 0; i < n; ++i) v[i].store(kSentBits, std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_release);
+}
+int poll_values(const double* v_, int n, void* stream) {
+    const std::atomic<uint64_t>* v = reinterpret_cast<const std::atomic<uint64_t>*>(v_);
+    static_assert(sizeof(std::atomic<uint64_t>) == sizeof(double), "lock-free 64-bit atomics expected");
+    auto pending = [&]() {
+        for (int i = 0; i < n; ++i)
+            if (v[i].load(std::memory_order_acquire) == kSentBits) return true;
+        return false;
+    };
+    for (long spins = 0; pending(); ++spins) {
+#ifndef TTM_HOST_ONLY
+        if ((spins & 0xfffff) != 0xfffff) continue;
+        const hipError_t st = hipStreamQuery((hipStream_t)stream);
+        if (st == hipErrorNotReady) continue;
+        if (st == hipSuccess) (void)hipStreamSynchronize((hipStream_t)stream);
+        if (pending()) return TTM_E_HIP;
+#else
+        (void)stream;
+        return TTM_E_HIP;
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (v[i].load(std::memory_order_relaxed) == kSentFail) return TTM_E_HIP;
+    return TTM_OK;
+}
+
 // Completion of the work queued on `stream` so far: a mark written behind it into pinned host memory (*flag), polled
 // here - a hipStreamSynchronize per evaluation costs ~12 us of host / driver latency on top of the ~13 us of device work.
 int wait_for_mark(double* flag_, long& seq, void* stream) {
@@ -188,10 +224,12 @@ namespace {
 // (TM:2990-2993), so sum_n log dS_n = N log(c + delta) + sum_n log dPsi_n and sum_n dPsi_n / dS_n = N / (c + delta): the
 // first evaluation of the loop goes to the device, every later one is two host operations - the same function to
 // rounding (1e-16 relative, like the order of a reduction), no launch, no round trip.  `delta` < 0 switches it off.
+typedef int (*SentLaunch)(const double* cc, double* out_host, void* stream, void* user);
+
 template <class Launch>
 int optimize_separable_with(Launch launch, int32_t m, const double* A, const double* b, double Ntotal, const double* lb,
                             const double* ub, double* x, double* sums_dev, double* sums_host, ttm_comm* comm, void* stream,
-                            int32_t maxiter, double* result, double delta = -1.0) {
+                            int32_t maxiter, double* result, double delta = -1.0, SentLaunch sent = nullptr, void* sent_user = nullptr) {
     struct Ctx {
         Launch& launch;
         const double *A, *b;
@@ -203,8 +241,10 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         long seq;
         double delta, Nw, KN;                                // closed form of m = 1: weights N, sum_n log dPsi_n
         bool closed, have0;
+        SentLaunch sent;                                     // the evaluation with self-validating results (no ticket, no mark)
+        void* sent_user;
     } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,
-        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false};
+        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false, comm ? nullptr : sent, sent_user};
     sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
@@ -213,6 +253,12 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         if (c.closed && c.have0 && cc[0] + c.delta > 0.0) {
             c.sums_host[0] = c.Nw * log(cc[0] + c.delta) + c.KN;
             c.sums_host[1] = c.Nw / (cc[0] + c.delta);
+        } else if (c.sent) {
+            arm_values(c.sums_host, 1 + n);
+            c.rc = c.sent(cc, c.sums_host, c.stream, c.sent_user);
+            if (c.rc) return c.rc;
+            c.rc = poll_values(c.sums_host, 1 + n, c.stream);
+            if (c.rc) return c.rc;
         } else if (!c.comm) {                                // results and completion mark from the reduction itself
             c.rc = objective_and_wait(c.sums_host + 1 + n, c.seq, c.stream,
                                       [&](double* flag, double mark) { return c.launch(cc, out, flag, mark, c.stream); });
@@ -265,7 +311,17 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
         return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
     };
     static const bool closed = [] { const char* e = getenv("TTM_SEP_CLOSED_FORM"); return !e || atoi(e) != 0; }();
-    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result, closed ? delta : -1.0);
+    // up to 128 workgroups and no communicator: evaluations with self-validating partial sums and results (ttm_sentinel_fill
+    // arms the rows once; every evaluation leaves them armed)
+    struct SentArgs { const double* dPsi; int64_t ldp, N; int32_t m; double delta; double* work; } sa{dPsi, ldp, N, m, delta, work};
+    SentLaunch sent = nullptr;
+    if (!comm && ttm_sentinel_fill(work, m, N, stream) == TTM_OK)
+        sent = [](const double* cc, double* out_host, void* st, void* user) -> int {
+            const SentArgs& a = *(const SentArgs*)user;
+            return ttm_objective_sep_cached_sent(a.dPsi, a.ldp, a.N, a.m, cc, a.delta, a.work, out_host, st);
+        };
+    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result, closed ? delta : -1.0,
+                                   sent, &sa);
 }
 
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta, int32_t nthreads,
@@ -282,8 +338,16 @@ int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N,
         auto launch = [&](const double* cc, double* out, double* flag, double mark, void* s2) {
             return ttm_objective_sep_direct_marked(q.xk, N, q.m, q.kinds, q.pars, cc, delta, q.work, q.counter, out, flag, mark, s2);
         };
+        // (self-validating sums as in ttm_optimize_separable: the same finish, hence the same bits, as the cached basis)
+        struct SentArgs { const ttm_sep_task* q; int64_t N; double delta; } sa{&q, N, delta};
+        SentLaunch sent = nullptr;
+        if (ttm_sentinel_fill(q.work, q.m, N, st) == TTM_OK)
+            sent = [](const double* cc, double* out_host, void* s2, void* user) -> int {
+                const SentArgs& a = *(const SentArgs*)user;
+                return ttm_objective_sep_direct_sent(a.q->xk, a.N, a.q->m, a.q->kinds, a.q->pars, cc, a.delta, a.q->work, out_host, s2);
+            };
         return q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
-                                              q.result);
+                                              q.result, -1.0, sent, &sa);
     });
 }
 

@@ -38,15 +38,34 @@ def lerp(a, b, t):
     return out
 
 
+_PLANS = {}
+
+
+def _plan_lists(n, q):
+    """plan(n, q) as plain lists + the sorted unique ranks, kept per (n, q): the placement of a filter asks for the same
+    quantiles of the same number of samples in every update."""
+    key = (int(n), tuple(np.atleast_1d(np.asarray(q, dtype=float)).tolist()))
+    p = _PLANS.get(key)
+    if p is None:
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        prev, nxt, gamma = plan(n, q)
+        p = _PLANS[key] = (prev.tolist(), nxt.tolist(), gamma.tolist(), np.unique(np.concatenate((prev, nxt))))
+    return p
+
+
 def quantile_from_order_statistics(n, q, fetch, shift=None):
     """fetch(ranks: sorted unique int array) -> values of those order statistics (same order).
     shift: quantiles of (x - shift) instead of x (a monotone map, so the order statistics shift along)."""
-    prev, nxt, gamma = plan(n, q)
-    ranks = np.unique(np.concatenate((prev, nxt)))
+    prev, nxt, gamma, ranks = _plan_lists(n, q)
     vals = np.asarray(fetch(ranks), dtype=float)
     if shift is not None:
         vals = vals - shift
     lut = dict(zip(ranks.tolist(), vals.tolist()))
-    a = np.array([lut[int(r)] for r in prev])
-    b = np.array([lut[int(r)] for r in nxt])
-    return lerp(a, b, gamma)
+    # lerp() element by element on plain floats (the same IEEE operations as the array expression)
+    out = np.empty(len(prev))
+    for i, (rp, rn, t) in enumerate(zip(prev, nxt, gamma)):
+        a, b = lut[rp], lut[rn]
+        diff = b - a
+        out[i] = b - diff * (1 - t) if t >= 0.5 else a + diff * t
+    return out

@@ -32,6 +32,8 @@ trials, table points) from per-sample weights w_b.
 
 import itertools
 
+import math
+
 import numpy as np
 
 # constants mirrored from include/ttm.h
@@ -186,13 +188,31 @@ class CompiledMap:
     def fill_special_terms(self, special):
         """Refresh the special-term constants after a new placement: per special
         term {centre, scale, 1/(sqrt2 scale), scale sqrt(2/pi), 1/(sqrt(2 pi) scale)}."""
-        for i, src in enumerate(self.dpar_sources):
-            if src[0] == 'st':
-                _, kc, cross, var, index, which = src
-                d = special[kc]['cross-terms'][var] if cross else special[kc][var]
-                mu, sc = float(d['centers'][index]), float(d['scales'][index])
-                self.dpar[i] = (mu, sc, 1.0 / (np.sqrt(2) * sc), sc * np.sqrt(2 / np.pi),
-                                1.0 / (np.sqrt(2 * np.pi) * sc))[which]
+        # (the special-term records are groups of five consecutive entries of one term - which = 0..4 -: walked once per term,
+        # the list of groups kept; the filter refreshes them three times per cycle)
+        groups = getattr(self, '_st_groups', None)
+        if groups is None:
+            groups = self._st_groups = [(i, src[1:5]) for i, src in enumerate(self.dpar_sources) if src[0] == 'st' and src[5] == 0]
+            whole = all(i + 4 < len(self.dpar_sources) and
+                        all(self.dpar_sources[i + w][0] == 'st' and tuple(self.dpar_sources[i + w][1:]) == tuple(key) + (w,) for w in range(5))
+                        for i, key in groups)
+            count = sum(1 for src in self.dpar_sources if src[0] == 'st')
+            if not whole or count != 5 * len(groups):
+                groups = self._st_groups = False
+        if groups is False:
+            for i, src in enumerate(self.dpar_sources):
+                if src[0] == 'st':
+                    _, kc, cross, var, index, which = src
+                    d = special[kc]['cross-terms'][var] if cross else special[kc][var]
+                    mu, sc = float(d['centers'][index]), float(d['scales'][index])
+                    self.dpar[i] = (mu, sc, 1.0 / (np.sqrt(2) * sc), sc * np.sqrt(2 / np.pi),
+                                    1.0 / (np.sqrt(2 * np.pi) * sc))[which]
+            return self.dpar
+        r2, r2pi, rpi = np.sqrt(2), np.sqrt(2 * np.pi), np.sqrt(2 / np.pi)
+        for i, (kc, cross, var, index) in groups:
+            d = special[kc]['cross-terms'][var] if cross else special[kc][var]
+            mu, sc = float(d['centers'][index]), float(d['scales'][index])
+            self.dpar[i:i + 5] = (mu, sc, 1.0 / (r2 * sc), sc * rpi, 1.0 / (r2pi * sc))
         return self.dpar
 
 
@@ -990,17 +1010,20 @@ def uform_geometry(cm, kappa=None):
         ng = int(uc[k, 2]) + (1 if uc[k, 7] & UCF_OWN else 0)
         uc[k, 6] = off
         off += 4 + U_GSTRIDE * ng
+    dpar = cm.dpar.tolist()         # (plain floats: a handful of terms per component - the array machinery of NumPy costs 45 us of
+    isfinite = math.isfinite        #  every filter update here; the arithmetic is the same IEEE operations)
     for k, u in enumerate(cm.u_info):
         nI = 0
         if len(u['st_p0']):
             base = int(cm.dpar_off[k])
-            mu = np.asarray([cm.dpar[base + p0] for p0 in u['st_p0']])
-            sc = np.asarray([cm.dpar[base + p0 + 1] for p0 in u['st_p0']])
-            if not (np.all(np.isfinite(mu)) and np.all(np.isfinite(sc)) and np.all(sc > 0)):
+            mu = [dpar[base + p0] for p0 in u['st_p0']]
+            sc = [dpar[base + p0 + 1] for p0 in u['st_p0']]
+            if not (all(isfinite(v) for v in mu) and all(isfinite(v) and v > 0 for v in sc)):
                 ok = False          # constants not placed yet (or degenerate): no U-form until they are
-                mu, sc = np.zeros(1), np.ones(1)
-            t_lo, t_hi = float(np.min(mu - U_SUPPORT * sc)), float(np.max(mu + U_SUPPORT * sc))
-            n_int = int(np.ceil((t_hi - t_lo) / (kappa * float(np.min(sc)))))
+                mu, sc = [0.0], [1.0]
+            t_lo = min(m_ - U_SUPPORT * s_ for m_, s_ in zip(mu, sc))
+            t_hi = max(m_ + U_SUPPORT * s_ for m_, s_ in zip(mu, sc))
+            n_int = int(math.ceil((t_hi - t_lo) / (kappa * min(sc))))
             n_int = max(n_int, 2)
             n_int += n_int % 2      # even number of columns: 16-byte copies
             nI = n_int + 2

@@ -328,8 +328,13 @@ class transport_map():
         termtable.uform_geometry(cm)
         if self._u_rejected:
             cm.u_enabled = False
-        self._ucomp_d = self._to_dev(cm.ucomp, dtype=torch.int32)
-        self._ugeo_d = self._to_dev(cm.ugeo)
+        # (the component table changes when a placement changes the number of spline intervals - not in most updates of a
+        # filter; the geometry always does: one short copy through the page-locked ring)
+        last = getattr(self, '_ucomp_host', None)
+        if last is None or last.shape != cm.ucomp.shape or not np.array_equal(last, cm.ucomp):
+            self._ucomp_host = np.array(cm.ucomp, copy=True)
+            self._ucomp_d = self._to_dev(cm.ucomp, dtype=torch.int32)
+        self._ugeo_d = self._to_dev_staged(np.ascontiguousarray(cm.ugeo, dtype=float))
         if getattr(self, '_ugrp_d', None) is None:
             self._ugrp_d = self._to_dev(cm.ugrp, dtype=torch.int32)
             self._umono_d = self._to_dev(cm.umono)
@@ -492,6 +497,46 @@ class transport_map():
             self._X_host = self._export(self._Xs, self._N, 0, self._Xs.shape[0], False)
         return self._X_host
 
+    # X_mean / X_std (TM:760-781): host copies of the standardisation constants.  After a reset of device-resident samples
+    # they are still on their way: the first reader fetches them (the filter's update reads them together with its order statistics)
+    def _resolve_moments(self):
+        pend = getattr(self, '_moments_pending', None)
+        if pend is not None:
+            self._moments_pending = None
+            both = _torch().stack(pend).cpu().numpy()
+            self._X_mean, self._X_std = both[0].copy(), both[1].copy()
+
+    @property
+    def X_mean(self):
+        self._resolve_moments()
+        return self._X_mean
+
+    @X_mean.setter
+    def X_mean(self, v):
+        self._resolve_moments()
+        self._X_mean = v
+
+    @property
+    def X_std(self):
+        self._resolve_moments()
+        return self._X_std
+
+    @X_std.setter
+    def X_std(self, v):
+        self._resolve_moments()
+        self._X_std = v
+
+    def _visit_buffers(self, d):
+        """(device, page-locked host) vectors of one host visit of reset_device: [mean (d) | std (d) | 16 order statistics per
+        column (16 d)]."""
+        torch = _torch()
+        vb = getattr(self, '_visit', None)
+        if vb is None or vb[0].numel() < 18 * d:
+            dev = torch.zeros(18 * d, dtype=torch.float64, device=self._dev)
+            host = torch.zeros(18 * d, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            vb = self._visit = (dev, host)
+        return vb
+
     def standardize(self, X=None):
         """TM:750-787.  'standard': mean / ddof-0 std per column (device reduction);
         'quantiles': median / quantile spread."""
@@ -502,7 +547,8 @@ class transport_map():
         on_device = isinstance(X, torch.Tensor)          # (reset_device: the raw samples are already there, row-major)
         if self.standardization.lower() == 'standard':
             Xrow = X if on_device else self._to_dev(X)
-            mean, sd = self._empty(d), self._empty(d)
+            visit = self._visit_buffers(d)[0]
+            mean, sd = (visit[:d], visit[d:2 * d]) if self._dist() is None else (self._empty(d), self._empty(d))
             work = self._workspace(self._lib.ttm_colstats_work_size(N, d))
             _capi.check(self._lib.ttm_colstats(self._ptr(Xrow), N, d, self._ptr(mean), self._ptr(sd), self._ptr(work),
                                                self._stream()))
@@ -514,10 +560,11 @@ class transport_map():
                 gmean = s1 / self._Nglobal
                 s2 = self._allreduce((sd * sd + (mean - gmean) ** 2) * n_r)
                 mean, sd = gmean, torch.sqrt(s2 / self._Nglobal)
-            # (one copy for both vectors; the device copies the layout kernels read are the reduction's own output)
-            both = torch.stack((mean, sd)).cpu().numpy()
-            self.X_mean, self.X_std = both[0].copy(), both[1].copy()
+            # (the device copies the layout kernels read are the reduction's own output; the host copies are read when
+            # somebody asks for them - X_mean / X_std below -, or together with the order statistics of the special-term
+            # placement: ONE host visit per reset instead of one per vector)
             self._mean_d, self._std_d = mean, sd
+            self._moments_pending = (mean, sd)
             return
         elif self.standardization.lower() in ('quantile', 'quantiles'):
             # median / quantile spread per column (TM:775-778) from device order statistics; the
@@ -566,28 +613,33 @@ class transport_map():
         ranks = np.asarray(ranks, dtype=np.int64)
         out = np.empty(len(ranks))
         # (scratch and the rank vectors - functions of N and the requested quantiles only - stay on the device between calls:
-        # the filter asks for the same order statistics in every update)
+        # the filter asks for the same order statistics in every update: _launch_select)
+        for i in range(0, len(ranks), 16):
+            o = self._empty(len(ranks[i:i + 16]))
+            self._launch_select(col, ranks[i:i + 16], o, handle)
+            out[i:i + 16] = o.cpu().numpy()
+        return out, n_total
+
+    def _launch_select(self, col, ranks, out, handle=None):
+        """ttm_order_statistics of <= 16 ranks of a device column into the device vector `out` (no host visit)."""
+        torch = _torch()
         work = getattr(self, '_select_work', None)
         if work is None:
-            work = self._select_work = torch.empty(int(self._lib.ttm_select_work_size(16)), dtype=torch.uint8, device=self._dev)
+            work = self._select_work = torch.zeros(int(self._lib.ttm_select_work_size(16)), dtype=torch.uint8, device=self._dev)
         rcache = getattr(self, '_select_ranks', None)
         if rcache is None or len(rcache) > 64:
             rcache = self._select_ranks = {}
-        for i in range(0, len(ranks), 16):
-            rkey = ranks[i:i + 16].tobytes()
-            r = rcache.get(rkey)
-            if r is None:
-                r = rcache[rkey] = self._to_dev(ranks[i:i + 16])
-            o = self._empty(len(ranks[i:i + 16]))
-            if handle is not None:
-                _capi.check(self._lib.ttm_order_statistics_dist(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()), r.numel(),
-                                                                self._ptr(o), ctypes.c_void_p(work.data_ptr()), handle, self._stream()))
-            else:
-                _capi.check(self._lib.ttm_order_statistics(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()),
-                                                           r.numel(), self._ptr(o), ctypes.c_void_p(work.data_ptr()),
-                                                           self._stream()))
-            out[i:i + 16] = o.cpu().numpy()
-        return out, n_total
+        rkey = ranks.tobytes()
+        r = rcache.get(rkey)
+        if r is None:
+            r = rcache[rkey] = self._to_dev(np.ascontiguousarray(ranks, dtype=np.int64))
+        if handle is not None:
+            _capi.check(self._lib.ttm_order_statistics_dist(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()), r.numel(),
+                                                            self._ptr(out), ctypes.c_void_p(work.data_ptr()), handle, self._stream()))
+        else:
+            _capi.check(self._lib.ttm_order_statistics(self._ptr(col), col.numel(), ctypes.c_void_p(r.data_ptr()),
+                                                       r.numel(), self._ptr(out), ctypes.c_void_p(work.data_ptr()),
+                                                       self._stream()))
 
     def _device_quantile(self, col, q, shift=None):
         """np.quantile(col - shift, q) (method 'linear'), bit-identical, from device order statistics."""
@@ -606,18 +658,54 @@ class transport_map():
         if len(req) == 0:
             return
         memo = {}
+        lut = self._prefetch_order_statistics(req)
 
         def column_quantiles(var, q):
             key = (var, tuple(np.asarray(q, dtype=float).tolist()))
             if key not in memo:
-                memo[key] = self._device_quantile(self._Xs[var, :self._N], q)
+                if lut is not None and var in lut:
+                    memo[key] = quantile.quantile_from_order_statistics(self._N, q, lambda ranks: [lut[var][int(r)] for r in ranks])
+                else:
+                    memo[key] = self._device_quantile(self._Xs[var, :self._N], q)
             return memo[key]
         termtable.place_special_terms(self.special_terms, column_quantiles, self.ST_scale_factor, self.ST_scale_mode)
         self._cm.fill_special_terms(self.special_terms)
-        self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
+        if self._dev.type == 'cuda':
+            self._to_dev_staged(self._cm.dpar, out=self._dpar_d)        # (page-locked staging: no synchronous copy in the runtime)
+        else:
+            self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
         self._epoch += 1                         # (the folded special-term records depend on centres and scales)
         self._u_rejected = False
         self._refresh_uform()
+
+    def _prefetch_order_statistics(self, req):
+        """Every order statistic the placement will interpolate between (req: {column: quantiles}), selected column by column
+        WITHOUT a host visit in between and read in one copy - together with the column moments of a reset that are still on
+        the device.  {column: {rank: value}}, or None when this does not apply (sharded samples, more than 16 ranks of a
+        column): the placement then asks column by column."""
+        torch = _torch()
+        if self._dist() is not None:
+            return None
+        d = self._cm.d_cols
+        plans = {}
+        for var, qs in req.items():
+            prev, nxt, _ = quantile.plan(self._N, qs)
+            ranks = np.unique(np.concatenate((prev, nxt))).astype(np.int64)
+            if len(ranks) > 16 or not 0 <= int(var) < d:
+                return None
+            plans[int(var)] = ranks
+        dev, host = self._visit_buffers(d)
+        for var, ranks in plans.items():
+            self._launch_select(self._Xs[var, :self._N], ranks, dev[2 * d + 16 * var:2 * d + 16 * var + len(ranks)])
+        host.copy_(dev, non_blocking=True)
+        if self._dev.type == 'cuda':
+            torch.cuda.current_stream().synchronize()
+        h = host.numpy()
+        if getattr(self, '_moments_pending', None) is not None and self._moments_pending[0].data_ptr() == dev.data_ptr():
+            self._moments_pending = None
+            self._X_mean, self._X_std = h[:d].copy(), h[d:2 * d].copy()
+        return {var: dict(zip(ranks.tolist(), h[2 * d + 16 * var:2 * d + 16 * var + len(ranks)].tolist()))
+                for var, ranks in plans.items()}
 
     def _linearization_thresholds(self):
         """TM:2364-2389: per column the quantiles (linearization, 1 - linearization) of the standardised training
@@ -662,7 +750,6 @@ class transport_map():
         for k in range(self.D):
             self.coeffs_mon[k] = np.asarray(self.coeffs_mon[k], dtype=float) * 0 + self.coeffs_init
             self.coeffs_nonmon[k] = np.asarray(self.coeffs_nonmon[k], dtype=float) * 0 + self.coeffs_init
-        Xrow = self._export(Xcols, N, 0, d, False, to_host=False)          # row-major copy for the moment / layout kernels
         self._N = N
         self._Nglobal = N
         dist = self._dist()
@@ -671,11 +758,40 @@ class transport_map():
             dist.all_reduce(n)
             self._Nglobal = int(n.item())
         self._X_host = None
-        if self.standardize_samples:
-            self.standardize(Xrow)
-        self._Xs = self._import(Xrow, self.standardize_samples)
         self._obj_cache = None
+        if not (dist is None and self.standardize_samples and self._standardize_cols(Xcols, N)):
+            Xrow = self._export(Xcols, N, 0, d, False, to_host=False)      # row-major copy for the moment / layout kernels
+            if self.standardize_samples:
+                self.standardize(Xrow)
+            self._Xs = self._import(Xrow, self.standardize_samples)
         self.determine_special_term_locations()
+
+    def _standardize_cols(self, Xcols, N):
+        """'standard' standardisation (TM:760-771) of a column-major device matrix without a row-major copy: moments in one
+        launch (ttm_colstats_cols: the same sums, hence the same bits, as ttm_colstats of the exported rows), one
+        elementwise pass.  False: not for this shape / setting (the caller exports)."""
+        if self.standardization.lower() != 'standard' or not hasattr(self._lib, 'ttm_colstats_cols'):
+            return False
+        d = self._cm.d_cols
+        visit = self._visit_buffers(d)[0]
+        mean, sd = visit[:d], visit[d:2 * d]
+        work = self._workspace(self._lib.ttm_colstats_work_size(N, d))
+        st = self._stream()
+        rc = self._lib.ttm_colstats_cols(self._ptr(Xcols), Xcols.shape[1], N, d, self._ptr(mean), self._ptr(sd), self._ptr(work), st)
+        if rc == _capi.TTM_E_UNSUPPORTED:
+            return False
+        _capi.check(rc)
+        # (the matrix of the reset before is taken over when it has the same shape: its padding beyond N is zero already)
+        Xs = getattr(self, '_Xs', None)
+        if Xs is None or not getattr(Xs, '_ttm_reset_cols', False) or tuple(Xs.shape) != (d, self._ld(N)):
+            Xs = self._cols(d, N, zero=True)
+            Xs._ttm_reset_cols = True
+        _capi.check(self._lib.ttm_standardize_cols(self._ptr(Xcols), Xcols.shape[1], N, d, self._ptr(mean), self._ptr(sd),
+                                                   self._ptr(Xs), Xs.shape[1], st))
+        self._mean_d, self._std_d = mean, sd
+        self._moments_pending = (mean, sd)
+        self._Xs = Xs
+        return True
 
     def map_columns(self, src, ncols_out, N, source=None, scale=None, shift=None, out=None):
         """out[j] = source[src[j]] * scale[j] + shift[j] on column-major device matrices (ttm_map_columns): column
@@ -731,7 +847,7 @@ class transport_map():
             self._pack_memo = (coef._ttm_epoch, host, coef)
         return coef
 
-    def _to_dev_staged(self, host):
+    def _to_dev_staged(self, host, out=None):
         """Host -> device copy of a short fp64 vector through a ring of pinned staging buffers (asynchronous on the current
         stream; a pageable source costs a synchronous staging copy inside the runtime: 17 against 8 us for 3.4 KB)."""
         torch = _torch()
@@ -747,7 +863,7 @@ class transport_map():
         if slot[1] is not None:
             slot[1].synchronize()                       # (the copy that last used this buffer - eight uploads ago - is done)
         slot[0][:n].numpy()[:] = host
-        dev = torch.empty(n, dtype=torch.float64, device=self._dev)
+        dev = torch.empty(n, dtype=torch.float64, device=self._dev) if out is None else out
         dev.copy_(slot[0][:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -1409,16 +1525,29 @@ class transport_map():
     def _gram_many(self, K):
         """Gram matrices of several components: the launches back to back, ONE all-reduce and ONE device-to-host
         copy for all of them."""
+        torch = _torch()
+        # (sizes, the device vector and its page-locked mirror are kept per set of components: the filter asks for the same
+        # matrices in every update; the copy into page-locked memory needs no staging copy inside the runtime)
+        memo = getattr(self, '_gram_memo', None)
         sizes = [int(self._cm.n_nm[k] + self._cm.n_mon[k]) for k in K]
-        offs = np.concatenate(([0], np.cumsum([m * m for m in sizes]))).astype(int)
-        out = self._empty(int(offs[-1]))
+        key = (tuple(int(k) for k in K), tuple(sizes))
+        if memo is None or memo[0] != key:
+            offs = [int(o) for o in np.concatenate(([0], np.cumsum([m * m for m in sizes])))]
+            out = self._empty(offs[-1])
+            pinned = torch.empty(offs[-1], dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            memo = self._gram_memo = (key, sizes, offs, out, pinned)
+        _, sizes, offs, out, pinned = memo
         work = self._workspace(self._lib.ttm_reduce_work_size(max(m * m for m in sizes)))
-        for k, o in zip(K, offs):
-            _capi.check(self._lib.ttm_gram(self._pp, int(k), self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
-                                           self._ptr(out, int(o)), self._stream()))
+        st = self._stream()
+        for k, o in zip(key[0], offs):
+            _capi.check(self._lib.ttm_gram(self._pp, k, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
+                                           self._ptr(out, o), st))
         self._allreduce(out)
-        host = out.cpu().numpy()
-        return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(K, offs, sizes)}
+        pinned.copy_(out, non_blocking=True)
+        if self._dev.type == 'cuda':
+            torch.cuda.current_stream().synchronize()
+        host = pinned.numpy().copy()
+        return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(key[0], offs, sizes)}
 
     def separable_setup(self, k, G=None):
         """The reduced separable problem of TM:2959-3050 from the Gram matrix of
@@ -1887,10 +2016,16 @@ class transport_map():
             start = stop
             grams = self._gram_many(batch)
             n = len(batch)
-            wsz = int(self._lib.ttm_reduce_work_size(17))
-            work = self._empty(n * wsz)
-            counters = self._zeros(n * 16, dtype=torch.int32)
-            sums = torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
+            # (scratch of the native loops, kept between calls: reduction workspaces, ticket counters - the kernels leave them
+            # zero -, page-locked result vectors and the cached derivative bases; the filter optimises the same components
+            # over the same number of samples in every update)
+            skey = (tuple(batch), int(self._N), int(self._Xs.shape[1]), tuple(int(self._cm.n_mon[k]) for k in batch))
+            scr = getattr(self, '_sep_batch_scratch', None)
+            if scr is None or scr[0] != skey:
+                wsz = int(self._lib.ttm_reduce_work_size(17))
+                scr = self._sep_batch_scratch = (skey, wsz, self._empty(n * wsz), self._zeros(n * 16, dtype=torch.int32),
+                                                 torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {})
+            _, wsz, work, counters, sums, dpsi_keep = scr
             tasks = (_capi.ttm_sep_task * n)()
             keep = []
             # special-term kinds and constants of the components that recompute their basis: one upload for the batch
@@ -1909,7 +2044,9 @@ class transport_map():
                 m = int(self._cm.n_mon[k])
                 dpsi = None
                 if direct[k] is None:
-                    dpsi = self._cols(m, self._N)
+                    dpsi = dpsi_keep.get(k)
+                    if dpsi is None or dpsi.shape[0] != m:
+                        dpsi = dpsi_keep[k] = self._cols(m, self._N)
                     _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
                                                     self._ptr(dpsi), dpsi.shape[1], self._stream()))
                 A = np.ascontiguousarray(A, dtype=float)
@@ -1931,8 +2068,11 @@ class transport_map():
                 t.work = work.data_ptr() + 8 * i * wsz
                 t.counter = counters.data_ptr() + 4 * 16 * i
                 t.sums_host = sums.data_ptr() + 8 * 32 * i
-            _capi.check(self._lib.ttm_optimize_separable_batch(tasks, n, self._N, float(self._Nglobal), float(self.delta),
-                                                               int(min(self.optimizer_threads, n)), self._stream(), 0))
+            rc = self._lib.ttm_optimize_separable_batch(tasks, n, self._N, float(self._Nglobal), float(self.delta),
+                                                        int(min(self.optimizer_threads, n)), self._stream(), 0)
+            if rc != 0:
+                self._sep_batch_scratch = None          # (a loop that was cut short may have left a ticket counter behind)
+            _capi.check(rc)
             for i, k in enumerate(batch):
                 class _Result:
                     pass
