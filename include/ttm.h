@@ -589,6 +589,12 @@ int ttm_objective_sep_direct_marked(const double* xk, int64_t N, int32_t m, cons
  * work: >= ttm_reduce_work_size(m*m) doubles.                                                      */
 int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, int64_t N,
              double* work, double* out, void* stream);
+/* The Gram matrices of nk <= 8 components (host list ks) in one launch + one reduction launch; out: the m_k x m_k blocks one
+ * behind the other, in the order of ks.  The same sums, the same bits, as ttm_gram component by component (work: as for
+ * the largest of them).  TTM_E_UNSUPPORTED: not for these components (more than 16 basis functions, no matrix-core path, more
+ * partial sums than `work` holds): call ttm_gram for each.                                                                */
+int ttm_gram_many(const ttm_program* p, const int32_t* ks, int32_t nk, const double* Xsoa, int64_t ldx, int64_t N,
+                  double* work, double* out, void* stream);
 
 /* ---- column utilities of the device-resident ensemble filter -----------------------------------------------
  * example_06.py:252-328 (the caller of the hot path in Examples C) keeps the ensemble in host NumPy; entf.Filter keeps
@@ -628,6 +634,8 @@ int ttm_map_columns(const double* in, int64_t ldi, const int32_t* src, const dou
  *   [nonmonotone | monotone] in x (host, start / result); regularization 0 none, 1 l1: sum lambda_i |c_i|, 2 l2:
  *   sum lambda_i c_i^2 (TM:3382-3431, 3575-3633; lambda: host, m doubles, NULL for 0).  work / counter as
  *   ttm_objective_host; sums_host / sums_dev / comm / Ntotal as ttm_optimize_separable.                                */
+/* hipStreamSynchronize(stream) for bindings that hold the raw stream handle only */
+int ttm_stream_synchronize(void* stream);
 /* ttm_signal: *flag = value, ordered behind everything already enqueued on the stream.  With flag in pinned host memory
  * a host loop polls it instead of paying hipStreamSynchronize per objective evaluation (ttm_optimize_separable does). */
 int ttm_signal(double* flag, double value, void* stream);

@@ -266,6 +266,8 @@ int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double*
     return 0;
 }
 
+int ttm_stream_synchronize(void*) { return TTM_OK; }
+
 int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double*, void*) {
     if (d > 8 || N > 131072) return TTM_E_UNSUPPORTED;            // (the device library's one-launch range)
     for (int j = 0; j < d; ++j) {
@@ -754,6 +756,19 @@ int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, 
     const int rc = ttm_objective_sep_cached(dPsi, ldp, N, m, h_coef_mon, delta, work, counter, out, stream);
     if (!rc && flag) *flag = mark;
     return rc;
+}
+
+int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*);
+int ttm_gram_many(const ttm_program* p, const int32_t* ks, int32_t nk, const double* X, int64_t ldx, int64_t N, double* work, double* out,
+                  void* stream) {
+    if (nk > 8) return TTM_E_UNSUPPORTED;
+    for (int y = 0; y < nk; ++y) {
+        const int m = p->h_coef_off[ks[y] + 1] - p->h_coef_off[ks[y]];
+        const int rc = ttm_gram(p, ks[y], X, ldx, N, work, out, stream);
+        if (rc) return rc;
+        out += m * m;
+    }
+    return TTM_OK;
 }
 
 int ttm_gram(const ttm_program* p, int32_t k, const double* X, int64_t ldx, int64_t N, double*, double* out, void*) {

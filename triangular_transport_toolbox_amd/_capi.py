@@ -86,12 +86,14 @@ _SIGNATURES = {
     'ttm_objective_host': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_host_marked': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
+    'ttm_stream_synchronize': (ctypes.c_int, [c_vp]),
     'ttm_sentinel_fill': (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
     'ttm_objective_sep_cached_sent': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_direct_sent': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_cached_marked': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_objective_sep_direct_marked': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_gram': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    'ttm_gram_many': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'ttm_lorenz63_rk4': (ctypes.c_int, [c_vp, c_i64, c_i64, c_dbl, c_i32, c_vp]),
     'ttm_perturb': (ctypes.c_int, [c_vp, c_vp, c_dbl, ctypes.c_uint64, ctypes.c_uint32, c_i64, c_i64, c_vp, c_vp]),
     'ttm_map_columns': (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_vp]),

@@ -2658,8 +2658,8 @@ typedef double ttm_v4f64 __attribute__((ext_vector_type(4)));
 // WIDE = false: m <= 16, one tile.  WIDE = true: 16 < m <= 32 - three tiles (G_lo,lo | G_lo,hi | G_hi,hi; the fourth is
 // the transpose of the second), a lane holds Psi_i and Psi_{16 + i} of its sample.
 template <bool WIDE>
-__global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
-                                                   int m, double* __restrict__ partial) {
+__device__ __forceinline__ void gram_mfma_body(const DevProg& P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
+                                               int m, double* __restrict__ partial) {
     double* rows;
     CacheStore<double> cst;
     Prog g = make_prog_lds(P, cst, rows);
@@ -2717,6 +2717,37 @@ __global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const doubl
             }
         }
     }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_gram_mfma(DevProg P, int k, const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                   int m, double* __restrict__ partial) {
+    gram_mfma_body<WIDE>(P, k, X, ldx, N, m, partial);
+}
+
+// Gram matrices of SEVERAL components in one launch (blockIdx.y = component of the batch; the optimiser batches of the filter:
+// three launches of 10 us one after the other, each followed by its reduction) and one reduction launch for all of them
+#define TTM_GRAM_BATCH 8
+struct GramBatch { int k[TTM_GRAM_BATCH]; int m[TTM_GRAM_BATCH]; int poff[TTM_GRAM_BATCH]; int ooff[TTM_GRAM_BATCH]; };
+
+__global__ __launch_bounds__(256) void k_gram_mfma_many(DevProg P, GramBatch gb, const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                        double* __restrict__ partial) {
+    const int y = blockIdx.y;
+    gram_mfma_body<false>(P, gb.k[y], X, ldx, N, gb.m[y], partial + gb.poff[y]);
+}
+
+// out[ooff[y] + i] = sum_b partial[poff[y] + b m_y^2 + i]: the order of k_reduce_partials, segment by segment
+__global__ __launch_bounds__(256) void k_reduce_partials_many(const double* __restrict__ partial, GramBatch gb, int nblocks,
+                                                              double* __restrict__ out) {
+    const int y = blockIdx.y, lane = threadIdx.x & 63;
+    const int nout = gb.m[y] * gb.m[y];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nout) return;
+    const double* src = partial + gb.poff[y];
+    double v = 0.0;
+    for (int b = lane; b < nblocks; b += 64) v += src[(int64_t)b * nout + i];
+    v = wave_sum(v);
+    if (lane == 0) out[gb.ooff[y] + i] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -3019,6 +3050,10 @@ int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double*
     hipLaunchKernelGGL(k_colsum, grid, dim3(256), 0, s, Xrow, N, (int)d, (const double*)mean, work);
     hipLaunchKernelGGL(k_colfinish, dim3(d), dim3(64), 0, s, work, nb, (int)d, N, sd, 1);
     return check_launch("k_colsum/k_colfinish");
+}
+
+int ttm_stream_synchronize(void* stream) {
+    return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? TTM_OK : set_err(TTM_E_HIP, "hipStreamSynchronize failed%s");
 }
 
 int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double* work, void* stream) {
@@ -3908,6 +3943,45 @@ int ttm_gram(const ttm_program* p, int32_t k, const double* Xsoa, int64_t ldx, i
     hipLaunchKernelGGL(k_gram, dim3(nb), dim3(bd), lds_bytes(m, bd, 0), (hipStream_t)stream, dev_prog(p), (int)k, Xsoa, ldx, N, m, partial);
     hipLaunchKernelGGL(k_reduce_partials, dim3((m * m + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nb, m * m, out);
     return check_launch("k_gram");
+}
+
+int ttm_gram_many(const ttm_program* p, const int32_t* ks, int32_t nk, const double* Xsoa, int64_t ldx, int64_t N, double* work,
+                  double* out, void* stream) {
+    if (!ks || nk < 1 || !Xsoa || !work || !out || N < 1 || ldx < N) return set_err(TTM_E_ARG, "ttm_gram_many: bad arguments%s");
+    if (nk > TTM_GRAM_BATCH || tuning().gram_mfma == 0) return TTM_E_UNSUPPORTED;
+    GramBatch gb;
+    int bd = 256, mmax = 0;
+    for (int y = 0; y < nk; ++y) {
+        const int rc = validate(p, ks[y], ks[y] + 1);
+        if (rc) return rc;
+        const int m = p->h_coef_off[ks[y] + 1] - p->h_coef_off[ks[y]];
+        int b = pick_block(m, 0);
+        if (b && m * m > TTM_GRAM_MAXPAIR * b) b = 0;
+        if (!b || b < 64 || m > 16) return TTM_E_UNSUPPORTED;            // (the caller takes ttm_gram component by component)
+        if (y > 0 && b != bd) return TTM_E_UNSUPPORTED;                    // (one block size for the launch: the same tiles, hence bits)
+        bd = b;
+        mmax = m > mmax ? m : mmax;
+        gb.k[y] = ks[y];
+        gb.m[y] = m;
+    }
+    int nb = grid_for(N, bd);
+    if (nb > TTM_RED_BLOCKS) nb = TTM_RED_BLOCKS;
+    int64_t poff = 0, ooff = 0;
+    for (int y = 0; y < nk; ++y) {
+        gb.poff[y] = (int)poff;
+        gb.ooff[y] = (int)ooff;
+        poff += (int64_t)nb * gb.m[y] * gb.m[y];
+        ooff += gb.m[y] * gb.m[y];
+    }
+    for (int y = nk; y < TTM_GRAM_BATCH; ++y) gb.k[y] = gb.m[y] = gb.poff[y] = gb.ooff[y] = 0;
+    if (poff > ttm_reduce_work_size(mmax * mmax) - TTM_OBJ_FOLD_MAX) return TTM_E_UNSUPPORTED;
+    const size_t glds = ((size_t)TTM_ERF_TABLE_LEN + (mmax * (bd + 1) >= 1024 ? (size_t)mmax * (bd + 1) : 1024)) * 8;
+    if (glds > (size_t)kLdsBudget) return TTM_E_UNSUPPORTED;
+    double* partial = work + TTM_OBJ_FOLD_MAX;
+    hipLaunchKernelGGL(k_gram_mfma_many, dim3(nb, nk), dim3(bd), glds, (hipStream_t)stream, dev_prog(p), gb, Xsoa, ldx, N, partial);
+    hipLaunchKernelGGL(k_reduce_partials_many, dim3((mmax * mmax + 3) / 4, nk), dim3(256), 0, (hipStream_t)stream, (const double*)partial, gb, nb,
+                       out);
+    return check_launch("k_gram_mfma_many");
 }
 
 int ttm_lorenz63_rk4(double* E, int64_t ld, int64_t N, double dt, int32_t nt, void* stream) {

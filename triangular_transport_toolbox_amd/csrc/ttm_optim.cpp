@@ -229,7 +229,8 @@ typedef int (*SentLaunch)(const double* cc, double* out_host, void* stream, void
 template <class Launch>
 int optimize_separable_with(Launch launch, int32_t m, const double* A, const double* b, double Ntotal, const double* lb,
                             const double* ub, double* x, double* sums_dev, double* sums_host, ttm_comm* comm, void* stream,
-                            int32_t maxiter, double* result, double delta = -1.0, SentLaunch sent = nullptr, void* sent_user = nullptr) {
+                            int32_t maxiter, double* result, double delta = -1.0, SentLaunch sent = nullptr, void* sent_user = nullptr,
+                            const double* pre_x = nullptr) {
     struct Ctx {
         Launch& launch;
         const double *A, *b;
@@ -243,14 +244,23 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         bool closed, have0;
         SentLaunch sent;                                     // the evaluation with self-validating results (no ticket, no mark)
         void* sent_user;
-    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,
-        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false, comm ? nullptr : sent, sent_user};
-    sums_host[1 + m] = 0.0;                                  // the completion mark (sums_host: >= 2 + m doubles)
+        const double* pre_x;                                 // an evaluation at this point is in flight already (its results
+    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,   // arrive in sums_host, armed)
+        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false, comm ? nullptr : sent, sent_user, (sent && !comm) ? pre_x : nullptr};
+    if (!c.pre_x) sums_host[1 + m] = 0.0;                    // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
         // sums[0] = sum_n log dS_n, sums[1 + i] = sum_n dPsi_{n,i} / dS_n  (TM:2990-3006), over the local samples
         double* out = c.comm ? c.sums_dev : c.sums_host;
-        if (c.closed && c.have0 && cc[0] + c.delta > 0.0) {
+        bool have = false;
+        if (c.pre_x) {                                       // the evaluation that was launched ahead: wait for it whatever it is good for
+            have = memcmp(cc, c.pre_x, (size_t)n * 8) == 0;
+            c.pre_x = nullptr;
+            c.rc = poll_values(c.sums_host, 1 + n, c.stream);
+            if (c.rc) return c.rc;
+        }
+        if (have) {
+        } else if (c.closed && c.have0 && cc[0] + c.delta > 0.0) {
             c.sums_host[0] = c.Nw * log(cc[0] + c.delta) + c.KN;
             c.sums_host[1] = c.Nw / (cc[0] + c.delta);
         } else if (c.sent) {
@@ -298,6 +308,59 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
     return c.rc ? c.rc : rc;
 }
 
+
+
+bool closed_form_enabled() {
+    static const bool closed = [] { const char* e = getenv("TTM_SEP_CLOSED_FORM"); return !e || atoi(e) != 0; }();
+    return closed;
+}
+
+// ttm_optimize_separable; pre_x != NULL: the rows of `work` are armed and an evaluation at pre_x is in flight (results: sums_host)
+int optimize_separable_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* A, const double* b, double Ntotal,
+                              double delta, const double* lb, const double* ub, double* x, double* work, uint32_t* counter,
+                              double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result,
+                              const double* pre_x) {
+    auto launch = [&](const double* cc, double* out, double* flag, double mark, void* st) {
+        return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
+    };
+    // up to 128 workgroups and no communicator: evaluations with self-validating partial sums and results (ttm_sentinel_fill
+    // arms the rows once; every evaluation leaves them armed)
+    struct SentArgs { const double* dPsi; int64_t ldp, N; int32_t m; double delta; double* work; } sa{dPsi, ldp, N, m, delta, work};
+    SentLaunch sent = nullptr;
+    if (!comm && (pre_x || ttm_sentinel_fill(work, m, N, stream) == TTM_OK))
+        sent = [](const double* cc, double* out_host, void* st, void* user) -> int {
+            const SentArgs& a = *(const SentArgs*)user;
+            return ttm_objective_sep_cached_sent(a.dPsi, a.ldp, a.N, a.m, cc, a.delta, a.work, out_host, st);
+        };
+    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result,
+                                   closed_form_enabled() ? delta : -1.0, sent, &sa, pre_x);
+}
+
+// one task of ttm_optimize_separable_batch on stream st
+int run_task(ttm_sep_task& q, int64_t N, double Ntotal, double delta, void* st, int32_t maxiter) {
+    if (q.dPsi)
+        return q.rc = (!q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
+                          ? (int)TTM_E_ARG
+                          : optimize_separable_cached(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
+                                                      q.sums_host, nullptr, st, maxiter, q.result, nullptr);
+    // derivative basis recomputed from the x_k column per evaluation
+    if (!q.xk || !q.kinds || !q.pars || !q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
+        return q.rc = TTM_E_ARG;
+    auto launch = [&](const double* cc, double* out, double* flag, double mark, void* s2) {
+        return ttm_objective_sep_direct_marked(q.xk, N, q.m, q.kinds, q.pars, cc, delta, q.work, q.counter, out, flag, mark, s2);
+    };
+    // (self-validating sums as in ttm_optimize_separable: the same finish, hence the same bits, as the cached basis)
+    struct SentArgs { const ttm_sep_task* q; int64_t N; double delta; } sa{&q, N, delta};
+    SentLaunch sent = nullptr;
+    if (ttm_sentinel_fill(q.work, q.m, N, st) == TTM_OK)
+        sent = [](const double* cc, double* out_host, void* s2, void* user) -> int {
+            const SentArgs& a = *(const SentArgs*)user;
+            return ttm_objective_sep_direct_sent(a.q->xk, a.N, a.q->m, a.q->kinds, a.q->pars, cc, a.delta, a.q->work, out_host, s2);
+        };
+    return q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
+                                          q.result, -1.0, sent, &sa);
+}
+
 }  // namespace
 
 extern "C" {
@@ -307,49 +370,63 @@ int ttm_optimize_separable(const double* dPsi, int64_t ldp, int64_t N, int32_t m
                            double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result) {
     if (!dPsi || !A || !b || !x || !work || !counter || !sums_host || m < 1 || N < 1 || !(Ntotal > 0.0)) return TTM_E_ARG;
     if (comm && !sums_dev) return TTM_E_ARG;
-    auto launch = [&](const double* cc, double* out, double* flag, double mark, void* st) {
-        return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
-    };
-    static const bool closed = [] { const char* e = getenv("TTM_SEP_CLOSED_FORM"); return !e || atoi(e) != 0; }();
-    // up to 128 workgroups and no communicator: evaluations with self-validating partial sums and results (ttm_sentinel_fill
-    // arms the rows once; every evaluation leaves them armed)
-    struct SentArgs { const double* dPsi; int64_t ldp, N; int32_t m; double delta; double* work; } sa{dPsi, ldp, N, m, delta, work};
-    SentLaunch sent = nullptr;
-    if (!comm && ttm_sentinel_fill(work, m, N, stream) == TTM_OK)
-        sent = [](const double* cc, double* out_host, void* st, void* user) -> int {
-            const SentArgs& a = *(const SentArgs*)user;
-            return ttm_objective_sep_cached_sent(a.dPsi, a.ldp, a.N, a.m, cc, a.delta, a.work, out_host, st);
-        };
-    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result, closed ? delta : -1.0,
-                                   sent, &sa);
+    return optimize_separable_cached(dPsi, ldp, N, m, A, b, Ntotal, delta, lb, ub, x, work, counter, sums_dev, sums_host, comm, stream, maxiter,
+                                     result, nullptr);
 }
 
 int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N, double Ntotal, double delta, int32_t nthreads,
                                  void* stream, int32_t maxiter) {
     if (!tasks || ntasks < 1 || N < 1) return TTM_E_ARG;
-    return run_batch(ntasks, nthreads, stream, [&](int t, void* st) {
-        ttm_sep_task& q = tasks[t];
-        if (q.dPsi)
-            return q.rc = ttm_optimize_separable(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter,
-                                                 nullptr, q.sums_host, nullptr, st, maxiter, q.result);
-        // derivative basis recomputed from the x_k column per evaluation
-        if (!q.xk || !q.kinds || !q.pars || !q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
-            return q.rc = TTM_E_ARG;
-        auto launch = [&](const double* cc, double* out, double* flag, double mark, void* s2) {
-            return ttm_objective_sep_direct_marked(q.xk, N, q.m, q.kinds, q.pars, cc, delta, q.work, q.counter, out, flag, mark, s2);
-        };
-        // (self-validating sums as in ttm_optimize_separable: the same finish, hence the same bits, as the cached basis)
-        struct SentArgs { const ttm_sep_task* q; int64_t N; double delta; } sa{&q, N, delta};
-        SentLaunch sent = nullptr;
-        if (ttm_sentinel_fill(q.work, q.m, N, st) == TTM_OK)
-            sent = [](const double* cc, double* out_host, void* s2, void* user) -> int {
-                const SentArgs& a = *(const SentArgs*)user;
-                return ttm_objective_sep_direct_sent(a.q->xk, a.N, a.q->m, a.q->kinds, a.q->pars, cc, a.delta, a.q->work, out_host, s2);
+#ifndef TTM_HOST_ONLY
+    // Components with ONE monotone term need one device evaluation (the closed form of optimize_separable_with takes over behind it).
+    // When at most one other component is in the batch - the filter's maps: two such components and one with special terms - no
+    // threads: the first evaluations of the one-term components are launched ahead on `stream`, the other component's loop runs
+    // behind them, and the one-term loops find their sums in place (a thread per component cost ~40 us each to start and fought
+    // the long loop for the runtime's launch lock).  The same evaluations at the same points: the same bits as the threaded batch.
+    {
+        std::vector<int> ahead, rest;
+        for (int t = 0; t < ntasks; ++t) {
+            const ttm_sep_task& q = tasks[t];
+            const bool one = q.dPsi && q.m == 1 && closed_form_enabled() && delta >= 0.0 && q.lb && q.lb[0] >= 0.0 && q.A && q.b && q.x &&
+                             q.work && q.counter && q.sums_host;
+            (one ? ahead : rest).push_back(t);
+        }
+        if (!ahead.empty() && rest.size() <= 1 && Ntotal > 0.0) {
+            std::vector<double> x0(ntasks, 0.0);
+            std::vector<char> flying(ntasks, 0);
+            int first_rc = TTM_OK;
+            for (int t : ahead) {
+                ttm_sep_task& q = tasks[t];
+                double v = q.x[0];                                       // the start as lbfgsb_minimize projects it
+                if (v <= q.lb[0]) v = q.lb[0];
+                else if (q.ub && q.ub[0] < INFINITY && v >= q.ub[0]) v = q.ub[0];
+                x0[t] = v;
+                if (ttm_sentinel_fill(q.work, 1, N, stream) != TTM_OK) continue;
+                arm_values(q.sums_host, 2);
+                if (ttm_objective_sep_cached_sent(q.dPsi, q.ldp, N, 1, &x0[t], delta, q.work, q.sums_host, stream) == TTM_OK) flying[t] = 1;
+            }
+            auto run_one = [&](int t) {
+                ttm_sep_task& q = tasks[t];
+                if (!q.dPsi) return -1;
+                q.rc = optimize_separable_cached(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
+                                                 q.sums_host, nullptr, stream, maxiter, q.result, flying[t] ? &x0[t] : nullptr);
+                if (q.rc && !first_rc) first_rc = q.rc;
+                return 0;
             };
-        return q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
-                                              q.result, -1.0, sent, &sa);
-    });
+            bool direct_rest = false;
+            for (int t : rest) if (run_one(t) < 0) direct_rest = true;
+            for (int t : ahead) run_one(t);
+            if (!direct_rest) return first_rc;
+            // (the other component recomputes its basis: it takes the general path below, alone)
+            if (first_rc) return first_rc;
+            const int t = rest[0];
+            return run_batch(1, 1, stream, [&](int, void* st) { return run_task(tasks[t], N, Ntotal, delta, st, maxiter); });
+        }
+    }
+#endif
+    return run_batch(ntasks, nthreads, stream, [&](int t, void* st) { return run_task(tasks[t], N, Ntotal, delta, st, maxiter); });
 }
+
 
 // (Gnn + ridge I)^-1 Gnm by Cholesky on the diagonally equilibrated matrix with one step of iterative refinement - the host
 // class's _normal_solve, ridge > 0.  G: the (n + m) x (n + m) Gram matrix, row-major; y: n x m.  false: not positive

@@ -72,6 +72,11 @@ def _parallel_copy(dst, src, threads=8):
 
 HOSTCOEF_MAX = 128           # coefficients of a component that travel as kernel arguments (csrc/ttm_dev.h: TTM_HOSTCOEF_MAX)
 
+class _Result:
+    """What an optimiser loop returns (the fields of scipy's OptimizeResult the class reads)."""
+    pass
+
+
 class transport_map():
 
     # the device the class allocates on; tests that inject the host test double
@@ -279,6 +284,26 @@ class transport_map():
         getter = getattr(torch._C, '_cuda_getCurrentRawStream', None)
         return ctypes.c_void_p(getter(idx) if getter is not None else torch.cuda.current_stream(idx).cuda_stream)
 
+    def _stream_obj(self):
+        """torch's current stream as a Stream object, kept while the raw handle stays the same (torch.cuda.current_stream()
+        resolves the device through four layers of Python on every call: 12 us, five times per filter update)."""
+        torch = _torch()
+        raw = self._stream().value
+        memo = getattr(self, '_stream_memo', None)
+        if memo is None or memo[0] != raw:
+            memo = self._stream_memo = (raw, torch.cuda.current_stream(self._dev_index))
+        return memo[1]
+
+    def _sync_stream(self):
+        """Wait for the work queued on the current stream (hipStreamSynchronize through the library: no Stream object)."""
+        if self._dev.type == 'cuda':
+            _capi.check(self._lib.ttm_stream_synchronize(self._stream()))
+
+    def _record_event(self):
+        ev = _torch().cuda.Event()
+        ev.record(self._stream_obj())
+        return ev
+
     @staticmethod
     def _ptr(t, offset=0):
         if t is None:
@@ -330,11 +355,20 @@ class transport_map():
             cm.u_enabled = False
         # (the component table changes when a placement changes the number of spline intervals - not in most updates of a
         # filter; the geometry always does: one short copy through the page-locked ring)
-        last = getattr(self, '_ucomp_host', None)
-        if last is None or last.shape != cm.ucomp.shape or not np.array_equal(last, cm.ucomp):
-            self._ucomp_host = np.array(cm.ucomp, copy=True)
+        self._u_layout = hash(cm.ucomp.tobytes())
+        if self._dev.type == 'cuda':
+            # geometry (fp64) and component table (int32) in ONE copy through the page-locked ring: the table rides along as the
+            # bit pattern of ceil(n / 2) doubles
+            uc = np.ascontiguousarray(cm.ucomp, dtype=np.int32)
+            if uc.shape[0] % 2:
+                uc = np.concatenate((uc, np.zeros(1, dtype=np.int32)))
+            ng = int(cm.ugeo.shape[0])
+            both = self._to_dev_staged(np.concatenate((np.ascontiguousarray(cm.ugeo, dtype=float), uc.view(np.float64))))
+            self._ugeo_d = both[:ng]
+            self._ucomp_d = both[ng:].view(torch.int32)
+        else:
             self._ucomp_d = self._to_dev(cm.ucomp, dtype=torch.int32)
-        self._ugeo_d = self._to_dev_staged(np.ascontiguousarray(cm.ugeo, dtype=float))
+            self._ugeo_d = self._to_dev(cm.ugeo)
         if getattr(self, '_ugrp_d', None) is None:
             self._ugrp_d = self._to_dev(cm.ugrp, dtype=torch.int32)
             self._umono_d = self._to_dev(cm.umono)
@@ -689,8 +723,7 @@ class transport_map():
         d = self._cm.d_cols
         plans = {}
         for var, qs in req.items():
-            prev, nxt, _ = quantile.plan(self._N, qs)
-            ranks = np.unique(np.concatenate((prev, nxt))).astype(np.int64)
+            ranks = quantile._plan_lists(self._N, qs)[3].astype(np.int64, copy=False)
             if len(ranks) > 16 or not 0 <= int(var) < d:
                 return None
             plans[int(var)] = ranks
@@ -698,8 +731,7 @@ class transport_map():
         for var, ranks in plans.items():
             self._launch_select(self._Xs[var, :self._N], ranks, dev[2 * d + 16 * var:2 * d + 16 * var + len(ranks)])
         host.copy_(dev, non_blocking=True)
-        if self._dev.type == 'cuda':
-            torch.cuda.current_stream().synchronize()
+        self._sync_stream()
         h = host.numpy()
         if getattr(self, '_moments_pending', None) is not None and self._moments_pending[0].data_ptr() == dev.data_ptr():
             self._moments_pending = None
@@ -865,9 +897,7 @@ class transport_map():
         slot[0][:n].numpy()[:] = host
         dev = torch.empty(n, dtype=torch.float64, device=self._dev) if out is None else out
         dev.copy_(slot[0][:n], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        slot[1] = ev
+        slot[1] = self._record_event()
         return dev
 
     def _fold_staged(self, host):
@@ -902,11 +932,14 @@ class transport_map():
         # zero-fill kernel (5 us) in front of the fold.  (Stream order protects the old contents' readers.)
         nfold = int(self._lib.ttm_fold_size(self._pp))
         prev = slot[4]() if slot[4] is not None else None
-        if prev is None and slot[5] is not None and slot[6] == (self._epoch, nfold):
+        # (`_u_layout`: the component table of the U section - a new special-term placement moves constants, not slots, unless it
+        # changes the number of spline intervals)
+        lkey = (id(self._cm), getattr(self, '_u_layout', self._epoch), nfold)
+        if prev is None and slot[5] is not None and slot[6] == lkey:
             fold = slot[5]
         else:
             fold = self._zeros(nfold)
-        slot[5], slot[6] = fold, (self._epoch, nfold)
+        slot[5], slot[6] = fold, lkey
         st = self._stream()
         pending = None
         rc = -1
@@ -914,7 +947,7 @@ class transport_map():
             # fold + U section and the default inverse tables as ONE launch (include/ttm.h: ttm_setup_staged - the table workgroups
             # fold for themselves into a scratch copy that belongs to this map: launches on one stream run one after the other)
             scratch = getattr(self, '_fold2', None)
-            skey = (self._epoch, nfold, st.value if hasattr(st, 'value') else st)
+            skey = (lkey, st.value if hasattr(st, 'value') else st)
             if scratch is None or scratch[0] != skey:
                 scratch = self._fold2 = (skey, self._zeros(nfold))
             coef._ttm_fold = fold
@@ -930,8 +963,7 @@ class transport_map():
         coef._ttm_tables = {}
         if pending is None and self._eager_tables():
             pending = self._launch_default_tables(coef, h_unsorted=slot[2])
-        done = torch.cuda.Event()
-        done.record()
+        done = self._record_event()
         slot[3] = done
         import weakref
         slot[4] = weakref.ref(coef)
@@ -1438,8 +1470,7 @@ class transport_map():
             # one stream synchronisation per evaluation (no H2D / D2H copies, two launches)
             torch = _torch()
             self._objective_launch(k, coef_k, work)
-            if self._dev.type == 'cuda':
-                torch.cuda.current_stream().synchronize()
+            self._sync_stream()
             return self._obj_out[:nout].numpy().copy()
         out = self._empty(nout)
         ck = self._to_dev(coef_k)
@@ -1522,7 +1553,7 @@ class transport_map():
         self._allreduce(out)
         return out.cpu().numpy().reshape(m, m)
 
-    def _gram_many(self, K):
+    def _gram_many(self, K, before_read=None):
         """Gram matrices of several components: the launches back to back, ONE all-reduce and ONE device-to-host
         copy for all of them."""
         torch = _torch()
@@ -1539,13 +1570,20 @@ class transport_map():
         _, sizes, offs, out, pinned = memo
         work = self._workspace(self._lib.ttm_reduce_work_size(max(m * m for m in sizes)))
         st = self._stream()
-        for k, o in zip(key[0], offs):
-            _capi.check(self._lib.ttm_gram(self._pp, k, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
-                                           self._ptr(out, o), st))
+        ks = np.asarray(key[0], dtype=np.int32)
+        rc = self._lib.ttm_gram_many(self._pp, ctypes.c_void_p(ks.ctypes.data), len(ks), self._ptr(self._Xs), self._Xs.shape[1],
+                                     self._N, self._ptr(work), self._ptr(out), st) if len(ks) > 1 else _capi.TTM_E_UNSUPPORTED
+        if rc == _capi.TTM_E_UNSUPPORTED:               # (one component, or shapes the batched launch does not take)
+            for k, o in zip(key[0], offs):
+                _capi.check(self._lib.ttm_gram(self._pp, k, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
+                                               self._ptr(out, o), st))
+        else:
+            _capi.check(rc)
         self._allreduce(out)
         pinned.copy_(out, non_blocking=True)
-        if self._dev.type == 'cuda':
-            torch.cuda.current_stream().synchronize()
+        if before_read is not None:
+            before_read()                               # (launches that do not need the matrices: they run while the host waits)
+        self._sync_stream()
         host = pinned.numpy().copy()
         return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(key[0], offs, sizes)}
 
@@ -1668,8 +1706,7 @@ class transport_map():
         if cache is not None and cache[0] == int(k) and self._dist() is None:
             m = len(c)
             self._sep_objective_launch(c)
-            if self._dev.type == 'cuda':
-                _torch().cuda.current_stream().synchronize()
+            self._sync_stream()
             sums = self._obj_out[:1 + m].numpy().copy()
         else:
             sums = self._device_sums(k, np.concatenate((np.zeros(int(self._cm.n_nm[k])), c)))
@@ -2014,7 +2051,6 @@ class transport_map():
                 stop += 1
             batch = K[start:stop]
             start = stop
-            grams = self._gram_many(batch)
             n = len(batch)
             # (scratch of the native loops, kept between calls: reduction workspaces, ticket counters - the kernels leave them
             # zero -, page-locked result vectors and the cached derivative bases; the filter optimises the same components
@@ -2026,6 +2062,18 @@ class transport_map():
                 scr = self._sep_batch_scratch = (skey, wsz, self._empty(n * wsz), self._zeros(n * 16, dtype=torch.int32),
                                                  torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {})
             _, wsz, work, counters, sums, dpsi_keep = scr
+
+            def launch_bases():
+                # the cached derivative bases: queued behind the Gram kernels, in front of the host's wait for the matrices
+                for k in batch:
+                    if direct[k] is None:
+                        m = int(self._cm.n_mon[k])
+                        dpsi = dpsi_keep.get(k)
+                        if dpsi is None or dpsi.shape[0] != m:
+                            dpsi = dpsi_keep[k] = self._cols(m, self._N)
+                        _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
+                                                        self._ptr(dpsi), dpsi.shape[1], self._stream()))
+            grams = self._gram_many(batch, before_read=launch_bases)
             tasks = (_capi.ttm_sep_task * n)()
             keep = []
             # special-term kinds and constants of the components that recompute their basis: one upload for the batch
@@ -2042,13 +2090,7 @@ class transport_map():
             for i, k in enumerate(batch):
                 A, solve_nonmon = self.separable_setup(k, G=grams[k])
                 m = int(self._cm.n_mon[k])
-                dpsi = None
-                if direct[k] is None:
-                    dpsi = dpsi_keep.get(k)
-                    if dpsi is None or dpsi.shape[0] != m:
-                        dpsi = dpsi_keep[k] = self._cols(m, self._N)
-                    _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
-                                                    self._ptr(dpsi), dpsi.shape[1], self._stream()))
+                dpsi = dpsi_keep[k] if direct[k] is None else None
                 A = np.ascontiguousarray(A, dtype=float)
                 b = np.ascontiguousarray(self.delta * np.sum(A, axis=-1))
                 x = np.array(self.coeffs_mon[k], dtype=float, copy=True)
@@ -2074,8 +2116,6 @@ class transport_map():
                 self._sep_batch_scratch = None          # (a loop that was cut short may have left a ticket counter behind)
             _capi.check(rc)
             for i, k in enumerate(batch):
-                class _Result:
-                    pass
                 out = _Result()
                 r = tasks[i].result
                 out.x, out.fun, out.nit, out.nfev, out.status = keep[i][2], float(r[0]), int(r[2]), int(r[3]), int(r[4])
@@ -2203,7 +2243,7 @@ class transport_map():
         for k in K_local:
             if batched is not None and self.monotonicity == "separable monotonicity":
                 opt = batched[k]
-                self.coeffs_mon[k] = copy.deepcopy(opt.x)
+                self.coeffs_mon[k] = np.array(opt.x, copy=True)
                 self.coeffs_nonmon[k] = opt.solve_nonmon(opt.x)
             elif batched is not None:
                 opt = batched[k]
