@@ -669,6 +669,8 @@ typedef struct ttm_sep_task {
     const double* xk;            /* device, the component's x_k column (N doubles) */
     const int32_t* kinds;        /* device, m */
     const double* pars;          /* device, 5 m */
+    int32_t armed;               /* in: 1 = the rows of partial sums in `work` are armed (ttm_sentinel_fill) for this m and N - a
+                                    previous call on the same `work` left them so; out: 1 when this call leaves them armed   */
 } ttm_sep_task;
 /* ttm_separable_reduce_l2 (host arithmetic only): the reduced separable problem with L2 regularisation (TM:3021-3050,
  * 3148-3169) from the (n + m) x (n + m) Gram matrix G of [Psi_nonmon | Psi_mon] (row-major, host): A (m x m) and sol (n x m,

@@ -71,6 +71,69 @@ def test_import_export_and_moments(backend):
         assert np.array_equal(tm._export(Xs, N, 1 if d > 1 else 0, d - (1 if d > 1 else 0), False), ref[:, (1 if d > 1 else 0):])
 
 
+def test_moments_and_standardisation_of_device_resident_columns(backend, ttm_opt):
+    """reset_device standardises column-major samples without a row-major copy (ttm_colstats_cols: up to 8 columns and 131 072
+    rows in ONE launch - per-workgroup means and squared deviations, Chan's combination in workgroup order -, then
+    ttm_standardize_cols).  Against NumPy, against the four-launch moments of the exported rows (option colstats_one = 0), and - on
+    the device library - bit for bit against ttm_colstats of the row-major copy, whatever the offset of the data."""
+    import torch
+    tm = small_map()
+    rng = np.random.default_rng(3)
+    for (N, d, offset) in ((1, 1, 0.0), (5, 2, 0.0), (1023, 4, 1e6), (4097, 8, -3.0), (100003, 4, 25.0), (131072, 3, 0.0)):
+        X = rng.standard_normal((N, d)) * rng.uniform(0.5, 3, d) + rng.uniform(-2, 2, d) + offset
+        if N > 100:
+            X[0] += 40.0                                                 # an outlier in the first row
+        Xc = tm._cols(d, N, zero=True)
+        Xc[:, :N].copy_(torch.from_numpy(np.ascontiguousarray(X.T)))
+        mean, sd = tm._empty(d), tm._empty(d)
+        work = tm._workspace(tm._lib.ttm_colstats_work_size(N, d))
+        rc = tm._lib.ttm_colstats_cols(tm._ptr(Xc), Xc.shape[1], N, d, tm._ptr(mean), tm._ptr(sd), tm._ptr(work), tm._stream())
+        assert rc == 0
+        m_, s_ = mean.cpu().numpy(), sd.cpu().numpy()
+        sd_ref = X.std(axis=0)
+        assert relerr(m_, X.mean(axis=0)) < 1e-13
+        assert np.all(np.abs(s_ - sd_ref) <= 1e-13 * np.maximum(sd_ref, 1e-300)) or N == 1
+        Xs = tm._cols(d, N, zero=True)
+        assert tm._lib.ttm_standardize_cols(tm._ptr(Xc), Xc.shape[1], N, d, tm._ptr(mean), tm._ptr(sd), tm._ptr(Xs), Xs.shape[1],
+                                            tm._stream()) == 0
+        if N > 1:
+            assert np.array_equal(Xs[:, :N].cpu().numpy(), ((X - m_) / s_).T)
+        # the row-major entry point: the same sums
+        Xr = tm._to_dev(X)
+        mean2, sd2 = tm._empty(d), tm._empty(d)
+        assert tm._lib.ttm_colstats(tm._ptr(Xr), N, d, tm._ptr(mean2), tm._ptr(sd2), tm._ptr(work), tm._stream()) == 0
+        if backend == 'hip':
+            assert np.array_equal(mean2.cpu().numpy(), m_) and np.array_equal(sd2.cpu().numpy(), s_)
+        ttm_opt('colstats_one', 0)
+        assert tm._lib.ttm_colstats(tm._ptr(Xr), N, d, tm._ptr(mean2), tm._ptr(sd2), tm._ptr(work), tm._stream()) == 0
+        assert relerr(mean2.cpu().numpy(), m_) < 1e-13
+        assert np.all(np.abs(sd2.cpu().numpy() - s_) <= 1e-12 * np.maximum(s_, 1e-300)) or N == 1
+        ttm_opt('colstats_one', -1)
+    # outside the one-launch range the column-major entry declines (the caller exports and takes ttm_colstats)
+    Xc = tm._cols(9, 64, zero=True)
+    mean, sd = tm._empty(9), tm._empty(9)
+    work = tm._workspace(tm._lib.ttm_colstats_work_size(64, 9))
+    assert tm._lib.ttm_colstats_cols(tm._ptr(Xc), Xc.shape[1], 64, 9, tm._ptr(mean), tm._ptr(sd), tm._ptr(work), tm._stream()) == -4
+
+
+def test_gram_matrices_of_a_batch_equal_component_by_component(backend):
+    """ttm_gram_many (one launch + one reduction for the components of an optimiser batch) against ttm_gram per component: the
+    same tiles and the same order of the partial sums - bit for bit on the device library."""
+    from triangular_transport_toolbox_amd.transport_map import transport_map
+    npz, desc = load_case('c3_sep')
+    X = case_X('c3_sep', npz)
+    tm = transport_map(X=X, monotone=desc['monotone'], nonmonotone=desc['nonmonotone'], verbose=False, **ctor_kwargs(desc))
+    K = list(range(tm.D))
+    many = tm._gram_many(K)
+    for k in K:
+        one = tm._gram(k)
+        assert many[k].shape == one.shape
+        if backend == 'hip':
+            assert np.array_equal(many[k], one)
+        else:
+            assert relerr(many[k], one) < 1e-14
+
+
 @pytest.mark.parametrize('name,ns', [('c3_sep', '2'), ('c5_sep', '2'), ('c2a_int', '2'), ('misc_grid', '2'), ('c3_sep', '4')])
 def test_multi_sample_kernel_variants(backend, name, ns, monkeypatch, ttm_opt):
     """The 2- and 4-samples-per-thread kernels (chosen automatically for large ensembles) give the same

@@ -374,6 +374,37 @@ def test_device_resident_filter_matches_reference_and_host_loop(backend):
     assert np.array_equal(ya, yb) and abs(ya.mean()) < 0.15 and abs(ya.std() - 2.0) < 0.1
 
 
+def test_filter_batch_without_threads_and_self_validating_sums_make_the_same_bits(backend, ttm_opt):
+    """The optimiser batch of the filter map - two components with ONE monotone term and one with special terms - runs without
+    host threads (the one-term components' single device evaluation launched ahead, csrc/ttm_optim.cpp), with self-validating
+    partial sums instead of ticket + completion mark (k_objective_sep_cached, sentinel finish).  Neither changes an
+    evaluation point or the order of a sum: the same coefficients, bit for bit, as component by component, as the
+    ticket finish (option sep_sentinel = 0) and as the 17-launch order statistics / four-launch moments of the reset."""
+    from triangular_transport_toolbox_amd import entf
+    npz, desc = load_case('entf')
+    ens = npz['ens0']
+    noises = [npz['noise_0_%d' % i] for i in range(3)]
+
+    def run(threads=3, **opts):
+        for name, v in opts.items():
+            ttm_opt(name, v)
+        tm = entf.make_filter_map(ens.shape[0], maxorder=3, lmbda=float(npz['lmbda']))
+        tm.optimizer_threads = threads
+        out = entf.assimilate(tm, ens, npz['obs'][0], list(noises))
+        for name in opts:
+            ttm_opt(name, -1)
+        return out, [np.array(c) for c in tm.coeffs_mon], [np.array(c) for c in tm.coeffs_nonmon]
+    base = run()
+    assert relerr(base[0], npz['ens_0_2']) < 1e-6
+    for other in (run(threads=1), run(sep_sentinel=0), run(select_coop=0)):
+        assert np.array_equal(other[0], base[0])
+        for a, b in zip(other[1] + other[2], base[1] + base[2]):
+            assert np.array_equal(a, b)
+    # the four-launch moments differ from the one-launch ones in the last bits of mean and standard deviation
+    loose = run(colstats_one=0)
+    assert relerr(loose[0], base[0]) < 1e-9
+
+
 def test_ents_backward_smoother_matches_reference(backend):
     """Ensemble Transport Smoother (example_07.py:368-465): the 6-column block map (skip_dimensions = 3, probabilist's
     Hermite polynomials with 'HF' terms, L2), three backward steps of reset -> optimize -> map -> inverse_map with

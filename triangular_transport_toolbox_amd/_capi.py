@@ -22,7 +22,7 @@ class ttm_sep_task(ctypes.Structure):
     """Mirror of `struct ttm_sep_task` (include/ttm.h: one component problem of ttm_optimize_separable_batch)."""
     _fields_ = [('dPsi', c_vp), ('ldp', c_i64), ('m', c_i32), ('rc', c_i32), ('A', c_vp), ('b', c_vp), ('lb', c_vp), ('ub', c_vp),
                 ('x', c_vp), ('work', c_vp), ('counter', c_vp), ('sums_host', c_vp), ('result', c_dbl * 5),
-                ('xk', c_vp), ('kinds', c_vp), ('pars', c_vp)]
+                ('xk', c_vp), ('kinds', c_vp), ('pars', c_vp), ('armed', c_i32)]
 
 
 class ttm_int_task(ctypes.Structure):

@@ -319,7 +319,7 @@ bool closed_form_enabled() {
 int optimize_separable_cached(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* A, const double* b, double Ntotal,
                               double delta, const double* lb, const double* ub, double* x, double* work, uint32_t* counter,
                               double* sums_dev, double* sums_host, ttm_comm* comm, void* stream, int32_t maxiter, double* result,
-                              const double* pre_x) {
+                              const double* pre_x, int32_t* armed = nullptr) {
     auto launch = [&](const double* cc, double* out, double* flag, double mark, void* st) {
         return ttm_objective_sep_cached_marked(dPsi, ldp, N, m, cc, delta, work, counter, out, flag, mark, st);
     };
@@ -327,13 +327,16 @@ int optimize_separable_cached(const double* dPsi, int64_t ldp, int64_t N, int32_
     // arms the rows once; every evaluation leaves them armed)
     struct SentArgs { const double* dPsi; int64_t ldp, N; int32_t m; double delta; double* work; } sa{dPsi, ldp, N, m, delta, work};
     SentLaunch sent = nullptr;
-    if (!comm && (pre_x || ttm_sentinel_fill(work, m, N, stream) == TTM_OK))
+    // (armed: the caller vouches that a previous loop on this `work` left the rows armed for the same m and N - no fill launch)
+    if (!comm && (pre_x || (armed && *armed) || ttm_sentinel_fill(work, m, N, stream) == TTM_OK))
         sent = [](const double* cc, double* out_host, void* st, void* user) -> int {
             const SentArgs& a = *(const SentArgs*)user;
             return ttm_objective_sep_cached_sent(a.dPsi, a.ldp, a.N, a.m, cc, a.delta, a.work, out_host, st);
         };
-    return optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result,
-                                   closed_form_enabled() ? delta : -1.0, sent, &sa, pre_x);
+    const int rc = optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result,
+                                           closed_form_enabled() ? delta : -1.0, sent, &sa, pre_x);
+    if (armed) *armed = (sent && rc == TTM_OK) ? 1 : 0;
+    return rc;
 }
 
 // one task of ttm_optimize_separable_batch on stream st
@@ -342,7 +345,7 @@ int run_task(ttm_sep_task& q, int64_t N, double Ntotal, double delta, void* st, 
         return q.rc = (!q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
                           ? (int)TTM_E_ARG
                           : optimize_separable_cached(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
-                                                      q.sums_host, nullptr, st, maxiter, q.result, nullptr);
+                                                      q.sums_host, nullptr, st, maxiter, q.result, nullptr, &q.armed);
     // derivative basis recomputed from the x_k column per evaluation
     if (!q.xk || !q.kinds || !q.pars || !q.A || !q.b || !q.x || !q.work || !q.counter || !q.sums_host || q.m < 1 || !(Ntotal > 0.0))
         return q.rc = TTM_E_ARG;
@@ -352,13 +355,15 @@ int run_task(ttm_sep_task& q, int64_t N, double Ntotal, double delta, void* st, 
     // (self-validating sums as in ttm_optimize_separable: the same finish, hence the same bits, as the cached basis)
     struct SentArgs { const ttm_sep_task* q; int64_t N; double delta; } sa{&q, N, delta};
     SentLaunch sent = nullptr;
-    if (ttm_sentinel_fill(q.work, q.m, N, st) == TTM_OK)
+    if (q.armed || ttm_sentinel_fill(q.work, q.m, N, st) == TTM_OK)
         sent = [](const double* cc, double* out_host, void* s2, void* user) -> int {
             const SentArgs& a = *(const SentArgs*)user;
             return ttm_objective_sep_direct_sent(a.q->xk, a.N, a.q->m, a.q->kinds, a.q->pars, cc, a.delta, a.q->work, out_host, s2);
         };
-    return q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
-                                          q.result, -1.0, sent, &sa);
+    q.rc = optimize_separable_with(launch, q.m, q.A, q.b, Ntotal, q.lb, q.ub, q.x, nullptr, q.sums_host, nullptr, st, maxiter,
+                                   q.result, -1.0, sent, &sa);
+    q.armed = (sent && q.rc == TTM_OK) ? 1 : 0;
+    return q.rc;
 }
 
 }  // namespace
@@ -401,7 +406,7 @@ int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N,
                 if (v <= q.lb[0]) v = q.lb[0];
                 else if (q.ub && q.ub[0] < INFINITY && v >= q.ub[0]) v = q.ub[0];
                 x0[t] = v;
-                if (ttm_sentinel_fill(q.work, 1, N, stream) != TTM_OK) continue;
+                if (!q.armed && ttm_sentinel_fill(q.work, 1, N, stream) != TTM_OK) continue;
                 arm_values(q.sums_host, 2);
                 if (ttm_objective_sep_cached_sent(q.dPsi, q.ldp, N, 1, &x0[t], delta, q.work, q.sums_host, stream) == TTM_OK) flying[t] = 1;
             }
@@ -409,7 +414,7 @@ int ttm_optimize_separable_batch(ttm_sep_task* tasks, int32_t ntasks, int64_t N,
                 ttm_sep_task& q = tasks[t];
                 if (!q.dPsi) return -1;
                 q.rc = optimize_separable_cached(q.dPsi, q.ldp, N, q.m, q.A, q.b, Ntotal, delta, q.lb, q.ub, q.x, q.work, q.counter, nullptr,
-                                                 q.sums_host, nullptr, stream, maxiter, q.result, flying[t] ? &x0[t] : nullptr);
+                                                 q.sums_host, nullptr, stream, maxiter, q.result, flying[t] ? &x0[t] : nullptr, &q.armed);
                 if (q.rc && !first_rc) first_rc = q.rc;
                 return 0;
             };

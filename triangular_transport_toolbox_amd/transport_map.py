@@ -708,6 +708,8 @@ class transport_map():
             self._to_dev_staged(self._cm.dpar, out=self._dpar_d)        # (page-locked staging: no synchronous copy in the runtime)
         else:
             self._dpar_d.copy_(_torch().from_numpy(self._cm.dpar))
+        self._dpar_version = getattr(self, '_dpar_version', 0) + 1
+        self._gram_ahead()
         self._epoch += 1                         # (the folded special-term records depend on centres and scales)
         self._u_rejected = False
         self._refresh_uform()
@@ -1553,7 +1555,7 @@ class transport_map():
         self._allreduce(out)
         return out.cpu().numpy().reshape(m, m)
 
-    def _gram_many(self, K, before_read=None):
+    def _gram_many(self, K, before_read=None, launch_only=False):
         """Gram matrices of several components: the launches back to back, ONE all-reduce and ONE device-to-host
         copy for all of them."""
         torch = _torch()
@@ -1568,6 +1570,18 @@ class transport_map():
             pinned = torch.empty(offs[-1], dtype=torch.float64, pin_memory=self._dev.type == 'cuda')
             memo = self._gram_memo = (key, sizes, offs, out, pinned)
         _, sizes, offs, out, pinned = memo
+        # (launched ahead by the reset that placed the special terms - _gram_ahead - and still good: same samples, same constants)
+        token = (key, id(self._Xs), int(self._N), getattr(self, '_dpar_version', 0))
+        ahead = getattr(self, '_gram_inflight', None)
+        self._gram_inflight = None
+        if launch_only:
+            self._gram_inflight = token
+        elif ahead == token:
+            if before_read is not None:
+                before_read()
+            self._sync_stream()
+            host = pinned.numpy().copy()
+            return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(key[0], offs, sizes)}
         work = self._workspace(self._lib.ttm_reduce_work_size(max(m * m for m in sizes)))
         st = self._stream()
         ks = np.asarray(key[0], dtype=np.int32)
@@ -1581,11 +1595,27 @@ class transport_map():
             _capi.check(rc)
         self._allreduce(out)
         pinned.copy_(out, non_blocking=True)
+        if launch_only:
+            return None
         if before_read is not None:
             before_read()                               # (launches that do not need the matrices: they run while the host waits)
         self._sync_stream()
         host = pinned.numpy().copy()
         return {k: host[o:o + m * m].reshape(m, m) for k, o, m in zip(key[0], offs, sizes)}
+
+    def _gram_ahead(self):
+        """The Gram matrices the next optimize() will ask for, launched as soon as the special-term constants of a reset are on
+        the device - in front of the host's work on the spline geometry, which the matrices do not depend on (the filter: the
+        kernels run while the host prepares the U-form tables).  Only when the last optimize() took all its components as one
+        batch of the native loops and nothing about the map's structure has changed since; a reset that is not followed by
+        optimize() has launched them in vain."""
+        hint = getattr(self, '_gram_hint', None)
+        if hint is None or self._dist() is not None or hint[1] != id(self._cm):
+            return
+        try:
+            self._gram_many(list(hint[0]), launch_only=True)
+        except Exception:                               # noqa: BLE001  (a hint, never an error: optimize() launches them itself)
+            self._gram_inflight = None
 
     def separable_setup(self, k, G=None):
         """The reduced separable problem of TM:2959-3050 from the Gram matrix of
@@ -2060,8 +2090,8 @@ class transport_map():
             if scr is None or scr[0] != skey:
                 wsz = int(self._lib.ttm_reduce_work_size(17))
                 scr = self._sep_batch_scratch = (skey, wsz, self._empty(n * wsz), self._zeros(n * 16, dtype=torch.int32),
-                                                 torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {})
-            _, wsz, work, counters, sums, dpsi_keep = scr
+                                                 torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {}, {})
+            _, wsz, work, counters, sums, dpsi_keep, armed = scr
 
             def launch_bases():
                 # the cached derivative bases: queued behind the Gram kernels, in front of the host's wait for the matrices
@@ -2074,6 +2104,8 @@ class transport_map():
                         _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
                                                         self._ptr(dpsi), dpsi.shape[1], self._stream()))
             grams = self._gram_many(batch, before_read=launch_bases)
+            # (a reset of the same map launches these matrices ahead: _gram_ahead)
+            self._gram_hint = (tuple(batch), id(self._cm)) if len(batch) == len(K) else None
             tasks = (_capi.ttm_sep_task * n)()
             keep = []
             # special-term kinds and constants of the components that recompute their basis: one upload for the batch
@@ -2107,6 +2139,7 @@ class transport_map():
                     t.kinds = kinds_d.data_ptr() + 4 * where[k][0]
                     t.pars = pars_d.data_ptr() + 8 * where[k][1]
                 t.A, t.b, t.lb, t.ub, t.x = A.ctypes.data, b.ctypes.data, lb.ctypes.data, ub.ctypes.data, x.ctypes.data
+                t.armed = armed.get(k, 0)                # (the rows of partial sums this slice of `work` was left with)
                 t.work = work.data_ptr() + 8 * i * wsz
                 t.counter = counters.data_ptr() + 4 * 16 * i
                 t.sums_host = sums.data_ptr() + 8 * 32 * i
@@ -2115,6 +2148,8 @@ class transport_map():
             if rc != 0:
                 self._sep_batch_scratch = None          # (a loop that was cut short may have left a ticket counter behind)
             _capi.check(rc)
+            for i, k in enumerate(batch):
+                armed[k] = int(tasks[i].armed)
             for i, k in enumerate(batch):
                 out = _Result()
                 r = tasks[i].result
