@@ -432,6 +432,29 @@ def other_configs(torch, names, steps=40):
                 lb = 8.0 * N * (d_used(tm) + 1)
                 r['pullback_logdet_only_ms'] = gl
                 roof['pullback_logdet_only'] = {'kernel': _last_kernel(tm), 'bytes': lb, 'achieved': lb / (gl * 1e-3) / 1e9}
+            # the step - and the step with the density terms, "forward + inverse + pullback" of BASELINE configs[1] - as ONE launch
+            # (ttm_roundtrip: maps of at most four components; the columns of a tile are read once, z stays in registers).  The same
+            # ALGORITHMIC bytes as the launches it stands for; checked against them bit for bit before it is timed.
+            Xr = tm._cols(d, N, zero=True)
+            tm.roundtrip_device(Xs, N, coef=coef, Z=Z, Xr=Xr)
+            rt_kernel = _last_kernel(tm)
+            if rt_kernel.startswith('k_band_few_roundtrip'):
+                step()
+                same = bool(torch.equal(Xr[:, :N], Xinv[:, :N]))
+                gr = graph_ms(torch, lambda: tm.roundtrip_device(Xs, N, coef=coef, Z=Z, Xr=Xr))
+                tm.roundtrip_device(Xs, N, coef=coef, Z=Z, Xr=Xr, logdet=ld, sigma=sigma, sumsq=ss)
+                # (with the density terms the library leaves the step to two launches - the fused kernel runs out of registers there)
+                gd = graph_ms(torch, lambda: tm.roundtrip_device(Xs, N, coef=coef, Z=Z, Xr=Xr, logdet=ld, sigma=sigma, sumsq=ss)) \
+                    if _last_kernel(tm).startswith('k_band_few_roundtrip') else None
+                if gr is not None:
+                    r.update(roundtrip_fused_ms=gr, roundtrip_fused_equals_two_launches=same, value_fused=N * D / (gr * 1e-3))
+                    roof['step_fused'] = {'kernel': rt_kernel, 'bytes': fb + ib, 'achieved': (fb + ib) / (gr * 1e-3) / 1e9,
+                                          'hbm_bytes_moved': 8.0 * N * (d_used(tm) + 2 * D)}
+                if gd is not None:
+                    db = fb + ib + 16.0 * N
+                    r['roundtrip_fused_with_density_ms'] = gd
+                    roof['step_fused_with_density'] = {'kernel': 'k_band_few_roundtrip<density>', 'bytes': db, 'achieved': db / (gd * 1e-3) / 1e9,
+                                                       'hbm_bytes_moved': 8.0 * N * (d_used(tm) + 2 * D + 2)}
             for v in roof.values():
                 if isinstance(v, dict):
                     v['frac'] = v['achieved'] / HBM_PEAK_GBS

@@ -485,6 +485,19 @@ int ttm_inverse_table_build_index(const ttm_program* p, const double* coef, cons
  * into LDS by DMA instead of assembling them per workgroup.  A pure function of the table: passing it changes no result.
  * ttm_inverse_table_image_doubles returns 0 when the map / table geometry has no such kernel (img must then be NULL).       */
 int64_t ttm_inverse_table_image_doubles(const ttm_program* p, int32_t k0, int32_t k1, int32_t T, int32_t nb);
+/* ---- forward map + table inverse of the image in ONE launch (maps of at most four components, N >= 65 536) -----------------
+ * What BASELINE configs[1] times as a step - map(X), then inverse_map of the result (TM:2554-2558, 2646-2712; optionally the
+ * log-determinant and the sum of squares of the pullback density, TM:3663-3789) - as one pass over the ensemble: Zsoa (nullable)
+ * = S(X), Xr = S^-1(S(X)) with the conditioning columns (if any) read from Xsoa; the columns of a tile are read once and z stays in
+ * registers (k_band_few_roundtrip).  The same bits as ttm_forward followed by ttm_inverse_table on the default tables.  tab_x ..
+ * nb: the sorted default tables of all components as for ttm_inverse_table (h_y_affine required).  TTM_E_UNSUPPORTED: not for
+ * this map / these options, or a shape the one launch is not faster for (a sweep that reaches three columns back, the density
+ * terms: option `roundtrip_fused` = 1 runs them anyway): make the two calls.                                                  */
+int ttm_roundtrip(const ttm_program* p, const double* coef, const double* fold, const double* Xsoa, int64_t ldx, int64_t N,
+                  double* Zsoa, int64_t ldz, double* Xr, int64_t ldr, double* logdet, const double* sigma, double* sumsq,
+                  const double* tab_x, int32_t T, const double* h_y_affine, const double* tmin, const double* tmax,
+                  const int32_t* bkt, int32_t nb, void* stream);
+
 /* ttm_setup_staged: ttm_fold_staged and ttm_inverse_table_build_index of ALL components (k0 = 0, k1 = D) as ONE launch whose two
  * kinds of workgroups run side by side (the tables need only the folded coefficients: the table workgroups fold for themselves into
  * fold2, a scratch of ttm_fold_size doubles, zero-filled once per layout like fold, that nobody else reads).  Every output as the

@@ -267,6 +267,11 @@ int ttm_colstats(const double* Xrow, int64_t N, int32_t d, double* mean, double*
 }
 
 int ttm_stream_synchronize(void*) { return TTM_OK; }
+// (one launch for forward + inverse: a device matter - the double declines and the class makes the two calls)
+int ttm_roundtrip(const ttm_program*, const double*, const double*, const double*, int64_t, int64_t, double*, int64_t, double*, int64_t, double*,
+                  const double*, double*, const double*, int32_t, const double*, const double*, const double*, const int32_t*, int32_t, void*) {
+    return TTM_E_UNSUPPORTED;
+}
 
 int ttm_colstats_cols(const double* Xcols, int64_t ld, int64_t N, int32_t d, double* mean, double* sd, double*, void*) {
     if (d > 8 || N > 131072) return TTM_E_UNSUPPORTED;            // (the device library's one-launch range)

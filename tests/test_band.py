@@ -535,3 +535,57 @@ def test_one_launch_setup_equals_the_two_launches(case, ttm_opt):
     for k in range(tm.D):
         om.coeffs_mon[k], om.coeffs_nonmon[k] = tm.coeffs_mon[k].copy(), tm.coeffs_nonmon[k].copy()
     assert relerr(Xi, om.inverse_map(Zin, X_star=X[:, :E] if E else None)) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [c for c in sorted(CASES) if CASES[c].get('few')])
+def test_roundtrip_in_one_launch_equals_forward_then_inverse(case, ttm_opt):
+    """ttm_roundtrip / roundtrip_device (k_band_few_roundtrip: the forward sweep, optionally the density terms, and the table inverse
+    of the image as ONE pass over the ensemble, z in registers) against forward_device followed by inverse_device: the same
+    statements in the same order, so the same bits - with and without the density terms, conditioning columns, one or several
+    tiles per workgroup, an odd number of rows; and the two calls when the fused launch is switched off."""
+    tm, om, X, rng = _build(case)
+    lib = tm._lib
+    lib.ttm_last_kernel.restype = ctypes.c_char_p
+    D, d = CASES[case]['D'], CASES[case]['d']
+    E = d - D
+    N, Xs = tm._N, tm._Xs
+    ttm_opt('u_loader', 1); ttm_opt('band_fwd', 1); ttm_opt('band_inv', 1)
+    ttm_opt('roundtrip_fused', 1)             # (every shape through the fused kernel, also those the default leaves to the two calls)
+    sigma = tm._to_dev(np.asarray(tm.X_std[E:E + D], dtype=float))
+
+    def two_calls(dens):
+        ld, ss = (tm._zeros(N), tm._zeros(N)) if dens else (None, None)
+        Z = tm.forward_device(Xs, N, logdet=ld, sigma=sigma if dens else None, sumsq=ss)
+        Xr = tm._cols(d, N, zero=True)
+        if E:
+            Xr[:E, :N].copy_(Xs[:E, :N])
+        tm.inverse_device(Z, N, X=Xr)
+        return Z, Xr, ld, ss, lib.ttm_last_kernel().decode()
+
+    def one_call(dens):
+        ld, ss = (tm._zeros(N), tm._zeros(N)) if dens else (None, None)
+        Z, Xr = tm.roundtrip_device(Xs, N, logdet=ld, sigma=sigma if dens else None, sumsq=ss)
+        return Z, Xr, ld, ss, lib.ttm_last_kernel().decode()
+
+    def same(a, b):
+        return np.array_equal(a[:, :N].cpu().numpy(), b[:, :N].cpu().numpy(), equal_nan=True)
+    for cus in (-1, 1, 2):
+        ttm_opt('band_cus', cus)
+        for dens in (False, True):
+            Z1, X1, l1, s1, inv_kernel = two_calls(dens)
+            Z2, X2, l2, s2, rt_kernel = one_call(dens)
+            if inv_kernel == 'k_band_few_inverse':
+                assert rt_kernel == ('k_band_few_roundtrip<density>' if dens else 'k_band_few_roundtrip'), (case, cus, dens, rt_kernel)
+            assert same(Z1, Z2) and same(X1, X2), (case, cus, dens)
+            if dens:
+                assert np.array_equal(l1.cpu().numpy(), l2.cpu().numpy(), equal_nan=True)
+                assert np.array_equal(s1.cpu().numpy(), s2.cpu().numpy(), equal_nan=True)
+    # the round trip is one: S^-1(S(x)) = x inside the tables
+    xs, xr = Xs[E:, :N].cpu().numpy(), X2[E:, :N].cpu().numpy()
+    inside = (np.abs(xs) < 5).all(axis=0)
+    assert inside.mean() > 0.9 and np.median(np.abs(xr[:, inside] - xs[:, inside])) < 1e-3
+    ttm_opt('band_cus', -1)
+    ttm_opt('roundtrip_fused', 0)
+    Z3, X3, _, _, k3 = one_call(False)
+    assert not k3.startswith('k_band_few_roundtrip') and same(Z3, Z2) and same(X3, X2)

@@ -87,6 +87,8 @@ _SIGNATURES = {
     'ttm_objective_sep_cached': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp]),
     'ttm_objective_host_marked': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp]),
     'ttm_stream_synchronize': (ctypes.c_int, [c_vp]),
+    'ttm_roundtrip': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                     c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'ttm_sentinel_fill': (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
     'ttm_objective_sep_cached_sent': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_direct_sent': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp]),

@@ -41,6 +41,14 @@ int inverse(const ttm_program* p, const double* U, int k0, int k1, const double*
             int64_t N, const double* tab_x, int T, const double* y_affine, const double* tmin, const double* tmax, const int32_t* bkt,
             int nb, const double* img, int img_doubles, int cus, size_t lds_per_cu, int window, int block, void* stream, const char** kernel_name);
 
+// forward map (+ log-determinant / sum of squares) and the table inverse of the image, in ONE launch, for maps of a few components
+// (k_band_few_roundtrip): Z (nullable) = S(X), Xr = S^-1(S(X)) - conditioning columns are read from X.  Without `force` only the
+// shapes the one launch is faster for (reach <= 2 columns, no density terms); 1: declined
+int roundtrip(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa, int64_t ldz,
+              double* Xr, int64_t ldr, double* logdet, const double* sigma, double* sumsq, const double* tab_x, int T, const double* y_affine,
+              const double* tmin, const double* tmax, const int32_t* bkt, int nb, int cus, size_t lds_per_cu, bool force, void* stream,
+              const char** kernel_name);
+
 // does the table inverse of [k0, k1) take resident-table images (csrc/ttm_band_image.h) for this table geometry?  The window
 // [w0, w0 + W) of every table and the doubles per image (the table-building kernel writes them, `inverse` reads them)
 bool image_plan(const ttm_program* p, int k0, int k1, int T, int nb, size_t lds_per_cu, int window, int block, int* w0, int* W, int* tab_slot);

@@ -1965,6 +1965,361 @@ __global__ __launch_bounds__(BAND_CT) void k_band_few_inverse(const double* __re
 }
 
 // ---------------------------------------------------------------------------
+// forward map, (optionally) the density terms, and the table inverse of the image in ONE launch - what BASELINE configs[1]
+// times as a step ("forward + inverse + pullback" of a map of a few components: two or three launches of ~10 us on 32 MB, each
+// a launch floor and a memory round trip of its own).  A tile's columns are read once; z_k stays in registers between the
+// forward sweep (k_band_few's arithmetic, statement for statement) and the inverse sweep (k_band_few_inverse's), which writes
+// S^-1(S(x)) to Xr.  Same bits as the two (three) launches: tests/test_band.py::test_roundtrip_in_one_launch...
+// LDS (doubles): [inverse tables: nc x tab_slot | {E_i, y_i}: 2 x Weven | forward exp table | forward splines: ntab]
+// ---------------------------------------------------------------------------
+template <int CLS, int LAG, int LAGE, bool PLAIN, bool DENS>
+__global__ __launch_bounds__(BAND_CT) void k_band_few_roundtrip(const double* __restrict__ U_, int64_t p_off, int k0, int k1, int kcol0,
+                                                                const double* __restrict__ X, int64_t ldx, int64_t N,
+                                                                double* __restrict__ Z, int64_t ldz, double* __restrict__ Xr, int64_t ldr,
+                                                                double* __restrict__ logdet, const double* __restrict__ sigma,
+                                                                double* __restrict__ sumsq, const double* __restrict__ tab_x, int T, double y0,
+                                                                double ystep, double ylast, const double* __restrict__ tmin,
+                                                                const double* __restrict__ tmax, const int* __restrict__ bkt, int nb, int tab_slot,
+                                                                int ntiles, int tab0, int ntab) {
+    constexpr int DB = cls_db(CLS), DA = cls_da(CLS), GP = cls_gp(CLS), PS = rec_stride(CLS, LAG);
+    constexpr int NS = BAND_FEW_NS, NP = NS / 2, CT = BAND_CT, ROWS = NS * CT, HALF = 2 * CT, FD = TTM_P_FEW_D, HDR = BAND_RT_HDR;
+    extern __shared__ __align__(16) double g_lds[];
+    const int tid = threadIdx.x;
+    const int nc = k1 - k0;
+    const int Weven = (T + 4 + 1) & ~1;
+    double* itabs = g_lds;                                    // the inverse's tables
+    double* ietab = itabs + (size_t)nc * tab_slot;            // {E_i, y_i}
+    double* etab = ietab + 2 * Weven;                         // the forward map's exp table
+    double* tabs = etab + BAND_ET_DOUBLES;                    // the forward map's splines
+    const lds_p etab1 = band_lds(ietab) - 16;
+    cdbl_p P = (cdbl_p)(U_ + p_off);
+    cdbl_p kt = (cdbl_p)g_band_taylor;
+    const unsigned int last_pair = (unsigned int)(((N + 1) & ~(int64_t)1) - 2);
+    const unsigned int N32 = (unsigned int)N;
+    const int64_t ldxb = ldx * 8, ldzb = ldz * 8, ldrb = ldr * 8;
+    const double y0m = y0 - ystep;
+    const int nb1 = nb - 1;
+    // everything a workgroup stages, requested now
+    const D2 ev = *(const D2*)(g_band_etab + 2 * min(tid, TTM_BAND_ET_N - 1));
+    D2 sv[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) sv[r] = *(const D2*)(U_ + tab0 + min(2 * tid + r * 2 * CT, ntab - 2));
+    double tv[FD];
+    {
+        const double* src = tab_x + min(tid, T - 1);
+#pragma unroll
+        for (int u = 0; u < FD; ++u) tv[u] = src[(int64_t)min(u, nc - 1) * T];
+    }
+    const int bc = min(tid >> 8, nc - 1), bw = tid & 255;
+    const int4 bv = *(const int4*)(bkt + (int64_t)bc * (nb + 1) + 4 * bw);
+    __builtin_amdgcn_sched_barrier(0);
+    auto interp = [&](double y_lo, double x_lo, double x_hi, double e_lo, double tgt, double& rr, double& ee) {
+        const double dx = fmax(x_hi - x_lo, 1e-300);
+        double rc = __builtin_amdgcn_rcp(dx);
+        rc = fma(fma(-dx, rc, 1.0), rc, rc);
+        const double delta = (ystep * rc) * (tgt - x_lo);
+        rr = delta + y_lo;
+        const double w = (delta * -0.25) * (y_lo + rr);
+        double p = fma(kt[0], w, kt[1]);
+        p = fma(p, w, kt[2]);
+        p = fma(p, w, kt[3]);
+        p = fma(p, w, kt[4]);
+        p = fma(p, w, kt[5]);
+        p = fma(p, w, 1.0);
+        p = fma(p, w, 1.0);
+        ee = e_lo * p;
+    };
+    double luni = 0.0;
+    bool staged = false;
+    auto request = [&](int tile, D2 (&xf)[LAGE][NP], D2 (&xin)[FD][NP]) {
+        unsigned int roff[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            unsigned int n = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid + (unsigned int)(q * HALF);
+            n = n < last_pair ? n : last_pair;
+            roff[q] = n * 8u;
+        }
+        if (kcol0 > 0) {
+#pragma unroll
+            for (int i = 0; i < LAGE; ++i) {
+                const int cc = kcol0 - LAGE + i;
+                const char* col = (const char*)X + (int64_t)(cc < 0 ? 0 : cc) * ldxb;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) xf[i][q] = band_load2(col + roff[q]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FD; ++j) {
+            const char* col = (const char*)X + (int64_t)(kcol0 + min(j, nc - 1)) * ldxb;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xin[j][q] = band_load2(col + roff[q]);
+        }
+    };
+    D2 xf[LAGE][NP], xin[FD][NP];
+    if ((int)blockIdx.x < ntiles) request(blockIdx.x, xf, xin);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned int tbase = (unsigned int)tile * (unsigned int)ROWS + 2u * (unsigned int)tid;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!staged) {
+            if (tid < TTM_BAND_ET_N) *(D2*)(etab + 2 * tid) = ev;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = 2 * tid + r * 2 * CT;
+                if (i < ntab) *(D2*)(tabs + i) = sv[r];
+            }
+            if (DENS && sigma) {
+                for (int k = 0; k < nc; ++k) luni -= band_log(sigma[k]);
+            }
+            if (tid < T) {
+                ietab[2 * tid] = band_expq_series(tid == T - 1 ? ylast : (double)tid * ystep + y0);
+                ietab[2 * tid + 1] = fma((double)(tid + 1), ystep, y0m);
+            }
+            if (tid < nc) {
+                double* slot = itabs + (size_t)tid * tab_slot;
+                double scale, bias;
+                band_bucket_params(tmin[tid], tmax[tid], nb, scale, bias);
+                slot[0] = scale; slot[1] = bias;
+                ((int*)slot)[4] = 0; ((int*)slot)[5] = 0;
+                slot[3] = 0.0; slot[4] = 0.0; slot[5] = 0.0;
+            }
+            if (tid < Weven) {
+#pragma unroll
+                for (int u = 0; u < FD; ++u) itabs[(size_t)min(u, nc - 1) * tab_slot + HDR + tid] = tid < T ? tv[u] : INFINITY;
+            }
+            {
+                unsigned short* bs = (unsigned short*)(itabs + (size_t)bc * tab_slot + HDR + Weven) + 4 * bw;
+                const uint2 pk = {(unsigned int)(bv.x & 0xffff) | ((unsigned int)bv.y << 16), (unsigned int)(bv.z & 0xffff) | ((unsigned int)bv.w << 16)};
+                *(uint2*)bs = pk;
+            }
+            __syncthreads();
+            if ((tid >> 8) < nc) {
+                const unsigned short* bs = (const unsigned short*)(itabs + (size_t)bc * tab_slot + HDR + Weven);
+                const int b4 = bw < 255 ? (int)bs[4 * bw + 4] : bv.w;
+                int per = max(bv.y - bv.x, max(bv.z - bv.y, bv.w - bv.z));
+                per = max(per, b4 - bv.w);
+                for (int o = 32; o > 0; o >>= 1) per = max(per, __shfl_xor(per, o));
+                if ((tid & 63) == 0) atomicMax((int*)(itabs + (size_t)bc * tab_slot) + 4, per);
+            }
+            __syncthreads();
+            staged = true;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- forward sweep (k_band_few) ----
+        double zk[FD][NS];
+        {
+            double pend[NS][LAGE];
+#pragma unroll
+            for (int l = 0; l < LAGE; ++l) {
+                const double s0 = P[(int64_t)(k0 + l) * PS];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) pend[e][l] = s0;
+            }
+            if (kcol0 > 0) {
+#pragma unroll
+                for (int i = 0; i < LAGE; ++i) {
+                    const bool there = kcol0 - LAGE + i >= 0;
+                    cdbl_p rec = P + (int64_t)(k0 + LAG - LAGE + i) * PS;
+                    const double start = P[(int64_t)(k0 + i) * PS];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const double xa = there ? xf[i][q].x : 0.0, xb = there ? xf[i][q].y : 0.0;
+                        band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xa, band_expq(etab, xa, kt), pend[2 * q]);
+                        band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xb, band_expq(etab, xb, kt), pend[2 * q + 1]);
+                    }
+                }
+            }
+            double ss[NS], prod[NS], dmin[NS];
+            int pexp[NS];
+#pragma unroll
+            for (int e = 0; e < NS; ++e) { ss[e] = 0.0; prod[e] = 1.0; dmin[e] = 0.0; pexp[e] = 0; }
+#pragma unroll
+            for (int j = 0; j < FD; ++j) {
+                if (DENS && j == 2 && nc > 2) {
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) { int ex; prod[e] = frexp(prod[e], &ex); pexp[e] = ex; }
+                }
+                if (j < nc) {
+                    cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
+                    const double start = P[(int64_t)(k0 + j + LAGE) * PS];
+                    const double sp_a = rec[2], sp_b = rec[3], sp_ds = rec[4], own1 = rec[7];
+                    cint_p ri = (cint_p)rec;
+                    const int nI = ri[10];
+                    const double* tab = tabs + (ri[11] - tab0);
+                    char* zcol = (char*)Z + (int64_t)j * ldzb;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        double zv[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int e = 2 * q + h;
+                            const double x = h ? xin[j][q].y : xin[j][q].x;
+                            double m = 0.0, dm = 0.0;
+                            if (nI > 0) {
+                                if (DENS) band_spline_d(tab, nI, sp_a, sp_b, sp_ds, x, m, dm);
+                                else m = band_spline(tab, nI, sp_a, sp_b, sp_ds, x);
+                            }
+                            const double E = band_expq(etab, x, kt);
+                            zv[h] = fma(own1, x, pend[e][0] + m);
+                            zk[j][e] = zv[h];
+                            if (DENS) {
+                                const double dx = fma(dm, sp_ds, own1);
+                                ss[e] = fma(zv[h], zv[h], ss[e]);
+                                prod[e] *= dx;
+                                dmin[e] = fmin(dmin[e], dx);
+                            }
+                            band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, x, E, pend[e]);
+                        }
+                        if (Z) {
+                            const unsigned int n = tbase + (unsigned int)(q * HALF);
+                            char* zp = zcol + (size_t)(n * 8u);
+                            if (n + 1 < N32) band_store2<BAND_FEW_NT != 0>(zp, zv[0], zv[1]);
+                            else if (n < N32) *(double*)zp = zv[0];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (DENS) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const unsigned int n = tbase + (unsigned int)(q * HALF);
+                    if (logdet) {
+                        const double la = dmin[2 * q] < 0.0 ? NAN : fma((double)pexp[2 * q], 6.93147180559945286e-01, band_log(prod[2 * q])) + luni;
+                        const double lb = dmin[2 * q + 1] < 0.0 ? NAN : fma((double)pexp[2 * q + 1], 6.93147180559945286e-01, band_log(prod[2 * q + 1])) + luni;
+                        if (n + 1 < N32) band_store2<false>((char*)(logdet + n), la, lb);
+                        else if (n < N32) logdet[n] = la;
+                    }
+                    if (sumsq) {
+                        if (n + 1 < N32) band_store2<false>((char*)(sumsq + n), ss[2 * q], ss[2 * q + 1]);
+                        else if (n < N32) sumsq[n] = ss[2 * q];
+                    }
+                }
+            }
+        }
+        // the columns of the workgroup's next tile travel while this tile is inverted (the conditioning columns of THIS tile are
+        // still needed: the next tile's go to a second set)
+        const bool more = tile + (int)gridDim.x < ntiles;
+        D2 xfc[LAGE][NP];
+#pragma unroll
+        for (int i = 0; i < LAGE; ++i)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xfc[i][q] = xf[i][q];
+        if (more && !DENS) request(tile + gridDim.x, xf, xin);       // (the density variant has no registers to spare: after the sweep)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- inverse sweep (k_band_few_inverse), targets from registers ----
+        {
+            double pend[NS][LAGE];
+#pragma unroll
+            for (int l = 0; l < LAGE; ++l) {
+                const double s0 = P[(int64_t)(k0 + l) * PS + 1];
+#pragma unroll
+                for (int e = 0; e < NS; ++e) pend[e][l] = s0;
+            }
+            if (kcol0 > 0) {
+#pragma unroll
+                for (int i = 0; i < LAGE; ++i) {
+                    const bool there = kcol0 - LAGE + i >= 0;
+                    cdbl_p rec = P + (int64_t)(k0 + LAG - LAGE + i) * PS;
+                    const double start = P[(int64_t)(k0 + i) * PS + 1];
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const double xa = there ? xfc[i][q].x : 0.0, xb = there ? xfc[i][q].y : 0.0;
+                        band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xa, there ? band_expq_series(xa) : 1.0, pend[2 * q]);
+                        band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, xb, there ? band_expq_series(xb) : 1.0, pend[2 * q + 1]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FD; ++j) {
+                if (j < nc) {
+                    cdbl_p rec = P + (int64_t)(k0 + j + LAG) * PS;
+                    const double start = P[(int64_t)(k0 + j + LAGE) * PS + 1];
+                    const double* slot = itabs + (size_t)j * tab_slot;
+                    const double scale = slot[0], bias = slot[1];
+                    const int per = __builtin_amdgcn_readfirstlane(((const int*)slot)[4]);
+                    const int pm = max(per, 1);
+                    const bool deg = pm + 3 >= T || per > 255;
+                    const lds_p xsl = band_lds(slot + HDR);
+                    const lds_p bkl = band_lds(slot + HDR + Weven);
+                    const double wl = band_lds_f64(xsl + 8 * (deg ? 1 : pm)), wh = band_lds_f64(xsl + 8 * (deg ? 1 : T - 2));
+                    const int nph = per <= 3 ? 1 : per <= 15 ? 2 : per <= 63 ? 3 : 4;
+                    double traw[NS], tg[NS], r[NS], E[NS];
+                    unsigned long long outl = deg ? ~0ull : 0ull;
+                    int pos[NS];
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {
+                        const double z = zk[j][e];
+                        traw[e] = z - pend[e][0];
+                        tg[e] = fmin(fmax(traw[e], wl), wh);
+                        outl |= __builtin_amdgcn_ballot_w64(traw[e] != tg[e]);
+                        const int bi = min((int)fma(tg[e], scale, bias), nb1);
+                        pos[e] = (int)*(const __attribute__((address_space(3))) unsigned short*)(bkl + 2 * bi);
+                    }
+                    for (int ph = 0, s = 1 << (2 * (nph - 1)); ph < nph; ++ph, s >>= 2) {
+                        double qv[NS][3];
+#pragma unroll
+                        for (int e = 0; e < NS; ++e)
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) qv[e][i] = band_lds_f64_single(xsl + 8 * min(pos[e] + (i + 1) * s - 1, T + 3));
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            int c = 0;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) c += qv[e][i] < tg[e] ? 1 : 0;
+                            pos[e] += c * s;
+                        }
+                    }
+                    {
+                        D2 ey[NS];
+                        double xlo[NS], xhi[NS];
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            const int ps1 = band_med3(pos[e], 1, T - 1);
+                            ey[e] = band_lds_pair(etab1 + 16 * ps1);
+                            const lds_p xp = xsl + 8 * ps1;
+                            xlo[e] = band_lds_f64(xp - 8);
+                            xhi[e] = band_lds_f64_single(xp);
+                        }
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) interp(ey[e].y, xlo[e], xhi[e], ey[e].x, tg[e], r[e], E[e]);
+                    }
+                    if (outl != 0) {
+                        const double* xg = tab_x + (int64_t)j * T;
+                        const double lo = tmin[j], hi = tmax[j];
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {
+                            if (deg || traw[e] != tg[e]) {
+                                double t = traw[e];
+                                const double cl = fmin(fmax(t, lo), hi);
+                                t = t != t ? t : cl;
+                                int a = 0, b = T;
+                                while (a < b) {
+                                    const int mid = (a + b) >> 1;
+                                    if (xg[mid] < t) a = mid + 1; else b = mid;
+                                }
+                                const int i = min(max(a, 1), T - 1);
+                                interp(fma((double)i, ystep, y0m), xg[i - 1], xg[i], band_expq_series((double)(i - 1) * ystep + y0), t, r[e], E[e]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) band_push_e<DB, DA, GP, LAGE, PLAIN>(rec + TTM_P_HDR, start, r[e], E[e], pend[e]);
+                    char* xcol = (char*)Xr + (int64_t)(kcol0 + j) * ldrb;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        const unsigned int n = tbase + (unsigned int)(q * HALF);
+                        char* xp = xcol + (size_t)(n * 8u);
+                        if (n + 1 < N32) band_store2<BAND_FEW_NT != 0>(xp, r[2 * q], r[2 * q + 1]);
+                        else if (n < N32) *(double*)xp = r[2 * q];
+                    }
+                }
+            }
+        }
+        if (more && DENS) request(tile + gridDim.x, xf, xin);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static void allow_lds(const void* kern, size_t bytes) {
@@ -2174,6 +2529,64 @@ int forward(const ttm_program* p, const double* U, int k0, int k1, const double*
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
                        (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, rows, Bc);
     if (kernel_name) *kernel_name = "k_band_forward";
+    return 0;
+}
+
+// forward (+ density terms) + table inverse of a map of a few components in one launch (k_band_few_roundtrip); 1: not for this map /
+// these buffers (the caller makes the separate calls)
+int roundtrip(const ttm_program* p, const double* U, int k0, int k1, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa, int64_t ldz,
+              double* Xr, int64_t ldr, double* logdet, const double* sigma, double* sumsq, const double* tab_x, int T, const double* y_affine,
+              const double* tmin, const double* tmax, const int32_t* bkt, int nb, int cus, size_t lds_per_cu, bool force, void* stream,
+              const char** kernel_name) {
+    const int nc = k1 - k0;
+    if (!usable(p, k0, k1) || nc > TTM_P_FEW_D || !Xr || !y_affine || T < 64 || T + 4 > BAND_CT || nb + 1 != 1024 || N >= ((int64_t)1 << 28)) return 1;
+    if ((uintptr_t)bkt % 16 != 0 || (sigma && !logdet)) return 1;
+    const double ymax = fabs(y_affine[0]) > fabs(y_affine[2]) ? fabs(y_affine[0]) : fabs(y_affine[2]);
+    if (!(y_affine[1] > 0.0 && y_affine[1] * ymax * 0.5 <= 0.1)) return 1;
+    const int64_t need = (N + 1) & ~(int64_t)1;
+    const bool aligned = ((uintptr_t)Xsoa % 16 == 0) && (ldx % 2 == 0) && ldx >= need && (!Zsoa || ((uintptr_t)Zsoa % 16 == 0 && ldz % 2 == 0 && ldz >= need)) &&
+                         ((uintptr_t)Xr % 16 == 0) && (ldr % 2 == 0) && ldr >= need && ((uintptr_t)U % 16 == 0) &&
+                         (!logdet || (uintptr_t)logdet % 16 == 0) && (!sumsq || (uintptr_t)sumsq % 16 == 0);
+    if (!aligned) return 1;
+    int tab0 = p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_TAB_OFF];
+    int ntab = p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_TAB_OFF] + TTM_U_TSTRIDE * p->h_ucomp[(k1 - 1) * TTM_UC_LEN + TTM_UC_NI] - tab0;
+    if (ntab <= 0) { tab0 = 0; ntab = 2; }
+    if (ntab < 2 || ntab % 2 != 0 || tab0 % 2 != 0 || ntab > BAND_FEW_TAB) return 1;
+    const int Weven = (T + 4 + 1) & ~1;
+    const int tab_slot = BAND_RT_HDR + Weven + (((nb + 1 + 3) / 4 + 1) & ~1);
+    const size_t lds = ((size_t)nc * tab_slot + (size_t)2 * Weven + (size_t)BAND_ET_DOUBLES + (size_t)ntab + 2) * 8;
+    int lage; bool plain;
+    sweep_shape(p, k0, k1, &lage, &plain);
+    if (lds > lds_per_cu || lage > p->u_p_lag) return 1;
+    const int cls = p->u_h_cls;
+    const bool dens = logdet || sumsq;
+    // Where it pays (measured, graph replay): sweeps that reach one or two columns back, without the density terms - C2b 19.9 us
+    // against 10.1 + 11.8 us.  A reach of three columns (C3: 29.8 against 10.5 + 13.1 us) and the density variant (C2b 31.6
+    // against 15.9 + 11.8 us) run out of registers (34-117 spilled with the inverse sweep's 128 in use): the launches are bound by the
+    // latency of a row's chain of dependent operations, not by the columns' traffic, so one pass instead of two saves a launch
+    // floor and a round trip, not the arithmetic.  `force`: tests (every shape through the fused kernel).
+    if (!force && (lage > 2 || dens)) return 1;
+    typedef void (*rkern_t)(const double*, int64_t, int, int, int, const double*, int64_t, int64_t, double*, int64_t, double*, int64_t, double*,
+                            const double*, double*, const double*, int, double, double, double, const double*, const double*, const int*, int, int, int,
+                            int, int);
+    rkern_t rk = nullptr;
+#define BAND_RTF_C(L, E, PL, DN) (cls == 1 ? k_band_few_roundtrip<1, L, E, PL, DN> : cls == 2 ? k_band_few_roundtrip<2, L, E, PL, DN> : cls == 3 ? k_band_few_roundtrip<3, L, E, PL, DN> : k_band_few_roundtrip<4, L, E, PL, DN>)
+#define BAND_RTF_P(L, E, DN) (plain ? BAND_RTF_C(L, E, true, DN) : BAND_RTF_C(L, E, false, DN))
+#define BAND_RTF_E(L, E) (dens ? BAND_RTF_P(L, E, true) : BAND_RTF_P(L, E, false))
+    if (p->u_p_lag == 5) rk = BAND_RTF_E(5, 5);
+    else if (p->u_p_lag == 3) rk = lage == 1 ? BAND_RTF_E(3, 1) : lage == 2 ? BAND_RTF_E(3, 2) : BAND_RTF_E(3, 3);
+    else rk = lage == 1 ? BAND_RTF_E(2, 1) : BAND_RTF_E(2, 2);
+#undef BAND_RTF_E
+#undef BAND_RTF_P
+#undef BAND_RTF_C
+    const int64_t trows = BAND_FEW_NS * BAND_CT;
+    const int64_t ntiles = (N + trows - 1) / trows;
+    const int64_t grid = ntiles < cus ? ntiles : cus;
+    allow_lds((const void*)rk, lds);
+    hipLaunchKernelGGL(rk, dim3((unsigned)grid), dim3(BAND_CT), lds, (hipStream_t)stream, U, (int64_t)p->u_p_off, k0, k1,
+                       (int)p->h_ucomp[k0 * TTM_UC_LEN + TTM_UC_KC], Xsoa, ldx, N, Zsoa, ldz, Xr, ldr, logdet, sigma, sumsq, tab_x, T, y_affine[0],
+                       y_affine[1], y_affine[2], tmin, tmax, bkt, nb, tab_slot, (int)ntiles, tab0, ntab);
+    if (kernel_name) *kernel_name = dens ? "k_band_few_roundtrip<density>" : "k_band_few_roundtrip";
     return 0;
 }
 

@@ -2845,7 +2845,9 @@ static const DeviceInfo& device_info() {
     X(setup_fused, -1)   /* 0: ttm_setup_staged declines (the caller then launches ttm_fold_staged and the table kernel)           */ \
     X(select_coop, -1)   /* 0: order statistics by 17 launches (k_select_hist / k_select_pick) whatever the column length          */ \
     X(colstats_one, -1)  /* 0: column moments by four launches (k_colsum / k_colfinish) whatever the shape                        */ \
-    X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid        */
+    X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid        */ \
+    X(roundtrip_fused, -1) /* 0: ttm_roundtrip declines (the caller makes the forward and the inverse call); 1: the fused kernel for \
+                              every shape it can run, also those it is slower for (reach of three columns, density terms)          */
 struct Tuning {
 #define X(name, dflt) int name = dflt;
     TTM_OPTIONS(X)
@@ -3537,6 +3539,29 @@ int ttm_setup_staged(const ttm_program* p, const double* h_coef, double* coef, d
                        (int64_t)p->u_p_off, records ? (int)p->u_p_lag : 0, (int)p->u_p_stride, h_err, pts, (int)T, (int)nb, out, tmin, tmax,
                        (int*)bkt, (int*)unsorted, (int*)h_unsorted, img, iw0, iW, islot);
     return check_launch("k_setup");
+}
+
+int ttm_roundtrip(const ttm_program* p, const double* coef, const double* fold, const double* Xsoa, int64_t ldx, int64_t N, double* Zsoa,
+                  int64_t ldz, double* Xr, int64_t ldr, double* logdet, const double* sigma, double* sumsq, const double* tab_x, int32_t T,
+                  const double* h_y_affine, const double* tmin, const double* tmax, const int32_t* bkt, int32_t nb, void* stream) {
+    int rc = validate(p, 0, p ? p->D : 0);
+    if (rc) return rc;
+    if (!coef || !fold || !Xsoa || !Xr || !tab_x || !tmin || !tmax || !bkt || !h_y_affine || N < 1 || ldx < N || ldr < N || (Zsoa && ldz < N) ||
+        T < 8 || T > 65536 || nb < 4 || nb > 65536)
+        return set_err(TTM_E_ARG, "ttm_roundtrip: bad arguments%s");
+    // the conditions of the two calls it stands for (ttm_forward -> k_band_few, ttm_inverse_table -> k_band_few_inverse)
+    const Tuning& tn = tuning();
+    if (p->monotonicity != TTM_MONO_SEPARABLE || !u_on(p) || p->u_h_cls < 1 || p->u_h_cls > 4 || !all_fast(p, 0, p->D) || tn.rt_off || tn.u_no_hot ||
+        tn.band_fwd == 0 || tn.band_inv == 0 || tn.roundtrip_fused == 0 || !(N >= 64 * 1024 || (tn.band_fwd == 1 && tn.u_loader == 1)) ||
+        !ttm_band::usable(p, 0, p->D))
+        return TTM_E_UNSUPPORTED;
+    const DeviceInfo& di = device_info();
+    const char* name = nullptr;
+    if (ttm_band::roundtrip(p, fold + fold_base_size(p), 0, p->D, Xsoa, ldx, N, Zsoa, ldz, Xr, ldr, logdet, sigma, sumsq, tab_x, (int)T, h_y_affine,
+                            tmin, tmax, bkt, (int)nb, tn.band_cus > 0 ? tn.band_cus : di.cus, di.lds_per_cu, tn.roundtrip_fused == 1, stream,
+                            &name) != 0)
+        return TTM_E_UNSUPPORTED;
+    return check_launch(name);
 }
 
 int ttm_inverse_table(const ttm_program* p, const double* coef, const double* fold, int32_t k0, int32_t k1, const double* Zsoa,

@@ -1205,6 +1205,35 @@ class transport_map():
                                           None, N, self._ptr(logdet), self._ptr(sigma), self._ptr(sumsq), self._stream()))
         return logdet, sumsq
 
+    def roundtrip_device(self, Xs, N, coef=None, Z=None, Xr=None, logdet=None, sigma=None, sumsq=None):
+        """Z = S(x) and S^-1(Z) of a standardised column-major device matrix in ONE pass (ttm_roundtrip: maps of at most four
+        components, N >= 65 536 - what BASELINE configs[1] times as a step; with logdet / sumsq also the terms of the pullback
+        density).  The same bits as forward_device followed by inverse_device on the default tables - which is what runs when
+        the fused kernel does not apply.  Returns (Z, Xr); the conditioning columns of Xr are copies of Xs's."""
+        coef = self._current(coef)
+        Z = self._cols(self.D, N) if Z is None else Z
+        Xr = self._cols(self._cm.d_cols, N, zero=True) if Xr is None else Xr
+        skip = self._cm.d_cols - self.D
+        if skip > 0:
+            Xr[:skip, :N].copy_(Xs[:skip, :N])
+        table = self.alternate_root_finding and self.monotonicity.lower() == 'separable monotonicity' and self.root_search_truncation
+        rc = _capi.TTM_E_UNSUPPORTED
+        if table and self._dev.type == 'cuda':
+            resolution, start_distance, nb = 1001, 10, self._inv_nb()
+            self._inverse_table(coef, 0, self.D, None, None, 0, resolution, start_distance)      # (the tables, if this vector has none yet)
+            out_d, tmin_d, tmax_d, bkt_d, is_sorted, _ = coef._ttm_tables[(0, self.D, resolution, start_distance, nb)]
+            if is_sorted:
+                rc = self._lib.ttm_roundtrip(self._pp, self._ptr(coef), self._ptr(coef._ttm_fold), self._ptr(Xs), Xs.shape[1], N,
+                                             self._ptr(Z), Z.shape[1], self._ptr(Xr), Xr.shape[1], self._ptr(logdet), self._ptr(sigma),
+                                             self._ptr(sumsq), self._ptr(out_d), resolution, self._pts_affine, self._ptr(tmin_d),
+                                             self._ptr(tmax_d), ctypes.c_void_p(bkt_d.data_ptr()), nb, self._stream())
+        if rc == _capi.TTM_E_UNSUPPORTED:
+            self.forward_device(Xs, N, coef, Z=Z, logdet=logdet, sigma=sigma, sumsq=sumsq)
+            self.inverse_device(Z, N, coef, X=Xr)
+        else:
+            _capi.check(rc)
+        return Z, Xr
+
     def inverse_device(self, Zs, N, coef=None, X=None, table=None):
         """S^{-1}(z) for a column-major device matrix Zs (D x N) -> standardised X (d x N);
         conditioning columns (if any) must already be in X."""
