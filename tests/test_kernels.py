@@ -29,10 +29,11 @@ def small_map(**kw):
                          quadrature_input={'order': 5}, **kw)
 
 
-@pytest.mark.parametrize('coop', [-1, 0])
+@pytest.mark.parametrize('coop', [-1, 0, 2])
 def test_order_statistics_exact(backend, ttm_opt, coop):
     # coop -1: columns of up to 131 072 rows through the one-launch select (k_select_coop: keys in registers, a grid barrier
-    # per pass), longer ones through the 17 launches; 0: the launches for every length
+    # per pass), longer ones through the 17 launches; 0: the launches for every length; 2: the one-launch select with every
+    # wait given up at once - what happens when the grid is not co-resident: workgroup 0 selects by itself (select_solo)
     ttm_opt('select_coop', coop)
     tm = small_map()
     rng = np.random.default_rng(1)

@@ -508,7 +508,7 @@ __device__ void select_solo(const double* __restrict__ col, int64_t N, const lon
 
 __global__ __launch_bounds__(256) void k_select_coop(const double* __restrict__ col, int64_t N, const long long* __restrict__ ranks,
                                                      int nr, unsigned int* __restrict__ ghist, unsigned int* __restrict__ bar,
-                                                     unsigned long long* __restrict__ cand, double* __restrict__ out) {
+                                                     unsigned long long* __restrict__ cand, double* __restrict__ out, int give_up) {
     __shared__ unsigned int lh[TTM_SEL_MAX * 256];
     __shared__ unsigned long long pf[TTM_SEL_MAX];
     __shared__ long long rk[TTM_SEL_MAX];
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_select_coop(const double* __restrict__ 
     }
     if (tid < nr) { pf[tid] = 0ull; rk[tid] = ranks[tid]; rep[tid] = 0; held[tid] = N; }
     unsigned int* ncand = bar + 16;
-    bool alive = true;
+    bool alive = give_up == 0;                 // (give_up: tests - every workgroup behaves as if its partners had not arrived)
     int gather_shift = -1;                     // >= 0: the passes ended early; bits >= gather_shift of every rank are known
     unsigned int arrivals = 0;
     for (int pass = 0; pass < 8 && alive; ++pass) {
@@ -2374,11 +2374,12 @@ __global__ __launch_bounds__(64) void k_fold_host(DevProg P, int k, HostCoef hc,
 #define TTM_SENT_SPINS (1 << 16)
 
 // (all threads of workgroup 0 call, behind the coherent_store of its own row; all: LDS, gridDim.x x nacc doubles; fin: nacc)
-__device__ __forceinline__ void sentinel_finish(double* __restrict__ partial, int nacc, double* all, double* fin, double* __restrict__ out) {
+__device__ __forceinline__ void sentinel_finish(double* __restrict__ partial, int nacc, double* all, double* fin, double* __restrict__ out,
+                                                bool give_up) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int total = (int)gridDim.x * nacc;
     bool done = false;
-    for (int spin = 0; spin < TTM_SENT_SPINS && !done; ++spin) {
+    for (int spin = 0; spin < (give_up ? 0 : TTM_SENT_SPINS) && !done; ++spin) {
         int ok = 1;
         for (int i = tid; i < total; i += (int)blockDim.x) {
             const double v = coherent_load(partial + i);
@@ -2479,7 +2480,7 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     if (sentinel) {                                   // self-validating rows: workgroup 0 polls them (sentinel_finish)
         __shared__ double all_s[TTM_SENT_WGS * (M + 1)];
         __shared__ double fin_s[M + 1];
-        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out);
+        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out, sentinel == 2);
         return;
     }
     drain_stores();
@@ -2560,7 +2561,7 @@ __global__ __launch_bounds__(256) void k_objective_sep_direct(const double* __re
     if (sentinel) {                                   // (as k_objective_sep_cached: the same finish, the same bits)
         __shared__ double all_s[TTM_SENT_WGS * (M + 1)];
         __shared__ double fin_s[M + 1];
-        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out);
+        if (blockIdx.x == 0) sentinel_finish(partial, nacc, all_s, fin_s, out, sentinel == 2);
         return;
     }
     drain_stores();
@@ -2843,9 +2844,11 @@ static const DeviceInfo& device_info() {
     X(fold_fused, -1)    /* 0: ttm_fold as three launches (k_fold, k_uform, k_band_records) instead of one                */ \
     X(table_fused, -1)   /* 0: inverse tables as two launches (k_table_build, k_table_index) instead of one               */ \
     X(setup_fused, -1)   /* 0: ttm_setup_staged declines (the caller then launches ttm_fold_staged and the table kernel)           */ \
-    X(select_coop, -1)   /* 0: order statistics by 17 launches (k_select_hist / k_select_pick) whatever the column length          */ \
+    X(select_coop, -1)   /* 0: order statistics by 17 launches (k_select_hist / k_select_pick) whatever the column length;         \
+                            2: tests - the one-launch select with every wait given up at once (workgroup 0 selects by itself)    */ \
     X(colstats_one, -1)  /* 0: column moments by four launches (k_colsum / k_colfinish) whatever the shape                        */ \
-    X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid        */ \
+    X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid;       \
+                            2: tests - the finishing workgroup gives up at once (the failure pattern reaches the host)            */ \
     X(roundtrip_fused, -1) /* 0: ttm_roundtrip declines (the caller makes the forward and the inverse call); 1: the fused kernel for \
                               every shape it can run, also those it is slower for (reach of three columns, density terms)          */
 struct Tuning {
@@ -2972,7 +2975,8 @@ static int select_passes(const double* col, int64_t N, const int64_t* ranks, int
         const int nb = (int)((N + 256 * TTM_SELC_ROWS - 1) / (256 * TTM_SELC_ROWS));
         if (hipMemsetAsync(bar, 0, (32 + TTM_SEL_MAX * 256) * 4, s) != hipSuccess)
             return set_err(TTM_E_HIP, "ttm_order_statistics: hipMemsetAsync failed%s");
-        hipLaunchKernelGGL(k_select_coop, dim3(nb), dim3(256), 0, s, col, N, (const long long*)ranks, (int)nr, ghist, bar, cand, out);
+        hipLaunchKernelGGL(k_select_coop, dim3(nb), dim3(256), 0, s, col, N, (const long long*)ranks, (int)nr, ghist, bar, cand, out,
+                           tuning().select_coop == 2 ? 1 : 0);
         return check_launch("k_select_coop");
     }
     hipLaunchKernelGGL(k_select_init, dim3(1), dim3(256), 0, s, (const long long*)ranks, (int)nr, st, hist);
@@ -3882,7 +3886,7 @@ static int launch_sep_objective(const double* dPsi, int64_t ldp, const double* x
             k_objective_sep_cached<9>, k_objective_sep_cached<10>, k_objective_sep_cached<11>, k_objective_sep_cached<12>,
             k_objective_sep_cached<13>, k_objective_sep_cached<14>, k_objective_sep_cached<15>, k_objective_sep_cached<16>};
         hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, hc, delta, partial, cnt, out, flag, mark,
-                           sentinel ? 1 : 0);
+                           sentinel ? (tuning().sep_sentinel == 2 ? 2 : 1) : 0);
     } else {
         typedef void (*dkern_t)(const double*, int64_t, const int*, const double*, SepCoef, double, double*, unsigned int*, double*, double*,
                                 double, int);
@@ -3892,7 +3896,7 @@ static int launch_sep_objective(const double* dPsi, int64_t ldp, const double* x
             k_objective_sep_direct<9>, k_objective_sep_direct<10>, k_objective_sep_direct<11>, k_objective_sep_direct<12>,
             k_objective_sep_direct<13>, k_objective_sep_direct<14>, k_objective_sep_direct<15>, k_objective_sep_direct<16>};
         hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta, partial, cnt, out,
-                           flag, mark, sentinel ? 1 : 0);
+                           flag, mark, sentinel ? (tuning().sep_sentinel == 2 ? 2 : 1) : 0);
     }
     if (!ticket) {
         if (flag)
