@@ -337,17 +337,31 @@ def objective_roofline(torch, tm, workload, passes=3):
     if tm._sep_cache is not None:
         c_k = np.ascontiguousarray(tm.coeffs_mon[k], dtype=float)
         m = len(c_k)
+        # the evaluation as the native L-BFGS-B loops launch it: self-validating sums, ONE launch whatever the grid
+        # (ttm_objective_sep_cached_sent); beside it the ticket / two-launch evaluation of rounds 3-5 (`two_launch_ms`), and the two
+        # checked against each other bit for bit (the sums land in the same page-locked vector)
+        ev_launch = tm._sep_objective_launch
+        two_ms = graph_ms(torch, lambda: tm._sep_objective_launch(c_k))
         tm._sep_objective_launch(c_k)
+        torch.cuda.synchronize()
+        ref_sums = tm._obj_out[:1 + m].numpy().copy()
+        sent_equal = None
+        if tm._sep_objective_launch_sent(c_k):
+            torch.cuda.synchronize()
+            sent_equal = bool(np.array_equal(tm._obj_out[:1 + m].numpy(), ref_sums))
+            ev_launch = tm._sep_objective_launch_sent
+        ev_launch(c_k)
         kern = _last_kernel(tm)
-        ms = graph_ms(torch, lambda: tm._sep_objective_launch(c_k))
+        ms = graph_ms(torch, lambda: ev_launch(c_k))
         how = 'HIP graph replay (20 evaluations per graph)'
         if ms is None:
-            ms, how = _events_ms(torch, lambda: tm._sep_objective_launch(c_k), 50), 'HIP events around each evaluation'
+            ms, how = _events_ms(torch, lambda: ev_launch(c_k), 50), 'HIP events around each evaluation'
         out['objective_separable'] = {
             'bound': 'hbm', 'kernel': kern, 'unit': 'GB/s', 'peak': HBM_PEAK_GBS, 'ms_per_evaluation': ms, 'timing': how, 'component': k,
             'm': m, 'algorithmic_bytes': 8.0 * N * m, 'achieved': 8.0 * N * m / (ms * 1e-3) / 1e9,
             'frac': 8.0 * N * m / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             'survey_8d_bytes': 8.0 * N, 'survey_8d_frac': 8.0 * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'self_validating_sums': ev_launch is not tm._sep_objective_launch, 'equals_two_launch_sums': sent_equal, 'two_launch_ms': two_ms,
             'what': 'one L-BFGS-B evaluation of the reduced separable objective (TM:2978-3018): the kernel streams the m cached '
                     'columns of dPsi_mon (8 N m bytes - what the reference keeps as der_Psi_mon); SURVEY section 8d counts an evaluation as '
                     '8 N d_k with the basis recomputed from the d_k = 1 column it depends on'}

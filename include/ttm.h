@@ -574,8 +574,9 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
                               double mark, void* stream);
 /* The same evaluation with SELF-VALIDATING sums for grids of up to 128 workgroups (N <= 131 072) - no ticket, no fence, no
  * mark: ttm_sentinel_fill arms the rows of partial sums in `work` once (every slot a signalling-NaN pattern no arithmetic
- * produces; TTM_E_UNSUPPORTED: the grid is larger, take the marked call); ttm_objective_sep_cached_sent evaluates, the
- * workgroup that finishes polls the slots of the others, leaves them armed again, and writes the 1 + m sums to out_host -
+ * produces; TTM_E_UNSUPPORTED: the grid is larger - measured slower than the second launch there - or option sep_sentinel = 0:
+ * take the marked call); ttm_objective_sep_cached_sent evaluates, workgroup 0 polls the slots of the others, adds the rows in
+ * the order of the ticket finish (the same bits), leaves them armed again, and writes the 1 + m sums to out_host -
  * page-locked host memory whose slots the CALLER has armed with the same pattern (0x7FF4DEADBEEF0001) and polls until none
  * holds it; 0x7FF4DEADBEEF0002 in a slot: the device gave up waiting (csrc/ttm_optim.cpp: arm_values / poll_values).   */
 int ttm_sentinel_fill(double* work, int32_t m, int64_t N, void* stream);

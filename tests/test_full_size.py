@@ -396,3 +396,4 @@ def test_c4_block_map_backward_step_at_1e5_against_the_oracle():
     record_parity('c4_block_1e5/map(%s)_vs_oracle_same_coefficients' % fk, e1, 1e-11)
     record_parity('c4_block_1e5/conditional_inverse_vs_oracle_same_coefficients', e2, 1e-11)
     assert e1 < 1e-11 and e2 < 1e-11
+

@@ -2378,6 +2378,7 @@ __device__ __forceinline__ void sentinel_finish(double* __restrict__ partial, in
                                                 bool give_up) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int total = (int)gridDim.x * nacc;
+    const double sent = __longlong_as_double((long long)TTM_SENT_BITS);
     bool done = false;
     for (int spin = 0; spin < (give_up ? 0 : TTM_SENT_SPINS) && !done; ++spin) {
         int ok = 1;
@@ -2388,7 +2389,6 @@ __device__ __forceinline__ void sentinel_finish(double* __restrict__ partial, in
         }
         done = __syncthreads_and(ok) != 0;
     }
-    const double sent = __longlong_as_double((long long)TTM_SENT_BITS);
     for (int i = tid; i < total; i += (int)blockDim.x) coherent_store(partial + i, sent);           // (the slots of the next evaluation)
     if (!done) {
         if (tid < nacc) __hip_atomic_store(out + tid, __longlong_as_double((long long)TTM_SENT_FAIL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3874,6 +3874,9 @@ static int launch_sep_objective(const double* dPsi, int64_t ldp, const double* x
     for (int i = 0; i < TTM_SEPC_MAXM; ++i) hc.c[i] = i < m ? h_coef_mon[i] : 0.0;
     int nb = grid_for(N, 256 * 4);
     if (nb > TTM_RED_BLOCKS - 8) nb = TTM_RED_BLOCKS - 8;         // (eight more rows of partial sums: the group sums of finish_sums)
+    // (self-validating sums for grids of up to 128 workgroups only: at N = 10^6 - 977 rows of partial sums polled and added from
+    // memory by one workgroup, the same bits as the second launch - an evaluation took 17.6 us against 13.0 us with the second
+    // launch, optimize() of C5 0.0205 against 0.016 s: measured and dropped, OPTLOG round 5 item 14)
     if (sentinel && nb > TTM_SENT_WGS) return TTM_E_UNSUPPORTED;
     const bool ticket = nb <= 128;
     unsigned int* cnt = ticket && !sentinel ? (unsigned int*)counter : (unsigned int*)nullptr;
@@ -3898,7 +3901,7 @@ static int launch_sep_objective(const double* dPsi, int64_t ldp, const double* x
         hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, xk, N, (const int*)kinds, pars, hc, delta, partial, cnt, out,
                            flag, mark, sentinel ? (tuning().sep_sentinel == 2 ? 2 : 1) : 0);
     }
-    if (!ticket) {
+    if (!ticket && !sentinel) {
         if (flag)
             hipLaunchKernelGGL(k_reduce_partials_mark, dim3(1), dim3(64 * (1 + (int)m < 16 ? 1 + (int)m : 16)), 0, (hipStream_t)stream,
                                (const double*)partial, nb, 1 + (int)m, out, flag, mark);

@@ -1614,14 +1614,16 @@ class transport_map():
         work = self._workspace(self._lib.ttm_reduce_work_size(max(m * m for m in sizes)))
         st = self._stream()
         ks = np.asarray(key[0], dtype=np.int32)
-        rc = self._lib.ttm_gram_many(self._pp, ctypes.c_void_p(ks.ctypes.data), len(ks), self._ptr(self._Xs), self._Xs.shape[1],
-                                     self._N, self._ptr(work), self._ptr(out), st) if len(ks) > 1 else _capi.TTM_E_UNSUPPORTED
-        if rc == _capi.TTM_E_UNSUPPORTED:               # (one component, or shapes the batched launch does not take)
-            for k, o in zip(key[0], offs):
-                _capi.check(self._lib.ttm_gram(self._pp, k, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
-                                               self._ptr(out, o), st))
-        else:
-            _capi.check(rc)
+        for c0 in range(0, len(ks), 8):                 # (ttm_gram_many: up to 8 components per launch)
+            kc = np.ascontiguousarray(ks[c0:c0 + 8])
+            rc = self._lib.ttm_gram_many(self._pp, ctypes.c_void_p(kc.ctypes.data), len(kc), self._ptr(self._Xs), self._Xs.shape[1],
+                                         self._N, self._ptr(work), self._ptr(out, offs[c0]), st) if len(kc) > 1 else _capi.TTM_E_UNSUPPORTED
+            if rc == _capi.TTM_E_UNSUPPORTED:           # (one component, or shapes the batched launch does not take)
+                for k, o in zip(kc.tolist(), offs[c0:c0 + 8]):
+                    _capi.check(self._lib.ttm_gram(self._pp, k, self._ptr(self._Xs), self._Xs.shape[1], self._N, self._ptr(work),
+                                                   self._ptr(out, o), st))
+            else:
+                _capi.check(rc)
         self._allreduce(out)
         pinned.copy_(out, non_blocking=True)
         if launch_only:
@@ -1785,6 +1787,23 @@ class transport_map():
                                                        ctypes.c_void_p(c.ctypes.data), float(self.delta), self._ptr(work),
                                                        ctypes.c_void_p(self._obj_cnt.data_ptr()),
                                                        ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+
+    def _sep_objective_launch_sent(self, c):
+        """The launch of one evaluation as the native L-BFGS-B loops make it for ensembles of up to 131 072 samples
+        (ttm_objective_sep_cached_sent: self-validating partial sums and results), no synchronisation - what bench.py times; the
+        sums land in self._obj_out.  False: the library declines (a larger grid, option sep_sentinel = 0): _sep_objective_launch."""
+        cache, m = self._sep_cache, len(c)
+        key = (m, int(self._N))
+        st = getattr(self, '_sep_sent_work', None)
+        if st is None or st[0] != key:
+            work = self._empty(int(self._lib.ttm_reduce_work_size(1 + m)))
+            if self._lib.ttm_sentinel_fill(self._ptr(work), m, self._N, self._stream()) != 0:
+                return False
+            st = self._sep_sent_work = (key, work)          # (armed once: every evaluation leaves the rows armed)
+        _capi.check(self._lib.ttm_objective_sep_cached_sent(self._ptr(cache[1]), cache[1].shape[1], self._N, m,
+                                                            ctypes.c_void_p(c.ctypes.data), float(self.delta), self._ptr(st[1]),
+                                                            ctypes.c_void_p(self._obj_out.data_ptr()), self._stream()))
+        return True
 
     def _respecify(self, monotone, nonmonotone):
         """New term lists on the resident ensemble (TM:432-438: function_constructor_alternative + precalculate)."""
