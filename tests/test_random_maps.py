@@ -149,7 +149,10 @@ def test_random_integrated_maps(backend, seed):
               regularization=[None, 'l1', 'l2'][seed % 3], regularization_lambda=0.03)
     tm, om = build_pair(mon, non, X, kw, rng, positive_mon=False)
     Xq = np.vstack((X[:250], 2.0 * rng.standard_normal((80, d)) * X.std(0) + X.mean(0)))
-    assert relerr(tm.map(Xq), om.map(Xq)) < 1e-10
+    Z, Zo = tm.map(Xq), om.map(Xq)
+    fin = np.isfinite(Zo)               # (plain polynomials of order 4 under an exponential rectifier overflow on the wide test points -
+    assert np.array_equal(np.isfinite(Z), fin) and np.array_equal(Z[~fin], Zo[~fin], equal_nan=True)    # in both, to the same infinity)
+    assert relerr(Z[fin], Zo[fin]) < 1e-10
     if rect not in ('exponential', 'expneg', 'softplus'):
         return      # the reference has no dr/dc for the other rectifiers (TM:5112-5165): no gradient, no optimize(); the
                     # engine evaluates objective and gradient in one pass and refuses both
