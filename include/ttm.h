@@ -584,6 +584,18 @@ int ttm_objective_sep_cached_sent(const double* dPsi, int64_t ldp, int64_t N, in
                                   double delta, double* work, double* out_host, void* stream);
 int ttm_objective_sep_direct_sent(const double* xk, int64_t N, int32_t m, const int32_t* kinds, const double* pars,
                                   const double* h_coef_mon, double delta, double* work, double* out_host, void* stream);
+/* The evaluation SERVER of an optimiser loop over grids of up to 128 workgroups (k_objective_sep_server): ONE launch for the whole
+ * loop - resident workgroups poll a mailbox in fine-grained DEVICE memory that the host writes through the PCIe BAR (posted
+ * writes: 2.6-3.7 us per request against 6.2 us for a launch + completion round trip, tools/micro/mailbox.cpp) and answer every
+ * request the way ttm_objective_sep_cached_sent does (the same bits).  ttm_mailbox_acquire: a 256-byte mailbox of the library's
+ * pool (NULL: none - launch per evaluation); the host writes the m trial coefficients to box + 8, then (sfence) the word
+ * gen << 32 | request number to box, request numbers 1, 2, ...; gen << 32 | 0xffffffff ends the server; a server that is not
+ * asked anything for 0.2 s leaves by itself.  work / out_host as ttm_objective_sep_cached_sent (rows armed by ttm_sentinel_fill).
+ * TTM_E_UNSUPPORTED: larger grids, option sep_server = 0.                                                                */
+void* ttm_mailbox_acquire(void);
+void ttm_mailbox_release(void* box);
+int ttm_objective_sep_server_start(const double* dPsi, int64_t ldp, int64_t N, int32_t m, double delta, double* work,
+                                   double* out_host, const void* box, uint32_t gen, void* stream);
 int ttm_objective_sep_cached_marked(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon,
                                     double delta, double* work, uint32_t* counter, double* out, double* flag,
                                     double mark, void* stream);

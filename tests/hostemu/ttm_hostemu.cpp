@@ -748,6 +748,11 @@ int ttm_objective_host_marked(const ttm_program* p, int32_t k, const double* h_c
 // (the device library's evaluation with self-validating sums: the double has nothing to wait for and declines - the loops
 // of csrc/ttm_optim.cpp then take the marked call)
 int ttm_sentinel_fill(double*, int32_t, int64_t, void*) { return TTM_E_UNSUPPORTED; }
+void* ttm_mailbox_acquire(void) { return nullptr; }
+void ttm_mailbox_release(void*) {}
+int ttm_objective_sep_server_start(const double*, int64_t, int64_t, int32_t, double, double*, double*, const void*, uint32_t, void*) {
+    return TTM_E_UNSUPPORTED;
+}
 int ttm_objective_sep_cached_sent(const double*, int64_t, int64_t, int32_t, const double*, double, double*, double*, void*) {
     return TTM_E_UNSUPPORTED;
 }

@@ -377,8 +377,9 @@ def test_device_resident_filter_matches_reference_and_host_loop(backend):
 def test_filter_batch_without_threads_and_self_validating_sums_make_the_same_bits(backend, ttm_opt):
     """The optimiser batch of the filter map - two components with ONE monotone term and one with special terms - runs without
     host threads (the one-term components' single device evaluation launched ahead, csrc/ttm_optim.cpp), with self-validating
-    partial sums instead of ticket + completion mark (k_objective_sep_cached, sentinel finish).  Neither changes an
-    evaluation point or the order of a sum: the same coefficients, bit for bit, as component by component, as the
+    partial sums instead of ticket + completion mark (k_objective_sep_cached, sentinel finish), and with ONE launch for the
+    whole L-BFGS-B loop of the component with special terms (k_objective_sep_server: requests through a mailbox in device
+    memory; option sep_server = 0: a launch per evaluation).  None of it changes an evaluation point or the order of a sum: the same coefficients, bit for bit, as component by component, as the
     ticket finish (option sep_sentinel = 0) and as the 17-launch order statistics / four-launch moments of the reset."""
     from triangular_transport_toolbox_amd import entf
     npz, desc = load_case('entf')
@@ -396,7 +397,7 @@ def test_filter_batch_without_threads_and_self_validating_sums_make_the_same_bit
         return out, [np.array(c) for c in tm.coeffs_mon], [np.array(c) for c in tm.coeffs_nonmon]
     base = run()
     assert relerr(base[0], npz['ens_0_2']) < 1e-6
-    for other in (run(threads=1), run(sep_sentinel=0), run(select_coop=0)):
+    for other in (run(threads=1), run(sep_sentinel=0), run(select_coop=0), run(sep_server=0)):
         assert np.array_equal(other[0], base[0])
         for a, b in zip(other[1] + other[2], base[1] + base[2]):
             assert np.array_equal(a, b)
@@ -425,6 +426,64 @@ def test_a_finishing_workgroup_that_gives_up_fails_the_loop_and_leaves_nothing_b
     tm.optimize()
     for k in range(tm.D):
         assert np.array_equal(tm.coeffs_mon[k], ref.coeffs_mon[k]) and np.array_equal(tm.coeffs_nonmon[k], ref.coeffs_nonmon[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['c2b_sep', 'c3_sep', 'c5_sep'])
+def test_evaluation_server_equals_a_launch_per_evaluation(name, ttm_opt):
+    """optimize() of separable maps at sizes whose grids have at most 128 workgroups: every component with more than one monotone
+    term gets ONE launch for its whole loop (k_objective_sep_server, several of them side by side on the batch's streams, each with a
+    mailbox of its own) - the same coefficients, bit for bit, as with a launch per evaluation; the servers have left when optimize()
+    returns (the stream is idle again at once) and a second optimize() finds mailboxes."""
+    import time
+    import torch
+    npz, desc = load_case(name)
+    runs = {}
+    for opt in (0, -1, -1):
+        ttm_opt('sep_server', opt)
+        tm = make_tm(name, npz, desc, with_coeffs=False)
+        tm.optimize()
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.05                  # (no server waiting for its 0.2 s to run out)
+        runs.setdefault(opt, []).append(([np.array(c) for c in tm.coeffs_mon], [np.array(c) for c in tm.coeffs_nonmon], tm.objective_total))
+    ref = runs[0][0]
+    for got in runs[-1]:
+        for a, b in zip(got[0] + got[1], ref[0] + ref[1]):
+            assert np.array_equal(a, b)
+        assert got[2] == ref[2]
+
+
+@pytest.mark.gpu
+def test_an_evaluation_server_that_was_left_waiting_is_replaced(tmp_path):
+    """The resident workgroups of an evaluation server leave when no request arrives for 0.2 s (a host that went away must not leave
+    waves behind).  A host thread that merely was not scheduled for that long (TTM_SRV_TEST_STALL = 5: 0.3 s in front of the fifth
+    request of every loop; read when the library loads, hence a process of its own) finds the stream idle and its request
+    unanswered, starts a new server and asks again: the same coefficients, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_transport_map import make_tm\n"
+        "from tests.util import load_case\n"
+        "npz, desc = load_case('c3_sep')\n"
+        "tm = make_tm('c3_sep', npz, desc, with_coeffs=False)\n"
+        "tm.optimize()\n"
+        "np.save(sys.argv[1], np.concatenate([np.concatenate((tm.coeffs_nonmon[k], tm.coeffs_mon[k])) for k in range(tm.D)]))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, stall in (('plain', None), ('stalled', '5')):
+        env = dict(os.environ)
+        env.pop('TTM_SRV_TEST_STALL', None)
+        if stall:
+            env['TTM_SRV_TEST_STALL'] = stall
+        path = str(tmp_path / (tag + '.npy'))
+        res = subprocess.run([sys.executable, '-c', script, path], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[tag] = np.load(path)
+    assert np.array_equal(out['plain'], out['stalled'])
 
 
 def test_ents_backward_smoother_matches_reference(backend):

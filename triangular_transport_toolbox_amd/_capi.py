@@ -89,6 +89,9 @@ _SIGNATURES = {
     'ttm_stream_synchronize': (ctypes.c_int, [c_vp]),
     'ttm_roundtrip': (ctypes.c_int, [ctypes.POINTER(ttm_program), c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                                      c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'ttm_mailbox_acquire': (c_vp, []),
+    'ttm_mailbox_release': (None, [c_vp]),
+    'ttm_objective_sep_server_start': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_dbl, c_vp, c_vp, c_vp, ctypes.c_uint32, c_vp]),
     'ttm_sentinel_fill': (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
     'ttm_objective_sep_cached_sent': (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_dbl, c_vp, c_vp, c_vp]),
     'ttm_objective_sep_direct_sent': (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp]),

@@ -18,6 +18,7 @@
 // do not depend on dispatch order or workgroup->XCD placement.
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -2493,6 +2494,100 @@ __global__ __launch_bounds__(256) void k_objective_sep_cached(const double* __re
     }
 }
 
+// THE EVALUATION SERVER of a host optimiser loop (grids of up to 128 workgroups; the filter's 37-evaluation chains): ONE
+// launch for the whole loop.  A launch per evaluation costs 6.2 us of launch + completion round trip even for an empty kernel;
+// a request posted by the host into a mailbox in DEVICE memory (fine-grained VRAM, written by the host through the PCIe BAR: posted
+// writes, pushed out by sfence) and polled there by resident workgroups costs 2.6-3.7 us (tools/micro/mailbox.cpp, 1 / 98
+// polling workgroups).  [Round 3 polled a mailbox in HOST memory: every poll a non-posted PCIe read - 27-94 us per request.]
+//   box:  [0] = generation << 32 | request number r = 1, 2, ... (0xffffffff: leave), [1 ..] the M trial coefficients - written by
+//         the host behind each other (coefficients, sfence, word, sfence).  The generation is the loop's (a process-wide counter):
+//         a word of an OLDER generation is what the mailbox's last user left (keep waiting), of a NEWER one a later loop's - this
+//         server was forgotten: leave;
+//   every workgroup waits for request r (bounded: TTM_SRV_TICKS of the 100 MHz wall clock - a host that went away lets the grid
+//   drain), adds its rows and stores its partial sums into region r mod 2 of the armed rows; workgroup 0 finishes the request as
+//   sentinel_finish does (the same order of the sums: the same bits as a launch per evaluation) and re-arms the region; it drains
+//   its stores BEHIND the results, so a region is clean before the request after next can write it.
+#define TTM_SRV_QUIT (~0ull)
+#define TTM_SRV_TICKS 20000000ll                      /* 0.2 s */
+
+template <int M>
+__global__ __launch_bounds__(256) void k_objective_sep_server(const double* __restrict__ dPsi, int64_t ldp, int64_t N, double delta,
+                                                              double* __restrict__ partial, double* __restrict__ out,
+                                                              const unsigned long long* box, unsigned int gen, int give_up) {
+    __shared__ double red[4][M + 1];
+    __shared__ double all_s[TTM_SENT_WGS * (M + 1)];
+    __shared__ double fin_s[M + 1];
+    __shared__ double s_c[M];
+    __shared__ unsigned long long s_seq;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int nacc = 1 + M;
+    const int region = (int)gridDim.x * nacc;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (unsigned long long r = 1;; ++r) {
+        if (tid == 0) {
+            unsigned long long v = 0;
+            const long long t0 = wall_clock64();
+            for (int spin = 0;; ++spin) {
+                v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned int vg = (unsigned int)(v >> 32), vr = (unsigned int)v;
+                if (vg == gen && vr >= (unsigned int)r) { v = vr == 0xffffffffu ? TTM_SRV_QUIT : v; break; }   // (the request, or "leave")
+                if (vg > gen) { v = TTM_SRV_QUIT; break; }
+                if ((spin & 255) == 255 && wall_clock64() - t0 > TTM_SRV_TICKS) { v = TTM_SRV_QUIT; break; }
+            }
+            s_seq = v;
+        }
+        __syncthreads();
+        if (s_seq == TTM_SRV_QUIT) return;
+        if (tid < M) s_c[tid] = __hip_atomic_load((const double*)(box + 1) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        double cc[M], acc[M + 1];
+#pragma unroll
+        for (int i = 0; i < M; ++i) cc[i] = s_c[i];
+#pragma unroll
+        for (int i = 0; i <= M; ++i) acc[i] = 0.0;
+        auto row = [&](const double (&d)[M]) {
+            double dS = 0.0, rowsum = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                dS = fma(cc[i], d[i], dS);
+                rowsum += d[i];
+            }
+            dS += rowsum * delta;
+            acc[0] += fast_log(dS);
+            const double inv = fast_rcp(dS);
+#pragma unroll
+            for (int i = 0; i < M; ++i) acc[1 + i] += d[i] * inv;
+        };
+        int64_t n = (int64_t)blockIdx.x * blockDim.x + tid;
+        for (; n + stride < N; n += 2 * stride) {
+            double d0[M], d1[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) { d0[i] = dPsi[(int64_t)i * ldp + n]; d1[i] = dPsi[(int64_t)i * ldp + n + stride]; }
+            row(d0);
+            row(d1);
+        }
+        if (n < N) {
+            double d0[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) d0[i] = dPsi[(int64_t)i * ldp + n];
+            row(d0);
+        }
+#pragma unroll
+        for (int i = 0; i <= M; ++i) {
+            const double v = wave_sum(acc[i]);
+            if (lane == 0) red[wv][i] = v;
+        }
+        __syncthreads();
+        double* rows = partial + (int)(r & 1ull) * region;
+        if (tid < nacc) coherent_store(rows + (int64_t)blockIdx.x * nacc + tid, (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+        if (blockIdx.x == 0) {
+            sentinel_finish(rows, nacc, all_s, fin_s, out, give_up != 0);
+            drain_stores();                            // (results out and the region re-armed before this workgroup takes the next request)
+        }
+        __syncthreads();
+    }
+}
+
 // The same reduction with the derivative basis RECOMPUTED from the x_k column: every monotone term of the component is
 // a plain special term of x_k (LET / RET / RBF / iRBF; kinds[i], pars[5 i ..] = its constants, in coefficient order), so
 // a row costs 8 bytes of HBM instead of 8 M and ~25 instructions per term (st_eval - the very code ttm_basis runs, hence
@@ -2849,6 +2944,7 @@ static const DeviceInfo& device_info() {
     X(colstats_one, -1)  /* 0: column moments by four launches (k_colsum / k_colfinish) whatever the shape                        */ \
     X(sep_sentinel, -1)  /* 0: the evaluations of ttm_optimize_separable with ticket and completion mark whatever the grid;       \
                             2: tests - the finishing workgroup gives up at once (the failure pattern reaches the host)            */ \
+    X(sep_server, -1)    /* 0: the loops of ttm_optimize_separable launch per evaluation instead of ONE evaluation server per loop      */ \
     X(roundtrip_fused, -1) /* 0: ttm_roundtrip declines (the caller makes the forward and the inverse call); 1: the fused kernel for \
                               every shape it can run, also those it is slower for (reach of three columns, density terms)          */
 struct Tuning {
@@ -3923,10 +4019,59 @@ int ttm_sentinel_fill(double* work, int32_t m, int64_t N, void* stream) {
     if (!work || m < 1 || m > TTM_SEPC_MAXM || N < 1) return set_err(TTM_E_ARG, "ttm_sentinel_fill: bad arguments%s");
     const int nb = grid_for(N, 256 * 4);
     if (nb > TTM_SENT_WGS || tuning().sep_sentinel == 0) return TTM_E_UNSUPPORTED;
-    const int n = nb * (1 + m);
+    const int n = 2 * nb * (1 + m);                   // (two regions: the evaluation server alternates between them)
     hipLaunchKernelGGL(k_fill_bits, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)(work + TTM_OBJ_FOLD_MAX), n,
                        (unsigned long long)TTM_SENT_BITS);
     return check_launch("k_fill_bits");
+}
+
+// The evaluation server of ttm_optimize_separable (k_objective_sep_server): one launch for a whole optimiser loop; box: a mailbox
+// from ttm_mailbox_acquire.  TTM_E_UNSUPPORTED: a grid of more than 128 workgroups, option sep_server = 0.
+int ttm_objective_sep_server_start(const double* dPsi, int64_t ldp, int64_t N, int32_t m, double delta, double* work, double* out_host,
+                                   const void* box, uint32_t gen, void* stream) {
+    if (!dPsi || !work || !out_host || !box || N < 1 || ldp < N || m < 1 || m > TTM_SEPC_MAXM)
+        return set_err(TTM_E_ARG, "ttm_objective_sep_server_start: bad arguments%s");
+    const int nb = grid_for(N, 256 * 4);
+    if (nb > TTM_SENT_WGS || tuning().sep_sentinel == 0 || tuning().sep_server == 0) return TTM_E_UNSUPPORTED;
+    typedef void (*vkern_t)(const double*, int64_t, int64_t, double, double*, double*, const unsigned long long*, unsigned int, int);
+    static const vkern_t kerns[TTM_SEPC_MAXM] = {
+        k_objective_sep_server<1>, k_objective_sep_server<2>, k_objective_sep_server<3>, k_objective_sep_server<4>,
+        k_objective_sep_server<5>, k_objective_sep_server<6>, k_objective_sep_server<7>, k_objective_sep_server<8>,
+        k_objective_sep_server<9>, k_objective_sep_server<10>, k_objective_sep_server<11>, k_objective_sep_server<12>,
+        k_objective_sep_server<13>, k_objective_sep_server<14>, k_objective_sep_server<15>, k_objective_sep_server<16>};
+    hipLaunchKernelGGL(kerns[m - 1], dim3(nb), dim3(256), 0, (hipStream_t)stream, dPsi, ldp, N, delta, work + TTM_OBJ_FOLD_MAX, out_host,
+                       (const unsigned long long*)box, (unsigned int)gen, tuning().sep_sentinel == 2 ? 1 : 0);
+    return check_launch("k_objective_sep_server");
+}
+
+// Mailboxes of the evaluation servers: 256-byte slots of ONE fine-grained device allocation per process (host-writable through the
+// PCIe BAR; hipExtMallocWithFlags), handed out and taken back under a lock.  NULL: none to be had (no such memory on this
+// platform, or all 64 in use) - the caller launches per evaluation.
+static std::mutex g_box_lock;
+static unsigned char* g_box_pool = nullptr;
+static unsigned long long g_box_used = 0;
+static bool g_box_tried = false;
+void* ttm_mailbox_acquire(void) {
+    std::lock_guard<std::mutex> g(g_box_lock);
+    if (!g_box_tried) {
+        g_box_tried = true;
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, 64 * 256, hipDeviceMallocFinegrained) == hipSuccess && p) {
+            if (hipMemset(p, 0, 64 * 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess) g_box_pool = (unsigned char*)p;
+            else (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
+    if (!g_box_pool) return nullptr;
+    for (int i = 0; i < 64; ++i)
+        if (!(g_box_used >> i & 1ull)) { g_box_used |= 1ull << i; return g_box_pool + 256 * i; }
+    return nullptr;
+}
+void ttm_mailbox_release(void* box) {
+    if (!box) return;
+    std::lock_guard<std::mutex> g(g_box_lock);
+    const long i = ((unsigned char*)box - g_box_pool) / 256;
+    if (g_box_pool && i >= 0 && i < 64) g_box_used &= ~(1ull << i);
 }
 
 int ttm_objective_sep_cached_sent(const double* dPsi, int64_t ldp, int64_t N, int32_t m, const double* h_coef_mon, double delta,

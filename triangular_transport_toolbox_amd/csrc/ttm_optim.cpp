@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -21,6 +22,7 @@
 
 #ifndef TTM_HOST_ONLY          // (tests/hostemu compiles this file for the host: no streams, nothing to wait for)
 #include <hip/hip_runtime.h>
+#include <immintrin.h>
 #endif
 
 #include "../../include/ttm.h"
@@ -60,7 +62,8 @@ void arm_values(double* v_, int n) {
     for (int i = 0; i < n; ++i) v[i].store(kSentBits, std::memory_order_relaxed);
     std::atomic_thread_fence(std::memory_order_release);
 }
-int poll_values(const double* v_, int n, void* stream) {
+int poll_values(const double* v_, int n, void* stream, bool* unanswered = nullptr) {
+    if (unanswered) *unanswered = false;
     const std::atomic<uint64_t>* v = reinterpret_cast<const std::atomic<uint64_t>*>(v_);
     static_assert(sizeof(std::atomic<uint64_t>) == sizeof(double), "lock-free 64-bit atomics expected");
     auto pending = [&]() {
@@ -74,7 +77,10 @@ int poll_values(const double* v_, int n, void* stream) {
         const hipError_t st = hipStreamQuery((hipStream_t)stream);
         if (st == hipErrorNotReady) continue;
         if (st == hipSuccess) (void)hipStreamSynchronize((hipStream_t)stream);
-        if (pending()) return TTM_E_HIP;
+        if (pending()) {
+            if (unanswered) *unanswered = st == hipSuccess;      // (an idle stream and no results: nobody is going to answer)
+            return TTM_E_HIP;
+        }
 #else
         (void)stream;
         return TTM_E_HIP;
@@ -226,11 +232,15 @@ namespace {
 // rounding (1e-16 relative, like the order of a reduction), no launch, no round trip.  `delta` < 0 switches it off.
 typedef int (*SentLaunch)(const double* cc, double* out_host, void* stream, void* user);
 
+// what the evaluation server of a loop needs (ttm_objective_sep_server_start; cached derivative basis only)
+struct ServerArgs { const double* dPsi; int64_t ldp, N; int32_t m; double delta; double* work; };
+std::atomic<uint32_t> g_server_gen{0};
+
 template <class Launch>
 int optimize_separable_with(Launch launch, int32_t m, const double* A, const double* b, double Ntotal, const double* lb,
                             const double* ub, double* x, double* sums_dev, double* sums_host, ttm_comm* comm, void* stream,
                             int32_t maxiter, double* result, double delta = -1.0, SentLaunch sent = nullptr, void* sent_user = nullptr,
-                            const double* pre_x = nullptr) {
+                            const double* pre_x = nullptr, const ServerArgs* server = nullptr) {
     struct Ctx {
         Launch& launch;
         const double *A, *b;
@@ -245,8 +255,12 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         SentLaunch sent;                                     // the evaluation with self-validating results (no ticket, no mark)
         void* sent_user;
         const double* pre_x;                                 // an evaluation at this point is in flight already (its results
-    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,   // arrive in sums_host, armed)
-        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false, comm ? nullptr : sent, sent_user, (sent && !comm) ? pre_x : nullptr};
+        const ServerArgs* server;                            // arrive in sums_host, armed); ONE launch answers every evaluation of the loop
+        unsigned char* box;                                  //   its mailbox (fine-grained device memory, host-written), once it runs
+        uint32_t gen, round;
+    } c{launch, A, b, 1.0 / Ntotal, sums_dev, sums_host, comm, stream, 0, 0, delta, 0.0, 0.0,
+        m == 1 && delta >= 0.0 && lb && lb[0] >= 0.0, false, comm ? nullptr : sent, sent_user, (sent && !comm) ? pre_x : nullptr,
+        (sent && !comm && m > 1) ? server : nullptr, nullptr, 0, 0};
     if (!c.pre_x) sums_host[1 + m] = 0.0;                    // the completion mark (sums_host: >= 2 + m doubles)
     auto fun = [](int32_t n, const double* cc, double* f, double* g, void* user) -> int32_t {
         Ctx& c = *(Ctx*)user;
@@ -259,10 +273,49 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
             c.rc = poll_values(c.sums_host, 1 + n, c.stream);
             if (c.rc) return c.rc;
         }
+#ifndef TTM_HOST_ONLY
+        if (!have && c.server && !c.box) {                   // the first evaluation of the loop: start its server
+            c.box = (unsigned char*)ttm_mailbox_acquire();
+            if (c.box) {
+                c.gen = ++g_server_gen;
+                c.round = 0;
+                const ServerArgs& a = *c.server;
+                const int rc = ttm_objective_sep_server_start(a.dPsi, a.ldp, a.N, a.m, a.delta, a.work, c.sums_host, c.box, c.gen, c.stream);
+                if (rc != TTM_OK) { ttm_mailbox_release(c.box); c.box = nullptr; }
+            }
+            if (!c.box) c.server = nullptr;                  // (no mailbox / a larger grid / switched off: a launch per evaluation)
+        }
+#endif
         if (have) {
         } else if (c.closed && c.have0 && cc[0] + c.delta > 0.0) {
             c.sums_host[0] = c.Nw * log(cc[0] + c.delta) + c.KN;
             c.sums_host[1] = c.Nw / (cc[0] + c.delta);
+#ifndef TTM_HOST_ONLY
+        } else if (c.box) {
+            // request: the coefficients, then - behind a store fence: the mailbox is a write-combining mapping - the word that
+            // announces them; the results arrive where a launch per evaluation puts them
+            // (tests: TTM_SRV_TEST_STALL = k makes the host miss the server's 0.2 s in front of request k of every loop)
+            static const int stall_at = [] { const char* e = getenv("TTM_SRV_TEST_STALL"); return e ? atoi(e) : 0; }();
+            if (stall_at > 0 && (int)c.round + 1 == stall_at) std::this_thread::sleep_for(std::chrono::milliseconds(300));
+            for (int attempt = 0;; ++attempt) {
+                arm_values(c.sums_host, 1 + n);
+                volatile double* bc = (volatile double*)(c.box + 8);
+                for (int i = 0; i < n; ++i) bc[i] = cc[i];
+                _mm_sfence();
+                *(volatile uint64_t*)c.box = ((uint64_t)c.gen << 32) | (uint64_t)(++c.round);
+                _mm_sfence();
+                bool unanswered = false;
+                c.rc = poll_values(c.sums_host, 1 + n, c.stream, &unanswered);
+                if (!c.rc || !unanswered || attempt >= 2) break;
+                // no answer and the stream idle: the server waited 0.2 s for this request (a host thread that was not scheduled) and
+                // left - both regions of the rows armed, as it leaves them between requests.  A new one takes over.
+                const ServerArgs& a = *c.server;
+                c.gen = ++g_server_gen;
+                c.round = 0;
+                if (ttm_objective_sep_server_start(a.dPsi, a.ldp, a.N, a.m, a.delta, a.work, c.sums_host, c.box, c.gen, c.stream) != TTM_OK) break;
+            }
+            if (c.rc) return c.rc;
+#endif
         } else if (c.sent) {
             arm_values(c.sums_host, 1 + n);
             c.rc = c.sent(cc, c.sums_host, c.stream, c.sent_user);
@@ -305,6 +358,13 @@ int optimize_separable_with(Launch launch, int32_t m, const double* A, const dou
         return 0;
     };
     const int rc = ttm_lbfgsb_minimize(m, x, lb, ub, fun, &c, maxiter, result);
+#ifndef TTM_HOST_ONLY
+    if (c.box) {                                             // the loop is over: the server leaves (and would by itself after 0.2 s)
+        *(volatile uint64_t*)c.box = ((uint64_t)c.gen << 32) | 0xffffffffull;
+        _mm_sfence();
+        ttm_mailbox_release(c.box);
+    }
+#endif
     return c.rc ? c.rc : rc;
 }
 
@@ -333,8 +393,9 @@ int optimize_separable_cached(const double* dPsi, int64_t ldp, int64_t N, int32_
             const SentArgs& a = *(const SentArgs*)user;
             return ttm_objective_sep_cached_sent(a.dPsi, a.ldp, a.N, a.m, cc, a.delta, a.work, out_host, st);
         };
+    const ServerArgs srv{dPsi, ldp, N, m, delta, work};
     const int rc = optimize_separable_with(launch, m, A, b, Ntotal, lb, ub, x, sums_dev, sums_host, comm, stream, maxiter, result,
-                                           closed_form_enabled() ? delta : -1.0, sent, &sa, pre_x);
+                                           closed_form_enabled() ? delta : -1.0, sent, &sa, pre_x, sent ? &srv : nullptr);
     if (armed) *armed = (sent && rc == TTM_OK) ? 1 : 0;
     return rc;
 }

@@ -1645,8 +1645,18 @@ class transport_map():
             return
         try:
             self._gram_many(list(hint[0]), launch_only=True)
+            self._bases_inflight = None
+            if hint[2] is not None and hint[3] == int(self._N) and hint[4] == int(self._Xs.shape[1]):
+                # (the cached derivative bases of the same batch: the closure of the optimize() that left the hint launches them
+                # into the buffers it keeps - laid out for the same number of samples)
+                hint[2](ahead=True)
         except Exception:                               # noqa: BLE001  (a hint, never an error: optimize() launches them itself)
             self._gram_inflight = None
+            self._bases_inflight = None
+
+    def _ahead_token(self):
+        """What the kernels launched ahead by a reset depend on: the samples, their number, the special-term constants, the map."""
+        return (id(self._cm), id(self._Xs), int(self._N), getattr(self, '_dpar_version', 0))
 
     def separable_setup(self, k, G=None):
         """The reduced separable problem of TM:2959-3050 from the Gram matrix of
@@ -2138,11 +2148,17 @@ class transport_map():
             if scr is None or scr[0] != skey:
                 wsz = int(self._lib.ttm_reduce_work_size(17))
                 scr = self._sep_batch_scratch = (skey, wsz, self._empty(n * wsz), self._zeros(n * 16, dtype=torch.int32),
-                                                 torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {}, {})
-            _, wsz, work, counters, sums, dpsi_keep, armed = scr
+                                                 torch.zeros(n * 32, dtype=torch.float64, pin_memory=self._dev.type == 'cuda'), {}, {}, {})
+            _, wsz, work, counters, sums, dpsi_keep, armed, host_keep = scr
 
-            def launch_bases():
+            def launch_bases(ahead=False):
                 # the cached derivative bases: queued behind the Gram kernels, in front of the host's wait for the matrices
+                # (or launched ahead with them by the reset that placed the special terms - _gram_ahead -, into THESE buffers)
+                token = (self._ahead_token(), tuple(batch), id(dpsi_keep))
+                if not ahead and getattr(self, '_bases_inflight', None) == token:
+                    self._bases_inflight = None
+                    return
+                self._bases_inflight = token if ahead else None
                 for k in batch:
                     if direct[k] is None:
                         m = int(self._cm.n_mon[k])
@@ -2152,9 +2168,15 @@ class transport_map():
                         _capi.check(self._lib.ttm_basis(self._pp, int(k), 2, self._ptr(self._Xs), self._Xs.shape[1], self._N,
                                                         self._ptr(dpsi), dpsi.shape[1], self._stream()))
             grams = self._gram_many(batch, before_read=launch_bases)
-            # (a reset of the same map launches these matrices ahead: _gram_ahead)
-            self._gram_hint = (tuple(batch), id(self._cm)) if len(batch) == len(K) else None
-            tasks = (_capi.ttm_sep_task * n)()
+            # (a reset of the same map launches these matrices - and the bases, once their buffers exist - ahead: _gram_ahead)
+            self._gram_hint = (tuple(batch), id(self._cm), launch_bases if not any(direct[k] is not None for k in batch) else None,
+                               int(self._N), int(self._Xs.shape[1])) if len(batch) == len(K) else None
+            # the task structures and the host vectors they point to are kept with the scratch: values are written in place
+            tasks = host_keep.get('tasks')
+            fresh = tasks is None
+            if fresh:
+                tasks = host_keep['tasks'] = (_capi.ttm_sep_task * n)()
+                host_keep['vec'] = {}
             keep = []
             # special-term kinds and constants of the components that recompute their basis: one upload for the batch
             kinds_all, pars_all, where = [], [], {}
@@ -2171,13 +2193,23 @@ class transport_map():
                 A, solve_nonmon = self.separable_setup(k, G=grams[k])
                 m = int(self._cm.n_mon[k])
                 dpsi = dpsi_keep[k] if direct[k] is None else None
-                A = np.ascontiguousarray(A, dtype=float)
-                b = np.ascontiguousarray(self.delta * np.sum(A, axis=-1))
-                x = np.array(self.coeffs_mon[k], dtype=float, copy=True)
-                lb = np.array([-np.inf if v is None else v for v in self.optimization_constraints_lb[k]], dtype=float)
-                ub = np.array([np.inf if v is None else v for v in self.optimization_constraints_ub[k]], dtype=float)
+                vec = host_keep['vec'].get(k)
+                if vec is None or vec[0].shape != (m, m):
+                    vec = host_keep['vec'][k] = (np.empty((m, m)), np.empty(m), np.empty(m),
+                                                 np.array([-np.inf if v is None else v for v in self.optimization_constraints_lb[k]], dtype=float),
+                                                 np.array([np.inf if v is None else v for v in self.optimization_constraints_ub[k]], dtype=float))
+                    fresh = True
+                Ab, b, x, lb, ub = vec
+                Ab[...] = A
+                A = Ab
+                b[...] = self.delta * np.sum(A, axis=-1)
+                x[...] = self.coeffs_mon[k]
                 keep.append((A, b, x, lb, ub, dpsi, solve_nonmon))
                 t = tasks[i]
+                if not fresh and direct[k] is None:
+                    t.dPsi, t.ldp = dpsi.data_ptr(), dpsi.shape[1]
+                    t.armed = armed.get(k, 0)
+                    continue                             # (every other pointer of the task is what it was)
                 t.m = m
                 if dpsi is not None:
                     t.dPsi, t.ldp = dpsi.data_ptr(), dpsi.shape[1]
