@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <setjmp.h>
+#include <signal.h>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -4051,13 +4053,33 @@ static std::mutex g_box_lock;
 static unsigned char* g_box_pool = nullptr;
 static unsigned long long g_box_used = 0;
 static bool g_box_tried = false;
+static sigjmp_buf g_box_jmp;
+static void box_fault(int) { siglongjmp(g_box_jmp, 1); }
 void* ttm_mailbox_acquire(void) {
     std::lock_guard<std::mutex> g(g_box_lock);
     if (!g_box_tried) {
         g_box_tried = true;
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, 64 * 256, hipDeviceMallocFinegrained) == hipSuccess && p) {
-            if (hipMemset(p, 0, 64 * 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess) g_box_pool = (unsigned char*)p;
+            bool ok = hipMemset(p, 0, 64 * 256) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            if (ok) {
+                // the one thing the servers need from the platform: a HOST store into this memory (a system without a large PCIe
+                // BAR maps none of it).  Probed once, with the fault caught: no mailboxes then, a launch per evaluation.
+                struct sigaction sa, old_segv, old_bus;
+                memset(&sa, 0, sizeof(sa));
+                sa.sa_handler = box_fault;
+                sigemptyset(&sa.sa_mask);
+                sigaction(SIGSEGV, &sa, &old_segv);
+                sigaction(SIGBUS, &sa, &old_bus);
+                ok = false;
+                if (sigsetjmp(g_box_jmp, 1) == 0) {
+                    *(volatile unsigned long long*)p = 0ull;
+                    ok = true;
+                }
+                sigaction(SIGSEGV, &old_segv, nullptr);
+                sigaction(SIGBUS, &old_bus, nullptr);
+            }
+            if (ok) g_box_pool = (unsigned char*)p;
             else (void)hipFree(p);
         }
         (void)hipGetLastError();
